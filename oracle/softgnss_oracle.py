@@ -1,0 +1,329 @@
+"""CPU oracle for the GPS L1 C/A acquisition + tracking hot path.  TEST INFRASTRUCTURE ONLY.
+
+This is a numpy restatement of the algorithm of perrysou/SoftGNSS-python (reference files
+initialize.py, acquisition.py, tracking.py), written in this repo's own words, keeping the
+reference's IEEE-754 operation order wherever a rounding function (ceil/floor/%/argmax)
+follows.  Each function cites the reference lines it follows.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module,
+and only as the checker / the timed CPU baseline.  The product path (softgnss-python_amd/)
+never imports it and fails loudly when its HIP library is missing.
+
+Pinning: the oracle is checked bit-for-bit against outputs of the reference itself
+(tests/golden/*.npz, produced by tests/golden/make_golden.py which imports a lib2to3-converted
+throw-away copy of /root/reference in the build container) by tests/test_oracle_golden.py.
+Third-party arithmetic (numpy.fft = pocketfft, np.sin/cos/linspace) is *called*, not restated,
+with numpy 2.2.6 - the version the goldens were captured with.
+"""
+import numpy as np
+
+NUM_SERIES = 13
+SERIES = ("absoluteSample", "codeFreq", "carrFreq", "I_P", "I_E", "I_L", "Q_E", "Q_P", "Q_L",
+          "dllDiscr", "dllDiscrFilt", "pllDiscr", "pllDiscrFilt")
+
+
+class OracleSettings(object):
+    """Attribute bag with the reference's names and defaults (initialize.py:85-173)."""
+
+    def __init__(self, **kw):
+        self.msToProcess = 37000.0
+        self.numberOfChannels = 8
+        self.skipNumberOfBytes = 0
+        self.dataType = 'int8'
+        self.IF = 9548000.0
+        self.samplingFreq = 38192000.0
+        self.codeFreqBasis = 1023000.0
+        self.codeLength = 1023
+        self.acqSatelliteList = range(1, 33)
+        self.acqSearchBand = 14.0
+        self.acqThreshold = 2.5
+        self.dllDampingRatio = 0.7
+        self.dllNoiseBandwidth = 2.0
+        self.dllCorrelatorSpacing = 0.5
+        self.pllDampingRatio = 0.7
+        self.pllNoiseBandwidth = 25.0
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+    @property
+    def samplesPerCode(self):
+        # initialize.py:183-185
+        return int(np.round(self.samplingFreq / (self.codeFreqBasis / self.codeLength)))
+
+
+G2_DELAY = (5, 6, 7, 8, 17, 18, 139, 140, 141, 251, 252, 254, 255, 256, 257, 258,
+            469, 470, 471, 472, 473, 474, 509, 512, 513, 514, 515, 516, 859, 860, 861, 862)
+
+
+def generate_ca_code(prn0):
+    """float64[1023] of +-1.0 for PRN index 0..31.  Follows initialize.py:234-302.
+
+    Two 10-stage registers of +-1 loaded with -1; output is the last stage; G1 feedback
+    stage3*stage10, G2 feedback stage2*3*6*8*9*10; G2 rotated right by the PRN's delay;
+    code = -(g1*g2).
+    """
+    if prn0 not in range(0, 32):
+        raise AssertionError("prn index out of range")  # initialize.py:250
+    g1 = np.zeros(1023)
+    g2 = np.zeros(1023)
+    ra = [-1.0] * 10
+    rb = [-1.0] * 10
+    for i in range(1023):
+        g1[i] = ra[9]
+        g2[i] = rb[9]
+        fa = ra[2] * ra[9]
+        fb = rb[1] * rb[2] * rb[5] * rb[7] * rb[8] * rb[9]
+        ra = [fa] + ra[:9]
+        rb = [fb] + rb[:9]
+    d = G2_DELAY[prn0]
+    g2 = np.concatenate((g2[1023 - d:], g2[:1023 - d]))
+    return -g1 * g2
+
+
+def ca_table_index(s):
+    """Chip index of every sample of one code period.  Follows initialize.py:210-226 (A3).
+
+    idx[k-1] = ceil((ts*k)/tc) - 1 for k = 1..N, last entry forced to 1022.  Multiply then
+    divide, both rounded: the value sits exactly on a chip boundary every 112 samples and
+    the fp64 result is what decides the index there.
+    """
+    n = s.samplesPerCode
+    ts = 1.0 / s.samplingFreq
+    tc = 1.0 / s.codeFreqBasis
+    idx = np.ceil(ts * np.arange(1, n + 1) / tc) - 1
+    idx = idx.astype(np.int64)
+    idx[-1] = 1022
+    return idx
+
+
+def make_ca_table(s):
+    """float64[32, N] sampled codes (initialize.py:188-231)."""
+    idx = ca_table_index(s)
+    out = np.zeros((32, s.samplesPerCode))
+    for p in range(32):
+        out[p] = generate_ca_code(p)[idx]
+    return out
+
+
+def calc_loop_coef(lbw, zeta, k):
+    """(tau1, tau2) of the 2nd-order loop filter (initialize.py:304-328)."""
+    wn = lbw * 8.0 * zeta / (4.0 * zeta ** 2 + 1)
+    return k / (wn * wn), 2.0 * zeta / wn
+
+
+def exclusion_index(code_phase, n, spc):
+    """Index list searched for the second peak (acquisition.py:147-159, A8b).
+
+    Kept quirks: a first-branch list that reaches index n raises IndexError when used
+    (code_phase == spc, Q5); a second-branch list may start at -1 (wraps to n-1).
+    """
+    e1 = code_phase - spc
+    e2 = code_phase + spc
+    if e1 <= 0:
+        return np.arange(e2, n + e1 + 1)
+    if e2 >= n - 1:
+        return np.arange(e2 - n, e1)
+    return np.concatenate((np.arange(0, e1 + 1), np.arange(e2, n)))
+
+
+def freq_bins(s):
+    """Carrier grid (acquisition.py:68,99-101, A4)."""
+    nb = int(np.round(s.acqSearchBand * 2) + 1)
+    return np.array([s.IF - s.acqSearchBand / 2 * 1000 + 500.0 * k for k in range(nb)])
+
+
+def acquire(s, long_signal, n_prn=None, n_blocks=2, noncoh=False, as_written=False):
+    """Parallel code-phase search + fine carrier estimate.  Follows acquisition.py:49-203.
+
+    n_prn      number of PRN indices searched (reference: len(acqSatelliteList), Q1).
+    n_blocks   1-ms blocks used by the coarse search (reference: 2).
+    noncoh     False = reference rule (keep the block with the larger maximum, A7);
+               True  = EXTENSION beyond the reference (BASELINE.json config 4): rows are the
+               sum of |corr|^2 over the n_blocks blocks.  This oracle is its definition.
+    as_written True recomputes the PRN-independent carrier mix and forward FFTs for every
+               PRN exactly as the reference does (same values; only used to time the
+               reference's own cost).
+    Returns a dict with the three reference outputs plus the internal indices.
+    """
+    x = np.asarray(long_signal)
+    n = s.samplesPerCode
+    if n_prn is None:
+        n_prn = len(s.acqSatelliteList)
+    sig0dc = x - x.mean()                                   # acquisition.py:59
+    ts = 1.0 / s.samplingFreq
+    phase_points = np.arange(n) * 2 * np.pi * ts            # acquisition.py:65 (A2)
+    bins = freq_bins(s)
+    nb = len(bins)
+    table = make_ca_table(s)
+    blocks = [x[b * n:(b + 1) * n] for b in range(n_blocks)]
+
+    def forward(k):
+        sc = np.sin(bins[k] * phase_points)                 # acquisition.py:103-105 (A5)
+        cc = np.cos(bins[k] * phase_points)
+        return [np.fft.fft(sc * blk + 1j * (cc * blk)) for blk in blocks]
+
+    fwd = None if as_written else [forward(k) for k in range(nb)]
+
+    carr = np.zeros(32)
+    cph = np.zeros(32)
+    metric = np.zeros(32)
+    fbin = np.full(32, -1, dtype=np.int64)
+    fine = np.full(32, -1, dtype=np.int64)
+    bsel = np.full((32, nb), -1, dtype=np.int64)
+    spc = int(round(s.samplingFreq / s.codeFreqBasis))       # acquisition.py:145
+    for p in range(n_prn):
+        code_fd = np.fft.fft(table[p]).conj()               # acquisition.py:95
+        res = np.zeros((nb, n))
+        for k in range(nb):
+            spec = forward(k) if as_written else fwd[k]
+            pw = [abs(np.fft.ifft(sp * code_fd)) ** 2 for sp in spec]   # acquisition.py:120-126 (A6)
+            if noncoh:
+                acc = pw[0]
+                for q in pw[1:]:
+                    acc = acc + q
+                res[k] = acc
+                bsel[p, k] = 0
+            else:
+                # acquisition.py:129-133 (A7) generalised left-to-right: later block wins ties
+                best = 0
+                for b in range(1, n_blocks):
+                    if not (pw[best].max() > pw[b].max()):
+                        best = b
+                res[k] = pw[best]
+                bsel[p, k] = best
+        fbi = int(res.max(1).argmax())                      # acquisition.py:139-140 (A8)
+        peak = res.max(0).max()
+        c = int(res.max(0).argmax())                        # acquisition.py:142-143
+        rng = exclusion_index(c, n, spc)
+        second = res[fbi, rng].max()                        # acquisition.py:162 (IndexError kept)
+        metric[p] = peak / second
+        fbin[p] = fbi
+        if peak / second > s.acqThreshold:                  # acquisition.py:166
+            code = generate_ca_code(p)
+            cvi = np.floor(ts * np.arange(1, 10 * n + 1) / (1.0 / s.codeFreqBasis))   # :172 (A9)
+            long_code = code[(cvi % 1023).astype(np.int64)]
+            xc = sig0dc[c:c + 10 * n] * long_code           # acquisition.py:177
+            npts = int(8 * 2 ** (np.ceil(np.log2(len(xc)))))
+            mag = np.abs(np.fft.fft(xc, npts))              # acquisition.py:182
+            uniq = int(np.ceil((npts + 1) / 2.0))
+            m = int(mag[4:uniq - 5].argmax())               # acquisition.py:187 (A10)
+            carr[p] = (np.arange(uniq) * s.samplingFreq / npts)[m]   # index not re-offset (Q3)
+            cph[p] = c
+            fine[p] = m
+    return dict(carrFreq=carr, codePhase=cph, peakMetric=metric, freqBin=fbin, fineIdx=fine, blockSel=bsel)
+
+
+def pre_run(s, acq):
+    """Channel table from acquisition results.  Follows acquisition.py:259-306 (a9).
+
+    Stable descending sort on peakMetric; the first min(numberOfChannels, #carrFreq>0) entries
+    become channels (PRN 1-based, 0 = off).
+    """
+    nch = int(s.numberOfChannels)
+    prn = np.zeros(nch, dtype=np.int64)
+    freq = np.zeros(nch)
+    cph = np.zeros(nch)
+    status = ['-'] * nch
+    order = sorted(enumerate(acq["peakMetric"]), key=lambda t: t[-1], reverse=True)
+    for i in range(min(nch, int(np.sum(acq["carrFreq"] > 0)))):
+        j = order[i][0]
+        prn[i] = j + 1
+        freq[i] = acq["carrFreq"][j]
+        cph[i] = acq["codePhase"][j]
+        status[i] = 'T'
+    return dict(PRN=prn, acquiredFreq=freq, codePhase=cph, status=status)
+
+
+def track(s, channels, record, ms=None):
+    """DLL/PLL tracking of every active channel.  Follows tracking.py:35-294.
+
+    record   int8 array holding the file from byte 0 (the reference seeks/reads a file object;
+             positions here are the same byte offsets).
+    Returns None on a short read (tracking.py:159-163), else a list with one dict per ACTIVE
+    channel (Q8) holding PRN, status and the 13 per-ms float64 series.
+    """
+    rec = np.asarray(record)
+    n_ms = int(s.msToProcess if ms is None else ms)
+    spc_el = s.dllCorrelatorSpacing
+    pdi = 0.001
+    t1c, t2c = calc_loop_coef(s.dllNoiseBandwidth, s.dllDampingRatio, 1.0)     # tracking.py:45
+    t1p, t2p = calc_loop_coef(s.pllNoiseBandwidth, s.pllDampingRatio, 0.25)    # tracking.py:52
+    fs = s.samplingFreq
+    out = []
+    for ch in range(int(s.numberOfChannels)):
+        if channels["PRN"][ch] == 0:
+            continue
+        ser = {k: (np.zeros(n_ms) if k in ("absoluteSample", "I_P", "I_E", "I_L", "Q_E", "Q_P", "Q_L")
+                   else np.inf * np.ones(n_ms)) for k in SERIES}       # tracking.py:65-94
+        pos = int(s.skipNumberOfBytes + channels["codePhase"][ch])     # tracking.py:107
+        code = generate_ca_code(int(channels["PRN"][ch]) - 1)
+        code = np.r_[code[-1], code, code[0]]                          # tracking.py:111
+        code_freq = s.codeFreqBasis
+        rem_code = 0.0
+        carr_freq = channels["acquiredFreq"][ch]
+        carr_basis = channels["acquiredFreq"][ch]
+        rem_carr = 0.0
+        old_code_nco = old_code_err = old_carr_nco = old_carr_err = 0.0
+        for it in range(n_ms):
+            step = code_freq / fs                                       # tracking.py:148 (T1)
+            blk = int(np.ceil((s.codeLength - rem_code) / step))
+            raw = rec[pos:pos + blk]                                    # tracking.py:154 (T2)
+            if len(raw) != blk:
+                return None
+            pos += blk
+            # tracking.py:166-188 (T3): three linspace ramps, ceil, gather
+            te = np.linspace(rem_code - spc_el, blk * step + rem_code - spc_el, blk, endpoint=False)
+            early = code[np.ceil(te).astype(np.int64)]
+            tl = np.linspace(rem_code + spc_el, blk * step + rem_code + spc_el, blk, endpoint=False)
+            late = code[np.ceil(tl).astype(np.int64)]
+            tp = np.linspace(rem_code, blk * step + rem_code, blk, endpoint=False)
+            prompt = code[np.ceil(tp).astype(np.int64)]
+            rem_code = tp[blk - 1] + step - 1023.0                      # tracking.py:190 (T4)
+            tm = np.arange(0, blk + 1) / fs                             # tracking.py:193 (T5)
+            arg = carr_freq * 2.0 * np.pi * tm + rem_carr
+            rem_carr = arg[blk] % (2 * np.pi)
+            ccos = np.cos(arg[0:blk])
+            csin = np.sin(arg[0:blk])
+            qbb = ccos * raw                                            # tracking.py:205-219 (T6)
+            ibb = csin * raw
+            i_e = (early * ibb).sum()
+            q_e = (early * qbb).sum()
+            i_p = (prompt * ibb).sum()
+            q_p = (prompt * qbb).sum()
+            i_l = (late * ibb).sum()
+            q_l = (late * qbb).sum()
+            with np.errstate(divide="ignore", invalid="ignore"):
+                carr_err = np.arctan(q_p / i_p) / 2.0 / np.pi           # tracking.py:223 (T7)
+            carr_nco = old_carr_nco + t2p / t1p * (carr_err - old_carr_err) + carr_err * (pdi / t1p)
+            old_carr_nco = carr_nco
+            old_carr_err = carr_err
+            carr_freq = carr_basis + carr_nco
+            ee = np.sqrt(i_e * i_e + q_e * q_e)                         # tracking.py:238 (T8)
+            ll = np.sqrt(i_l * i_l + q_l * q_l)
+            code_err = (ee - ll) / (ee + ll)
+            code_nco = old_code_nco + t2c / t1c * (code_err - old_code_err) + code_err * (pdi / t1c)
+            old_code_nco = code_nco
+            old_code_err = code_err
+            code_freq = s.codeFreqBasis - code_nco
+            ser["absoluteSample"][it] = pos                             # tracking.py:255 (T9)
+            ser["codeFreq"][it] = code_freq
+            ser["carrFreq"][it] = carr_freq
+            ser["I_P"][it] = i_p
+            ser["I_E"][it] = i_e
+            ser["I_L"][it] = i_l
+            ser["Q_E"][it] = q_e
+            ser["Q_P"][it] = q_p
+            ser["Q_L"][it] = q_l
+            ser["dllDiscr"][it] = code_err
+            ser["dllDiscrFilt"][it] = code_nco
+            ser["pllDiscr"][it] = carr_err
+            ser["pllDiscrFilt"][it] = carr_nco
+        ser["PRN"] = int(channels["PRN"][ch])
+        ser["status"] = channels["status"][ch]
+        out.append(ser)
+    return out
+
+
+def stack_series(tracks):
+    """[n_active, 13, ms] float64 view of track() output in SERIES order."""
+    return np.stack([np.stack([t[k] for k in SERIES]) for t in tracks])

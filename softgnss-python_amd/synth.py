@@ -1,0 +1,136 @@
+"""Deterministic, integer-only synthetic GPS L1 C/A IF record generator (host side).
+
+The reference ships no sample data (its default input is a path on the author's
+laptop, reference initialize.py:99), so parity tests and the bench need their own
+record.  Every sample is a pure function of (scene, sample index) computed with
+integer arithmetic only, so this numpy generator and the HIP generator in
+csrc/sgx_synth.hip produce bit-identical int8 streams.
+
+sample(n) = clip( noise(n) + sum_sat round(A * ca[chip(n)] * nav(n) * cosLUT[phase32(n) >> 24] / 128), -127, 127 )
+
+  noise(n)   : Irwin-Hall sum of 4 bytes of splitmix64(seed + (n+1)*GOLDEN), centred, * 35 >> 8  (sigma ~ 20 LSB)
+  phase32(n) : 32-bit carrier NCO, (ph0 + n * car_fcw) mod 2^32
+  chip(n)    : 32.32 fixed-point code NCO, ((n * code_fcw + code_c0) >> 32) mod 1023
+  nav(n)     : +-1 from splitmix64(nav_seed + (bit+1)*GOLDEN) & 1, one bit per 20 code periods
+"""
+import numpy as np
+
+GOLDEN = 0x9E3779B97F4A7C15
+MASK64 = (1 << 64) - 1
+MAX_SATS = 16
+NOISE_MUL = 35
+NOISE_SHIFT = 8
+L1_HZ = 1575.42e6
+
+
+def splitmix64(x):
+    """splitmix64 finaliser on a uint64 array (wraps mod 2^64)."""
+    x = np.asarray(x, dtype=np.uint64)
+    z = x.copy()
+    z ^= z >> np.uint64(30)
+    z *= np.uint64(0xBF58476D1CE4E5B9)
+    z ^= z >> np.uint64(27)
+    z *= np.uint64(0x94D049BB133111EB)
+    z ^= z >> np.uint64(31)
+    return z
+
+
+def ca_code_bits(prn0):
+    """1023-chip C/A Gold code as +-1 int8, PRN index 0..31 (IS-GPS-200 G2 delay form).
+
+    Integer LFSR statement of the sequence the reference builds in
+    initialize.py:234-302 (G1 taps 3,10; G2 taps 2,3,6,8,9,10; G2 delayed by g2s).
+    """
+    g2s = [5, 6, 7, 8, 17, 18, 139, 140, 141, 251, 252, 254, 255, 256, 257, 258,
+           469, 470, 471, 472, 473, 474, 509, 512, 513, 514, 515, 516, 859, 860, 861, 862]
+    if not 0 <= prn0 < 32:
+        raise ValueError("prn index must be in 0..31")
+    r1 = [1] * 10
+    r2 = [1] * 10
+    g1 = np.empty(1023, dtype=np.int8)
+    g2 = np.empty(1023, dtype=np.int8)
+    for i in range(1023):
+        g1[i] = r1[9]
+        g2[i] = r2[9]
+        f1 = r1[2] ^ r1[9]
+        f2 = r2[1] ^ r2[2] ^ r2[5] ^ r2[7] ^ r2[8] ^ r2[9]
+        r1 = [f1] + r1[:9]
+        r2 = [f2] + r2[:9]
+    g2 = np.roll(g2, g2s[prn0])
+    # bit 1 <-> chip +1 (ICD first-10-chips octal convention)
+    return (1 - 2 * (g1 ^ g2 ^ 1)).astype(np.int8)
+
+
+class Scene(object):
+    """Integer description of a synthetic record. All fields are plain Python ints."""
+
+    def __init__(self, seed, sats, fs, cos_lut=None):
+        self.seed = int(seed) & MASK64
+        self.fs = float(fs)
+        self.sats = sats  # list of dicts: prn, amp, car_fcw, car_ph0, code_fcw, code_c0, nav_seed
+        if cos_lut is None:
+            k = np.arange(256)
+            cos_lut = np.round(127.0 * np.cos(2.0 * np.pi * (k + 0.5) / 256.0)).astype(np.int16)
+        self.cos_lut = np.asarray(cos_lut, dtype=np.int16)
+        assert len(self.sats) <= MAX_SATS
+
+    @staticmethod
+    def make(seed, fs, IF, prns, dopplers, code_starts, amps, fc=1.023e6):
+        """Build a scene from physical parameters (exact rational arithmetic on the host)."""
+        from fractions import Fraction
+        sats = []
+        for prn, fd, start, amp in zip(prns, dopplers, code_starts, amps):
+            car = Fraction(IF) + Fraction(fd)
+            car_fcw = int(round(car / Fraction(fs) * (1 << 32))) & 0xFFFFFFFF
+            chip_rate = Fraction(fc) * (1 + Fraction(fd) / Fraction(L1_HZ))
+            code_fcw = int(round(chip_rate / Fraction(fs) * (1 << 32)))
+            period = 1023 << 32
+            code_c0 = (-int(start) * code_fcw) % period
+            h = int(splitmix64(np.array([(seed + 977 * prn) & MASK64], dtype=np.uint64))[0])
+            sats.append(dict(prn=int(prn), amp=int(amp), car_fcw=car_fcw,
+                             car_ph0=(h >> 16) & 0xFFFFFFFF, code_fcw=code_fcw, code_c0=code_c0,
+                             nav_seed=(h ^ 0xA5A5A5A5DEADBEEF) & MASK64))
+        return Scene(seed, sats, fs)
+
+    @staticmethod
+    def default(fs=38192000.0, IF=9548000.0, n_sats=8):
+        """SURVEY.md section 8(d) default scene: seed 0x5EED0001, 8 satellites."""
+        prns = [1, 3, 7, 11, 14, 19, 22, 31][:n_sats]
+        dop = [1250, -3100, 4800, -650, 2900, -4400, 350, -1900][:n_sats]
+        starts = [12345, 30001, 5, 20000, 777, 38000, 15000, 9000][:n_sats]
+        amps = [8, 7, 6, 7, 8, 6, 7, 6][:n_sats]
+        return Scene.make(0x5EED0001, fs, IF, prns, dop, starts, amps)
+
+
+def generate(scene, n, offset=0, chunk=1 << 21):
+    """Return int8[n] samples [offset, offset+n) of the scene (numpy, chunked)."""
+    out = np.empty(n, dtype=np.int8)
+    codes = {s["prn"]: ca_code_bits(s["prn"] - 1).astype(np.int64) for s in scene.sats}
+    lut = scene.cos_lut.astype(np.int64)
+    g = np.uint64(GOLDEN)
+    with np.errstate(over="ignore"):
+        for a in range(0, n, chunk):
+            m = min(chunk, n - a)
+            idx = np.arange(offset + a, offset + a + m, dtype=np.uint64)
+            h = splitmix64(np.uint64(scene.seed) + (idx + np.uint64(1)) * g)
+            s4 = ((h & np.uint64(0xFF)) + ((h >> np.uint64(8)) & np.uint64(0xFF)) +
+                  ((h >> np.uint64(16)) & np.uint64(0xFF)) + ((h >> np.uint64(24)) & np.uint64(0xFF)))
+            acc = ((s4.astype(np.int64) - 510) * NOISE_MUL) >> NOISE_SHIFT
+            for s in scene.sats:
+                cp = idx * np.uint64(s["code_fcw"]) + np.uint64(s["code_c0"])
+                chipw = cp >> np.uint64(32)
+                chip = (chipw % np.uint64(1023)).astype(np.int64)
+                bit = chipw // np.uint64(1023 * 20)
+                navh = splitmix64(np.uint64(s["nav_seed"]) + (bit + np.uint64(1)) * g)
+                nav = 1 - 2 * (navh & np.uint64(1)).astype(np.int64)
+                ph = (np.uint64(s["car_ph0"]) + idx * np.uint64(s["car_fcw"])) & np.uint64(0xFFFFFFFF)
+                c = lut[(ph >> np.uint64(24)).astype(np.int64)]
+                acc += (s["amp"] * codes[s["prn"]][chip] * nav * c + 64) >> 7
+            out[a:a + m] = np.clip(acc, -127, 127).astype(np.int8)
+    return out
+
+
+def record_length(settings_samples_per_code, ms):
+    """Bytes needed so that `ms` tracking blocks plus the 11 ms acquisition window always fit."""
+    n = int(settings_samples_per_code)
+    return (int(ms) + 1) * (n + 1) + n
