@@ -1,0 +1,172 @@
+/* sgx.h - C-ABI of libsgx.so: MI355X (gfx950) GPS L1 C/A acquisition + tracking engine.
+ *
+ * The reference (perrysou/SoftGNSS-python) has no FFI; its boundary is the Python object API
+ *   Settings                              reference initialize.py:80-185
+ *   AcquisitionResult.acquire(longSignal) reference acquisition.py:27-204
+ *   AcquisitionResult.preRun()            reference acquisition.py:259-306  (host glue, stays in Python)
+ *   TrackingResult.track(fid)             reference tracking.py:13-295
+ * The entry points below sit directly under those methods: the drop-in Python modules in
+ * softgnss-python_amd/ bind them with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions: plain C, int status return (0 = SGX_OK, <0 = error; text via sgx_last_error),
+ * no exceptions/callbacks across the boundary, the CALLER owns every host buffer (the library
+ * copies and never keeps a host pointer after return), opaque handles for the device context
+ * and for IF records resident in HBM.  One context per device; a context is not thread-safe,
+ * different contexts are.  No torch / framework types anywhere in the signatures.
+ */
+#ifndef SGX_H
+#define SGX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGX_OK          0
+#define SGX_E_ARG      -1   /* bad argument */
+#define SGX_E_HIP      -2   /* HIP runtime error (no device, launch failure, ...) */
+#define SGX_E_NOMEM    -3   /* allocation failed */
+#define SGX_E_INDEX    -4   /* the reference's IndexError: coarse code phase == samples-per-chip
+                               (acquisition.py:152-153 builds index N) */
+#define SGX_E_RCCL     -5   /* RCCL error / library not loadable */
+#define SGX_E_RANGE    -6   /* record too short for the request */
+
+#define SGX_NUM_SERIES 13   /* per-ms tracking series, in this order (tracking.py:255-275):
+                               absoluteSample codeFreq carrFreq I_P I_E I_L Q_E Q_P Q_L
+                               dllDiscr dllDiscrFilt pllDiscr pllDiscrFilt */
+#define SGX_MAX_SATS   16
+
+typedef struct sgx_ctx sgx_ctx;     /* device context: one per GPU */
+typedef struct sgx_if sgx_if;       /* int8 IF record resident in HBM */
+typedef struct sgx_comm sgx_comm;   /* RCCL communicator for the acquisition peak gather */
+
+/* POD mirror of the reference's Settings attributes used on the path (initialize.py:85-173). */
+typedef struct sgx_settings {
+    double samplingFreq;          /* initialize.py:107 */
+    double IF;                    /* initialize.py:105 */
+    double codeFreqBasis;         /* initialize.py:109 */
+    double acqSearchBand;         /* kHz, initialize.py:123 */
+    double acqThreshold;          /* initialize.py:126 */
+    double dllDampingRatio;       /* initialize.py:130 */
+    double dllNoiseBandwidth;     /* initialize.py:132 */
+    double dllCorrelatorSpacing;  /* initialize.py:134 */
+    double pllDampingRatio;       /* initialize.py:137 */
+    double pllNoiseBandwidth;     /* initialize.py:139 */
+    int64_t skipNumberOfBytes;    /* initialize.py:94 */
+    int32_t codeLength;           /* initialize.py:112 */
+    int32_t numberOfChannels;     /* initialize.py:88 */
+} sgx_settings;
+
+/* One tracking channel as preRun() hands it over (acquisition.py:285-303). */
+typedef struct sgx_chan_init {
+    double acquiredFreq;
+    double codePhase;   /* samples; tracking seeks to skipNumberOfBytes + codePhase (tracking.py:107) */
+    int32_t prn;        /* 1-based; 0 = channel off */
+    int32_t reserved;
+} sgx_chan_init;
+
+/* Integer-only synthetic scene (softgnss-python_amd/synth.py); host and device generators are
+ * bit-identical. */
+typedef struct sgx_sat {
+    uint64_t code_fcw;  /* 32.32 chips per sample */
+    uint64_t code_c0;   /* 32.32 code phase at sample 0, < 1023 << 32 */
+    uint64_t nav_seed;
+    uint32_t car_fcw;   /* carrier NCO word, cycles per sample * 2^32 */
+    uint32_t car_ph0;
+    int32_t prn;        /* 1-based */
+    int32_t amp;
+} sgx_sat;
+
+typedef struct sgx_scene {
+    uint64_t seed;
+    int32_t n_sats;
+    int32_t reserved;
+    sgx_sat sats[SGX_MAX_SATS];
+    int16_t cos_lut[256];
+} sgx_scene;
+
+/* Timings of the last call, measured with HIP events on the context's stream. */
+typedef struct sgx_timing {
+    float acquire_ms;        /* whole sgx_acquire device time */
+    float acq_coarse_ms;     /* mix + FFTs + correlation + peak search */
+    float acq_fine_ms;       /* fine-frequency FFTs */
+    float track_ms;          /* the tracking kernel */
+    float synth_ms;          /* the generator kernel */
+    float reserved[3];
+} sgx_timing;
+
+/* ---- library ------------------------------------------------------------------------------ */
+const char* sgx_version(void);
+int sgx_last_error(char* buf, size_t n);         /* copies the calling thread's last error text */
+
+/* ---- host-side exact helpers (no GPU needed) ---------------------------------------------- */
+/* samplesPerCode property, initialize.py:183-185 */
+int sgx_samples_per_code(const sgx_settings* s, int64_t* n);
+/* Settings.generateCAcode(prn0), initialize.py:234-302: out[1023] of +-1.0, prn0 in 0..31 */
+int sgx_generate_ca_code(int32_t prn0, double* out);
+/* Settings.makeCaTable(), initialize.py:188-231: out[32 * samplesPerCode] of +-1.0 */
+int sgx_make_ca_table(const sgx_settings* s, double* out);
+/* Settings.calcLoopCoef(LBW, zeta, k), initialize.py:304-328 */
+int sgx_calc_loop_coef(double lbw, double zeta, double k, double* tau1, double* tau2);
+
+/* ---- device context and IF records --------------------------------------------------------- */
+int sgx_device_count(int* n);
+int sgx_ctx_create(const sgx_settings* s, int device, sgx_ctx** out);
+int sgx_ctx_destroy(sgx_ctx* c);
+int sgx_ctx_sync(sgx_ctx* c);                     /* hipStreamSynchronize on the context stream */
+int sgx_get_timing(sgx_ctx* c, sgx_timing* out);
+
+/* np.fromfile(fid, 'int8', n) replacement: copy n host samples into a new HBM record
+ * (initialize.py:481, tracking.py:154). */
+int sgx_if_upload(sgx_ctx* c, const int8_t* host, size_t n, sgx_if** out);
+/* Generate samples [offset, offset+n) of a synthetic scene directly in HBM. */
+int sgx_if_synth(sgx_ctx* c, const sgx_scene* scene, uint64_t offset, size_t n, sgx_if** out);
+int sgx_if_download(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n, int8_t* host);
+int sgx_if_length(const sgx_if* r, size_t* n);
+int sgx_if_free(sgx_ctx* c, sgx_if* r);
+
+/* ---- AcquisitionResult.acquire (acquisition.py:27-204) -------------------------------------
+ * Searches PRN indices prn0[0..n_prn) (0-based) on samples [offset, offset+n_samples) of the
+ * record.  n_blocks 1-ms blocks feed the coarse search (reference: 2); noncoh = 0 keeps the
+ * reference rule (block with the larger maximum, acquisition.py:129-133), noncoh = 1 sums
+ * |corr|^2 over the blocks (extension, BASELINE.json config 4).  n_samples is the length of the
+ * reference's longSignal: its mean is the DC removed before the fine search (acquisition.py:59)
+ * and codePhase + 10 ms must fit in it (acquisition.py:177).
+ * Outputs, each [n_prn]: the three reference fields (acquisition.py:201-203) and, for parity
+ * checks, frequencyBinIndex and fftMaxIndex (-1 where the PRN is not detected).
+ * Returns SGX_E_INDEX where the reference raises IndexError (outputs up to that PRN are valid).
+ */
+int sgx_acquire(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n_samples,
+                const int32_t* prn0, int32_t n_prn, int32_t n_blocks, int32_t noncoh,
+                double* carrFreq, double* codePhase, double* peakMetric,
+                int32_t* freqBin, int32_t* fineIdx);
+
+/* ---- TrackingResult.track (tracking.py:13-295) ----------------------------------------------
+ * Tracks n_ch channels for `ms` code periods on the record.  rec_file_offset is the byte offset
+ * in the reference's file of the record's first sample (0 when the whole file was uploaded):
+ * a channel starts at file byte skipNumberOfBytes + codePhase (tracking.py:107) and
+ * absoluteSample is reported as a file position (tracking.py:255).
+ * out is [n_ch][SGX_NUM_SERIES][ms] float64, pre-filled exactly like tracking.py:65-94 (0 or
+ * +Inf) for entries never reached; ms_done[ch] = blocks completed (== ms unless the record ran
+ * out, the reference's short-read exit tracking.py:159-163; channels with prn == 0 report 0).
+ */
+int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset,
+              const sgx_chan_init* ch, int32_t n_ch, int32_t ms,
+              double* out, int32_t* ms_done);
+
+/* ---- RCCL peak gather (multi-GPU acquisition shard) ------------------
+ * One process per GPU.  Rank 0 calls sgx_comm_unique_id and ships the 128 bytes to the other
+ * ranks by any host channel; every rank then calls sgx_comm_create.  sgx_comm_allgather
+ * all-gathers `bytes` bytes per rank (host buffers, staged through HBM, ncclAllGather on the
+ * context stream over xGMI). */
+int sgx_comm_unique_id(uint8_t id[128]);
+int sgx_comm_create(sgx_ctx* c, int32_t n_ranks, int32_t rank, const uint8_t id[128], sgx_comm** out);
+int sgx_comm_allgather(sgx_comm* m, const void* send, void* recv, size_t bytes);
+int sgx_comm_destroy(sgx_comm* m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGX_H */

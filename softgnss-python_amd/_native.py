@@ -1,0 +1,271 @@
+"""ctypes binding of libsgx.so (include/sgx.h).  No torch, no fallback.
+
+The product path fails loudly: if the library is missing, or a device entry point is called
+without a GPU, an exception is raised - there is no CPU implementation behind these calls.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libsgx.so")
+
+SGX_OK = 0
+SGX_E_ARG, SGX_E_HIP, SGX_E_NOMEM, SGX_E_INDEX, SGX_E_RCCL, SGX_E_RANGE = -1, -2, -3, -4, -5, -6
+NUM_SERIES = 13
+MAX_SATS = 16
+SERIES = ("absoluteSample", "codeFreq", "carrFreq", "I_P", "I_E", "I_L", "Q_E", "Q_P", "Q_L",
+          "dllDiscr", "dllDiscrFilt", "pllDiscr", "pllDiscrFilt")
+
+
+class SgxError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "libsgx error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Settings(C.Structure):
+    _fields_ = [("samplingFreq", C.c_double), ("IF", C.c_double), ("codeFreqBasis", C.c_double),
+                ("acqSearchBand", C.c_double), ("acqThreshold", C.c_double),
+                ("dllDampingRatio", C.c_double), ("dllNoiseBandwidth", C.c_double),
+                ("dllCorrelatorSpacing", C.c_double), ("pllDampingRatio", C.c_double),
+                ("pllNoiseBandwidth", C.c_double), ("skipNumberOfBytes", C.c_int64),
+                ("codeLength", C.c_int32), ("numberOfChannels", C.c_int32)]
+
+
+class ChanInit(C.Structure):
+    _fields_ = [("acquiredFreq", C.c_double), ("codePhase", C.c_double), ("prn", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class Sat(C.Structure):
+    _fields_ = [("code_fcw", C.c_uint64), ("code_c0", C.c_uint64), ("nav_seed", C.c_uint64),
+                ("car_fcw", C.c_uint32), ("car_ph0", C.c_uint32), ("prn", C.c_int32), ("amp", C.c_int32)]
+
+
+class Scene(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("n_sats", C.c_int32), ("reserved", C.c_int32),
+                ("sats", Sat * MAX_SATS), ("cos_lut", C.c_int16 * 256)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("acquire_ms", C.c_float), ("acq_coarse_ms", C.c_float), ("acq_fine_ms", C.c_float),
+                ("track_ms", C.c_float), ("synth_ms", C.c_float), ("reserved", C.c_float * 3)]
+
+
+# every symbol include/sgx.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+_PROTOS = {
+    "sgx_version": (C.c_char_p, []),
+    "sgx_last_error": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "sgx_samples_per_code": (C.c_int, [C.POINTER(Settings), C.POINTER(C.c_int64)]),
+    "sgx_generate_ca_code": (C.c_int, [C.c_int32, _P]),
+    "sgx_make_ca_table": (C.c_int, [C.POINTER(Settings), _P]),
+    "sgx_calc_loop_coef": (C.c_int, [C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double),
+                                     C.POINTER(C.c_double)]),
+    "sgx_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "sgx_ctx_create": (C.c_int, [C.POINTER(Settings), C.c_int, C.POINTER(_P)]),
+    "sgx_ctx_destroy": (C.c_int, [_P]),
+    "sgx_ctx_sync": (C.c_int, [_P]),
+    "sgx_get_timing": (C.c_int, [_P, C.POINTER(Timing)]),
+    "sgx_if_upload": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(_P)]),
+    "sgx_if_synth": (C.c_int, [_P, C.POINTER(Scene), C.c_uint64, C.c_size_t, C.POINTER(_P)]),
+    "sgx_if_download": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P]),
+    "sgx_if_length": (C.c_int, [_P, C.POINTER(C.c_size_t)]),
+    "sgx_if_free": (C.c_int, [_P, _P]),
+    "sgx_acquire": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, C.c_int32, C.c_int32, C.c_int32,
+                              _P, _P, _P, _P, _P]),
+    "sgx_track": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, C.c_int32, _P, _P]),
+    "sgx_comm_unique_id": (C.c_int, [_P]),
+    "sgx_comm_create": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.POINTER(_P)]),
+    "sgx_comm_allgather": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "sgx_comm_destroy": (C.c_int, [_P]),
+}
+SYMBOLS = tuple(sorted(_PROTOS))
+
+_lib = None
+
+
+def lib():
+    """Load libsgx.so (built in-tree by build.py / __graft_entry__.build). Raises if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libsgx.so is not built (%s missing): run `python __graft_entry__.py` or "
+                              "`python softgnss-python_amd/build.py`; there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            f = getattr(L, name)   # AttributeError if the library lacks a declared symbol
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def last_error():
+    buf = C.create_string_buffer(512)
+    lib().sgx_last_error(buf, 512)
+    return buf.value.decode(errors="replace")
+
+
+def check(code):
+    if code != SGX_OK:
+        msg = last_error()
+        if code == SGX_E_INDEX:
+            raise IndexError(msg)          # the reference raises IndexError here (acquisition.py:152-162)
+        raise SgxError(code, msg)
+
+
+def settings_struct(s):
+    """POD mirror of a Settings-like object (attribute names of reference initialize.py:85-173)."""
+    return Settings(float(s.samplingFreq), float(s.IF), float(s.codeFreqBasis), float(s.acqSearchBand),
+                    float(s.acqThreshold), float(s.dllDampingRatio), float(s.dllNoiseBandwidth),
+                    float(s.dllCorrelatorSpacing), float(s.pllDampingRatio), float(s.pllNoiseBandwidth),
+                    int(s.skipNumberOfBytes), int(s.codeLength), int(s.numberOfChannels))
+
+
+def scene_struct(scene):
+    sc = Scene()
+    sc.seed = scene.seed
+    sc.n_sats = len(scene.sats)
+    for i, s in enumerate(scene.sats):
+        sc.sats[i] = Sat(s["code_fcw"], s["code_c0"], s["nav_seed"], s["car_fcw"], s["car_ph0"], s["prn"],
+                         s["amp"])
+    for i in range(256):
+        sc.cos_lut[i] = int(scene.cos_lut[i])
+    return sc
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = lib().sgx_device_count(C.byref(n))
+    return n.value if rc == SGX_OK else 0
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context(object):
+    """One device context (hipStream + scratch) per GPU."""
+
+    def __init__(self, settings, device=0):
+        self._h = _P()
+        self._s = settings_struct(settings)
+        check(lib().sgx_ctx_create(C.byref(self._s), int(device), C.byref(self._h)))
+        self.device = int(device)
+
+    def close(self):
+        if self._h:
+            lib().sgx_ctx_destroy(self._h)
+            self._h = _P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(lib().sgx_ctx_sync(self._h))
+
+    def timing(self):
+        t = Timing()
+        check(lib().sgx_get_timing(self._h, C.byref(t)))
+        return dict(acquire_ms=t.acquire_ms, acq_coarse_ms=t.acq_coarse_ms, acq_fine_ms=t.acq_fine_ms,
+                    track_ms=t.track_ms, synth_ms=t.synth_ms)
+
+    # ---- records ----
+    def upload(self, samples):
+        a = np.ascontiguousarray(samples, dtype=np.int8)
+        h = _P()
+        check(lib().sgx_if_upload(self._h, _ptr(a), a.size, C.byref(h)))
+        return Record(self, h, a.size)
+
+    def synth(self, scene, n, offset=0):
+        h = _P()
+        sc = scene_struct(scene)
+        check(lib().sgx_if_synth(self._h, C.byref(sc), int(offset), int(n), C.byref(h)))
+        return Record(self, h, int(n))
+
+    # ---- hot path ----
+    def acquire(self, rec, offset, n_samples, prn0, n_blocks=2, noncoh=False):
+        prn = np.ascontiguousarray(prn0, dtype=np.int32)
+        n = prn.size
+        carr = np.zeros(n)
+        cph = np.zeros(n)
+        met = np.zeros(n)
+        fb = np.zeros(n, dtype=np.int32)
+        fi = np.zeros(n, dtype=np.int32)
+        check(lib().sgx_acquire(self._h, rec._h, int(offset), int(n_samples), _ptr(prn), n, int(n_blocks),
+                                1 if noncoh else 0, _ptr(carr), _ptr(cph), _ptr(met), _ptr(fb), _ptr(fi)))
+        return dict(carrFreq=carr, codePhase=cph, peakMetric=met, freqBin=fb, fineIdx=fi)
+
+    def track(self, rec, chans, ms, rec_file_offset=0):
+        """chans: sequence of (prn, acquiredFreq, codePhase). Returns (series[n_ch,13,ms], ms_done)."""
+        n = len(chans)
+        arr = (ChanInit * n)()
+        for i, (prn, f, cp) in enumerate(chans):
+            arr[i] = ChanInit(float(f), float(cp), int(prn), 0)
+        out = np.empty((n, NUM_SERIES, int(ms)))
+        done = np.zeros(n, dtype=np.int32)
+        check(lib().sgx_track(self._h, rec._h, int(rec_file_offset), C.cast(arr, _P), n, int(ms), _ptr(out),
+                              _ptr(done)))
+        return out, done
+
+
+class Record(object):
+    """int8 IF record resident in HBM."""
+
+    def __init__(self, ctx, handle, n):
+        self.ctx = ctx
+        self._h = handle
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def download(self, offset=0, n=None):
+        n = self.n - offset if n is None else n
+        out = np.empty(n, dtype=np.int8)
+        check(lib().sgx_if_download(self.ctx._h, self._h, int(offset), int(n), _ptr(out)))
+        return out
+
+    def free(self):
+        if self._h and self.ctx._h:
+            lib().sgx_if_free(self.ctx._h, self._h)
+        self._h = _P()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Comm(object):
+    """RCCL communicator for the acquisition peak gather (one process per GPU)."""
+
+    def __init__(self, ctx, n_ranks, rank, unique_id):
+        self._h = _P()
+        self.n_ranks = n_ranks
+        uid = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        check(lib().sgx_comm_create(ctx._h, n_ranks, rank, C.cast(uid, _P), C.byref(self._h)))
+
+    @staticmethod
+    def unique_id():
+        uid = (C.c_uint8 * 128)()
+        check(lib().sgx_comm_unique_id(C.cast(uid, _P)))
+        return bytes(uid)
+
+    def allgather(self, payload):
+        send = np.ascontiguousarray(payload).view(np.uint8).ravel()
+        recv = np.empty(send.size * self.n_ranks, dtype=np.uint8)
+        check(lib().sgx_comm_allgather(self._h, _ptr(send), _ptr(recv), send.size))
+        return recv.reshape(self.n_ranks, send.size)
+
+    def close(self):
+        if self._h:
+            lib().sgx_comm_destroy(self._h)
+            self._h = _P()

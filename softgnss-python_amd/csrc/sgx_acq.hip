@@ -1,0 +1,499 @@
+// AcquisitionResult.acquire on gfx950 (reference acquisition.py:27-204).
+//
+// Data flow per call (everything fp64 / complex128, int8 IF read once):
+//   mix      x[n]*(sin,cos)(f_k * phasePoints[n])        -> [blocks][bins][N]      (PRN independent,
+//   FFT_N                                                 -> spectra X[b][k]         computed ONCE; the
+//                                                                                    reference redoes it
+//                                                                                    per PRN, Q6)
+//   code     table[p][n] = ca[p][ceil((ts*k)/tc)-1]      -> FFT_N -> F[p]
+//   corr     conj(X[b][k]) * F[p]  -> FFT_N  (= conj(N * ifft(X conj F)))  -> |.|^2 / N^2
+//   peaks    per row max / first argmax (device), block choice + exclusion list (host, tiny),
+//            second peak over the exclusion list (device)
+//   fine     (x - mean) * code(floor((ts*k)/tc) mod 1023), zero-padded 2^22-point FFT, argmax of |X|
+// HBM-resident scratch replaces the reference's per-PRN numpy temporaries.
+#include <math.h>
+
+#include "sgx_internal.h"
+
+#define ACQ_MAX_BINS 128
+#define ACQ_MAX_ROWS 2048
+
+struct MixArgs {
+    double frq[ACQ_MAX_BINS];
+    int n_bins;
+    int n_blocks;
+};
+
+// acquisition.py:62-117: phasePoints[n] = ((n*2)*pi)*ts ; theta = frq*phasePoints ; I = sin*x, Q = cos*x
+__global__ __launch_bounds__(256) void acq_mix_kernel(const int8_t* __restrict__ x, cplx* __restrict__ out,
+                                                      long long n, double ts, MixArgs a) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int k = blockIdx.y % a.n_bins;
+    const int b = blockIdx.y / a.n_bins;
+    const double pp = ((double)(i * 2) * M_PI) * ts;
+    const double th = a.frq[k] * pp;
+    double s, c;
+    sincos(th, &s, &c);
+    const double xv = (double)x[(long long)b * n + i];
+    out[((long long)b * a.n_bins + k) * n + i] = make_double2(s * xv, c * xv);
+}
+
+// initialize.py:210-226 (A3) on the device, same IEEE operations: idx = ceil((ts*k)/tc) - 1
+__global__ __launch_bounds__(256) void acq_code_kernel(const int8_t* __restrict__ codes,
+                                                       const int* __restrict__ prn0, cplx* __restrict__ out,
+                                                       long long n, double ts, double tc) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int p = prn0[blockIdx.y];
+    int idx = (int)ceil((ts * (double)(i + 1)) / tc) - 1;
+    if (i == n - 1) idx = 1022;
+    idx = idx < 0 ? 0 : (idx > 1022 ? 1022 : idx);
+    out[(long long)blockIdx.y * n + i] = make_double2((double)codes[p * 1023 + idx], 0.0);
+}
+
+// rows r = (pi, b, k): Y = conj(X[b][k]) * F[pi]
+__global__ __launch_bounds__(256) void acq_mul_kernel(const cplx* __restrict__ X, const cplx* __restrict__ F,
+                                                      cplx* __restrict__ Y, long long n, int rows_per_prn,
+                                                      int prn_base) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int r = blockIdx.y;
+    const int pi = r / rows_per_prn;
+    const int bk = r % rows_per_prn;
+    const cplx xv = X[(long long)bk * n + i];
+    const cplx fv = F[(long long)(prn_base + pi) * n + i];
+    // conj(x) * f
+    Y[(long long)r * n + i] =
+        make_double2(__builtin_fma(xv.x, fv.x, xv.y * fv.y), __builtin_fma(xv.x, fv.y, -(xv.y * fv.x)));
+}
+
+// |fft|^2 / N^2 per output row (optionally summed over the blocks: noncoherent extension),
+// plus row max and FIRST argmax (numpy argmax semantics, acquisition.py:139-143).
+__global__ __launch_bounds__(256) void acq_power_kernel(const cplx* __restrict__ Z, double* __restrict__ P,
+                                                        double* __restrict__ rowmax, int* __restrict__ rowarg,
+                                                        long long n, double inv_n, int n_bins, int n_blocks,
+                                                        int noncoh) {
+    const int ro = blockIdx.x;   // output row
+    double best = -1.0;
+    int arg = 0;
+    double* __restrict__ prow = P + (long long)ro * n;
+    for (long long i = threadIdx.x; i < n; i += 256) {
+        double v;
+        if (noncoh) {
+            const int pi = ro / n_bins, k = ro % n_bins;
+            v = 0.0;
+            for (int b = 0; b < n_blocks; ++b) {
+                const cplx z = Z[(((long long)pi * n_blocks + b) * n_bins + k) * n + i];
+                const double re = z.x * inv_n, im = z.y * inv_n;
+                const double pw = re * re + im * im;
+                v = (b == 0) ? pw : v + pw;
+            }
+        } else {
+            const cplx z = Z[(long long)ro * n + i];
+            const double re = z.x * inv_n, im = z.y * inv_n;
+            v = re * re + im * im;
+        }
+        prow[i] = v;
+        if (v > best) {
+            best = v;
+            arg = (int)i;
+        }
+    }
+    __shared__ double s_v[256];
+    __shared__ int s_i[256];
+    s_v[threadIdx.x] = best;
+    s_i[threadIdx.x] = arg;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            const double ov = s_v[threadIdx.x + s];
+            const int oi = s_i[threadIdx.x + s];
+            if (ov > s_v[threadIdx.x] || (ov == s_v[threadIdx.x] && oi < s_i[threadIdx.x])) {
+                s_v[threadIdx.x] = ov;
+                s_i[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        rowmax[ro] = s_v[0];
+        rowarg[ro] = s_i[0];
+    }
+}
+
+struct SecondArgs {
+    int row[32];          // power row to search, -1 = skip
+    int lo0[32], hi0[32]; // first index range [lo0, hi0)
+    int lo1[32], hi1[32]; // second index range
+};
+
+// acquisition.py:162: max of the chosen frequency row over the exclusion index list
+__global__ __launch_bounds__(256) void acq_second_kernel(const double* __restrict__ P, double* __restrict__ out,
+                                                         long long n, SecondArgs a) {
+    const int p = blockIdx.x;
+    double best = -1.0;
+    if (a.row[p] >= 0) {
+        const double* __restrict__ prow = P + (long long)a.row[p] * n;
+        for (int i = a.lo0[p] + threadIdx.x; i < a.hi0[p]; i += 256) best = fmax(best, prow[i]);
+        for (int i = a.lo1[p] + threadIdx.x; i < a.hi1[p]; i += 256) best = fmax(best, prow[i]);
+    }
+    __shared__ double s_v[256];
+    s_v[threadIdx.x] = best;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) s_v[threadIdx.x] = fmax(s_v[threadIdx.x], s_v[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[p] = s_v[0];
+}
+
+// integer sum of the record window (mean for acquisition.py:59)
+__global__ __launch_bounds__(256) void acq_sum_kernel(const int8_t* __restrict__ x, long long n,
+                                                      long long* __restrict__ out) {
+    long long acc = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        acc += x[i];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long*)out, (unsigned long long)acc);
+}
+
+// acquisition.py:170-177 (A9): xCarrier = (x - mean)[c : c+10N] * code[floor((ts*k)/tc1) mod 1023]
+__global__ __launch_bounds__(256) void acq_fine_prep_kernel(const int8_t* __restrict__ x,
+                                                            const int8_t* __restrict__ codes, cplx* __restrict__ out,
+                                                            long long len, long long row_stride, double mean,
+                                                            double ts, double tc1, const int* __restrict__ det_prn,
+                                                            const int* __restrict__ det_phase) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= len) return;
+    const int d = blockIdx.y;
+    const double v = floor((ts * (double)(i + 1)) / tc1);
+    const int chip = (int)((long long)v % 1023);
+    const double xv = (double)x[det_phase[d] + i] - mean;
+    out[(long long)d * row_stride + i] = make_double2(xv * (double)codes[det_prn[d] * 1023 + chip], 0.0);
+}
+
+// acquisition.py:182-187: argmax of |X[4 : uniq-5]| (first occurrence); per-block partial results
+__global__ __launch_bounds__(256) void acq_fine_argmax_kernel(const cplx* __restrict__ X, long long row_stride,
+                                                              long long lo, long long hi,
+                                                              double* __restrict__ pv, long long* __restrict__ pi) {
+    const int d = blockIdx.y;
+    const cplx* __restrict__ row = X + (long long)d * row_stride;
+    double best = -1.0;
+    long long arg = lo;
+    for (long long i = lo + (long long)blockIdx.x * 256 + threadIdx.x; i < hi; i += (long long)gridDim.x * 256) {
+        const cplx z = row[i];
+        const double v = z.x * z.x + z.y * z.y;
+        if (v > best) {
+            best = v;
+            arg = i;
+        }
+    }
+    __shared__ double s_v[256];
+    __shared__ long long s_i[256];
+    s_v[threadIdx.x] = best;
+    s_i[threadIdx.x] = arg;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            const double ov = s_v[threadIdx.x + s];
+            const long long oi = s_i[threadIdx.x + s];
+            if (ov > s_v[threadIdx.x] || (ov == s_v[threadIdx.x] && oi < s_i[threadIdx.x])) {
+                s_v[threadIdx.x] = ov;
+                s_i[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        pv[(long long)d * gridDim.x + blockIdx.x] = s_v[0];
+        pi[(long long)d * gridDim.x + blockIdx.x] = s_i[0];
+    }
+}
+
+static int ensure_buf(void** p, size_t* cap_bytes, size_t need) {
+    if (*p && *cap_bytes >= need) return SGX_OK;
+    if (*p) hipFree(*p);
+    *p = nullptr;
+    hipError_t e = hipMalloc(p, need);
+    if (e != hipSuccess) {
+        sgx_set_error("hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+        *cap_bytes = 0;
+        return SGX_E_NOMEM;
+    }
+    *cap_bytes = need;
+    return SGX_OK;
+}
+
+extern "C" int sgx_acquire(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n_samples, const int32_t* prn0,
+                           int32_t n_prn, int32_t n_blocks, int32_t noncoh, double* carrFreq, double* codePhase,
+                           double* peakMetric, int32_t* freqBin, int32_t* fineIdx) {
+    SGX_CHECK_ARG(c && r && prn0 && carrFreq && codePhase && peakMetric && freqBin && fineIdx);
+    SGX_CHECK_ARG(n_prn >= 1 && n_prn <= 32 && n_blocks >= 1 && n_blocks <= 64);
+    for (int i = 0; i < n_prn; ++i) SGX_CHECK_ARG(prn0[i] >= 0 && prn0[i] < 32);
+    const long long N = c->n_code;
+    const sgx_settings& S = c->s;
+    if (offset > r->n || n_samples > r->n - offset || (long long)n_samples < (long long)n_blocks * N) {
+        sgx_set_error("record window too short: %zu samples at offset %zu, %lld needed for the coarse search",
+                      n_samples, offset, (long long)n_blocks * N);
+        return SGX_E_RANGE;
+    }
+    SGX_HIP(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const int8_t* x = r->d + offset;
+
+    // A4 frequency grid (acquisition.py:68,99-101)
+    const int n_bins = (int)(nearbyint(S.acqSearchBand * 2) + 1);
+    SGX_CHECK_ARG(n_bins >= 1 && n_bins <= ACQ_MAX_BINS);
+    MixArgs ma;
+    ma.n_bins = n_bins;
+    ma.n_blocks = n_blocks;
+    for (int k = 0; k < n_bins; ++k) ma.frq[k] = S.IF - S.acqSearchBand / 2 * 1000 + 500.0 * k;
+    const double ts = 1.0 / S.samplingFreq;
+    const double tc = 1.0 / S.codeFreqBasis;
+    const int spc = (int)llround(S.samplingFreq / S.codeFreqBasis);   // acquisition.py:145
+
+    int rc = sgx_fft_plan_create(&c->plan_code, N);
+    if (rc != SGX_OK) return rc;
+
+    // ---- scratch ------------------------------------------------------------------------------
+    const int rows_fwd = n_blocks * n_bins;
+    const int rows_per_prn = rows_fwd;
+    SGX_CHECK_ARG(rows_per_prn <= ACQ_MAX_ROWS);
+    int prn_chunk = ACQ_MAX_ROWS / rows_per_prn;
+    if (prn_chunk < 1) prn_chunk = 1;
+    if (prn_chunk > n_prn) prn_chunk = n_prn;
+    const size_t row_bytes = sizeof(cplx) * (size_t)N;
+    size_t work_rows = (size_t)prn_chunk * rows_per_prn;
+    if (work_rows < (size_t)rows_fwd) work_rows = rows_fwd;
+    if (work_rows < (size_t)n_prn) work_rows = n_prn;
+    if ((rc = ensure_buf((void**)&c->d_work[0], &c->cap_w0, work_rows * row_bytes)) != SGX_OK) return rc;
+    if ((rc = ensure_buf((void**)&c->d_work[1], &c->cap_w1, work_rows * row_bytes)) != SGX_OK) return rc;
+    if ((rc = ensure_buf((void**)&c->d_fwd, &c->cap_fwd, (size_t)rows_fwd * row_bytes)) != SGX_OK) return rc;
+    if ((rc = ensure_buf((void**)&c->d_codefd, &c->cap_code, (size_t)n_prn * row_bytes)) != SGX_OK) return rc;
+    if ((rc = ensure_buf((void**)&c->d_pow, &c->cap_pow, work_rows * sizeof(double) * (size_t)N)) != SGX_OK) return rc;
+
+    char* dsm = (char*)c->d_small;
+    char* hsm = (char*)c->h_small;
+    // d_small layout: [0,8) sum | [64, 64+128) prn list | [256, ...) rowmax doubles | rowarg ints | second | fine
+    long long* d_sum = (long long*)dsm;
+    int* d_prn = (int*)(dsm + 64);
+    double* d_rowmax = (double*)(dsm + 1024);
+    int* d_rowarg = (int*)(dsm + 1024 + 8 * 4096);
+    double* d_second = (double*)(dsm + 1024 + 12 * 4096);
+    int* d_detprn = (int*)(dsm + 1024 + 12 * 4096 + 512);
+    int* d_detph = d_detprn + 32;
+    double* d_pv = (double*)(dsm + 65536);
+    long long* d_pi = (long long*)(dsm + 65536 + 8 * 32 * 256);
+
+    hipEventRecord(c->ev[0], st);
+    SGX_HIP(hipMemsetAsync(d_sum, 0, 8, st));
+    SGX_HIP(hipMemcpyAsync(d_prn, prn0, sizeof(int) * (size_t)n_prn, hipMemcpyHostToDevice, st));
+    acq_sum_kernel<<<256, 256, 0, st>>>(x, (long long)n_samples, d_sum);
+
+    // ---- PRN-independent part: mix + forward FFTs ------------------------------------------------
+    {
+        dim3 grid((unsigned)((N + 255) / 256), (unsigned)rows_fwd);
+        acq_mix_kernel<<<grid, 256, 0, st>>>(x, c->d_work[0], N, ts, ma);
+        cplx* res = nullptr;
+        rc = sgx_fft_forward(&c->plan_code, c->d_work[0], c->d_work[1], rows_fwd, st, &res, N);
+        if (rc != SGX_OK) return rc;
+        SGX_HIP(hipMemcpyAsync(c->d_fwd, res, (size_t)rows_fwd * row_bytes, hipMemcpyDeviceToDevice, st));
+    }
+    // ---- code spectra ---------------------------------------------------------------------------
+    {
+        dim3 grid((unsigned)((N + 255) / 256), (unsigned)n_prn);
+        acq_code_kernel<<<grid, 256, 0, st>>>(c->d_codes, d_prn, c->d_work[0], N, ts, tc);
+        cplx* res = nullptr;
+        rc = sgx_fft_forward(&c->plan_code, c->d_work[0], c->d_work[1], n_prn, st, &res, N);
+        if (rc != SGX_OK) return rc;
+        SGX_HIP(hipMemcpyAsync(c->d_codefd, res, (size_t)n_prn * row_bytes, hipMemcpyDeviceToDevice, st));
+    }
+
+    // ---- correlation + peak search, PRN chunk by chunk ---------------------------------------------
+    std::vector<int> det_prn, det_phase, det_slot;
+    int status = SGX_OK;
+    for (int i = 0; i < n_prn; ++i) {
+        carrFreq[i] = 0.0;
+        codePhase[i] = 0.0;
+        peakMetric[i] = 0.0;
+        freqBin[i] = -1;
+        fineIdx[i] = -1;
+    }
+    const double inv_n = 1.0 / (double)N;
+    for (int p0 = 0; p0 < n_prn && status == SGX_OK; p0 += prn_chunk) {
+        const int np = (p0 + prn_chunk <= n_prn) ? prn_chunk : (n_prn - p0);
+        const int rows = np * rows_per_prn;
+        dim3 grid((unsigned)((N + 255) / 256), (unsigned)rows);
+        acq_mul_kernel<<<grid, 256, 0, st>>>(c->d_fwd, c->d_codefd, c->d_work[0], N, rows_per_prn, p0);
+        cplx* res = nullptr;
+        rc = sgx_fft_forward(&c->plan_code, c->d_work[0], c->d_work[1], rows, st, &res, N);
+        if (rc != SGX_OK) return rc;
+        const int rows_out = noncoh ? np * n_bins : rows;
+        acq_power_kernel<<<rows_out, 256, 0, st>>>(res, c->d_pow, d_rowmax, d_rowarg, N, inv_n, n_bins, n_blocks,
+                                                   noncoh ? 1 : 0);
+        double* h_rowmax = (double*)(hsm + 1024);
+        int* h_rowarg = (int*)(hsm + 1024 + 8 * 4096);
+        SGX_HIP(hipMemcpyAsync(h_rowmax, d_rowmax, sizeof(double) * (size_t)rows_out, hipMemcpyDeviceToHost, st));
+        SGX_HIP(hipMemcpyAsync(h_rowarg, d_rowarg, sizeof(int) * (size_t)rows_out, hipMemcpyDeviceToHost, st));
+        SGX_HIP(hipStreamSynchronize(st));
+
+        // host: block choice (A7), global peak (A8), exclusion list (A8b)
+        SecondArgs sa;
+        double peak[32];
+        int cph[32], fbi[32];
+        for (int pi = 0; pi < 32; ++pi) sa.row[pi] = -1, sa.lo0[pi] = sa.hi0[pi] = sa.lo1[pi] = sa.hi1[pi] = 0;
+        for (int pi = 0; pi < np; ++pi) {
+            double gmax = -1.0;
+            int gk = 0, gc = 0, grow = 0;
+            bool have = false;
+            for (int k = 0; k < n_bins; ++k) {
+                int row;
+                if (noncoh) {
+                    row = pi * n_bins + k;
+                } else {
+                    int best = 0;   // acquisition.py:129-133 generalised left to right, later block wins ties
+                    for (int b = 1; b < n_blocks; ++b) {
+                        const double vb = h_rowmax[(pi * n_blocks + best) * n_bins + k];
+                        const double vn = h_rowmax[(pi * n_blocks + b) * n_bins + k];
+                        if (!(vb > vn)) best = b;
+                    }
+                    row = (pi * n_blocks + best) * n_bins + k;
+                }
+                const double v = h_rowmax[row];
+                const int a = h_rowarg[row];
+                if (!have || v > gmax) {
+                    gmax = v;
+                    gk = k;          // first row attaining the maximum (results.max(1).argmax())
+                    gc = a;
+                    grow = row;
+                    have = true;
+                } else if (v == gmax && a < gc) {
+                    gc = a;          // results.max(0).argmax(): first column attaining the maximum
+                }
+            }
+            peak[pi] = gmax;
+            cph[pi] = gc;
+            fbi[pi] = gk;
+            const int e1 = gc - spc, e2 = gc + spc;
+            sa.row[pi] = grow;
+            if (e1 <= 0) {
+                if ((long long)N + e1 + 1 > N) {   // index N would be read: the reference's IndexError (Q5)
+                    sgx_set_error("IndexError: index %lld is out of bounds for axis 1 with size %lld "
+                                  "(PRN index %d, codePhase %d; reference acquisition.py:152-162)",
+                                  N, N, prn0[p0 + pi], gc);
+                    status = SGX_E_INDEX;
+                    sa.row[pi] = -1;
+                    break;
+                }
+                sa.lo0[pi] = e2;
+                sa.hi0[pi] = (int)(N + e1 + 1);
+            } else if (e2 >= N - 1) {
+                const int lo = (int)(e2 - N);
+                if (lo < 0) {   // arange starts at -1: numpy wraps it to N-1
+                    sa.lo0[pi] = 0;
+                    sa.hi0[pi] = e1;
+                    sa.lo1[pi] = (int)N - 1;
+                    sa.hi1[pi] = (int)N;
+                } else {
+                    sa.lo0[pi] = lo;
+                    sa.hi0[pi] = e1;
+                }
+            } else {
+                sa.lo0[pi] = 0;
+                sa.hi0[pi] = e1 + 1;
+                sa.lo1[pi] = e2;
+                sa.hi1[pi] = (int)N;
+            }
+        }
+        if (status != SGX_OK) break;
+        acq_second_kernel<<<np, 256, 0, st>>>(c->d_pow, d_second, N, sa);
+        double* h_second = (double*)(hsm + 1024 + 12 * 4096);
+        SGX_HIP(hipMemcpyAsync(h_second, d_second, sizeof(double) * (size_t)np, hipMemcpyDeviceToHost, st));
+        SGX_HIP(hipStreamSynchronize(st));
+        for (int pi = 0; pi < np; ++pi) {
+            const int o = p0 + pi;
+            const double ratio = peak[pi] / h_second[pi];
+            peakMetric[o] = ratio;
+            freqBin[o] = fbi[pi];
+            if (ratio > S.acqThreshold) {
+                det_prn.push_back(prn0[o]);
+                det_phase.push_back(cph[pi]);
+                det_slot.push_back(o);
+            }
+        }
+    }
+    hipEventRecord(c->ev[1], st);
+    if (status != SGX_OK) {
+        hipStreamSynchronize(st);
+        return status;
+    }
+
+    // ---- fine frequency search (acquisition.py:167-193) -----------------------------------------------
+    const int n_det = (int)det_prn.size();
+    if (n_det > 0) {
+        const long long len = 10 * N;
+        const long long npts = 8ll << (long long)ceil(log2((double)len));
+        const long long uniq = (long long)ceil((double)(npts + 1) / 2.0);
+        for (int d = 0; d < n_det; ++d) {
+            if ((long long)det_phase[d] + len > (long long)n_samples) {
+                sgx_set_error("fine search needs codePhase + 10 ms = %lld samples, record window has %zu "
+                              "(reference acquisition.py:177 would fail to broadcast)",
+                              (long long)det_phase[d] + len, n_samples);
+                return SGX_E_RANGE;
+            }
+        }
+        rc = sgx_fft_plan_create(&c->plan_fine, npts);
+        if (rc != SGX_OK) return rc;
+        if ((rc = ensure_buf((void**)&c->d_fine[0], &c->cap_f0, (size_t)n_det * sizeof(cplx) * (size_t)npts)) != SGX_OK)
+            return rc;
+        if ((rc = ensure_buf((void**)&c->d_fine[1], &c->cap_f1, (size_t)n_det * sizeof(cplx) * (size_t)npts)) != SGX_OK)
+            return rc;
+        long long h_sum = 0;
+        SGX_HIP(hipMemcpyAsync(&h_sum, d_sum, 8, hipMemcpyDeviceToHost, st));
+        SGX_HIP(hipMemcpyAsync(d_detprn, det_prn.data(), sizeof(int) * (size_t)n_det, hipMemcpyHostToDevice, st));
+        SGX_HIP(hipMemcpyAsync(d_detph, det_phase.data(), sizeof(int) * (size_t)n_det, hipMemcpyHostToDevice, st));
+        SGX_HIP(hipStreamSynchronize(st));
+        const double mean = (double)h_sum / (double)n_samples;   // longSignal.mean(), acquisition.py:59
+        const double tc1 = 1.0 / S.codeFreqBasis;
+        dim3 grid((unsigned)((len + 255) / 256), (unsigned)n_det);
+        acq_fine_prep_kernel<<<grid, 256, 0, st>>>(x, c->d_codes, c->d_fine[0], len, npts, mean, ts, tc1, d_detprn,
+                                                   d_detph);
+        cplx* res = nullptr;
+        rc = sgx_fft_forward(&c->plan_fine, c->d_fine[0], c->d_fine[1], n_det, st, &res, len);
+        if (rc != SGX_OK) return rc;
+        const int nblk = 256;
+        dim3 g2((unsigned)nblk, (unsigned)n_det);
+        acq_fine_argmax_kernel<<<g2, 256, 0, st>>>(res, npts, 4, uniq - 5, d_pv, d_pi);
+        double* h_pv = (double*)(hsm + 65536);
+        long long* h_pi = (long long*)(hsm + 65536 + 8 * 32 * 256);
+        SGX_HIP(hipMemcpyAsync(h_pv, d_pv, sizeof(double) * (size_t)n_det * nblk, hipMemcpyDeviceToHost, st));
+        SGX_HIP(hipMemcpyAsync(h_pi, d_pi, sizeof(long long) * (size_t)n_det * nblk, hipMemcpyDeviceToHost, st));
+        hipEventRecord(c->ev[2], st);
+        SGX_HIP(hipStreamSynchronize(st));
+        for (int d = 0; d < n_det; ++d) {
+            double bv = -1.0;
+            long long bi = 0;
+            for (int b = 0; b < nblk; ++b) {
+                const double v = h_pv[d * nblk + b];
+                const long long i = h_pi[d * nblk + b];
+                if (v > bv || (v == bv && i < bi)) {
+                    bv = v;
+                    bi = i;
+                }
+            }
+            const long long m = bi - 4;   // index inside the [4:uniq-5] slice (acquisition.py:187)
+            const int o = det_slot[d];
+            carrFreq[o] = ((double)m * S.samplingFreq) / (double)npts;   // acquisition.py:189-191 (Q3)
+            codePhase[o] = (double)det_phase[d];
+            fineIdx[o] = (int)m;
+        }
+    } else {
+        hipEventRecord(c->ev[2], st);
+        SGX_HIP(hipStreamSynchronize(st));
+    }
+    hipEventElapsedTime(&c->timing.acq_coarse_ms, c->ev[0], c->ev[1]);
+    hipEventElapsedTime(&c->timing.acq_fine_ms, c->ev[1], c->ev[2]);
+    hipEventElapsedTime(&c->timing.acquire_ms, c->ev[0], c->ev[2]);
+    return SGX_OK;
+}

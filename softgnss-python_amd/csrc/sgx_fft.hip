@@ -1,0 +1,301 @@
+// Batched complex128 forward DFT for gfx950: Stockham autosort passes through HBM/L2, mixed radix.
+//
+// samplesPerCode = 38192 = 16*7*11*31 is not a power of two (SURVEY.md section 7 hard part 4), the
+// fine-frequency search needs 2^22 points.  Each pass is one launch over [rows][n/R] butterflies:
+//   thread j: k = j mod Ns; v[q] = in[j + q*n/R] * W_n^(q*k*n/(Ns*R)); V = DFT_R(v);
+//             out[(j/Ns)*Ns*R + k + q*Ns] = V[q]
+// Radix 16/8/4/2 are register butterflies built from radix-4/2; odd radices (3..31) use a direct
+// DFT that pairs v[q] +- v[R-q] (conjugate symmetry of the roots: (R-1) FMAs per output instead
+// of 4(R-1)).  fp64 throughout: the acquisition argmax indices must match the reference bit for
+// bit, and the fine-search top-2 bins can differ by 4e-5 relative.
+// MFMA is deliberately unused (BASELINE.json north_star).
+#include <math.h>
+
+#include "sgx_internal.h"
+
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) {
+    return make_double2(__builtin_fma(a.x, b.x, -(a.y * b.y)), __builtin_fma(a.x, b.y, a.y * b.x));
+}
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return make_double2(a.x - b.x, a.y - b.y); }
+// multiply by -i (forward DFT quarter turn)
+__device__ __forceinline__ cplx mul_mi(cplx a) { return make_double2(a.y, -a.x); }
+
+__device__ __forceinline__ void bfly4(cplx& x0, cplx& x1, cplx& x2, cplx& x3) {
+    const cplx t0 = cadd(x0, x2), t1 = csub(x0, x2), t2 = cadd(x1, x3), t3 = mul_mi(csub(x1, x3));
+    x0 = cadd(t0, t2);
+    x1 = cadd(t1, t3);
+    x2 = csub(t0, t2);
+    x3 = csub(t1, t3);
+}
+
+struct PassArgs {
+    const cplx* in;
+    cplx* out;
+    const cplx* tw_hi;
+    const cplx* tw_lo;
+    const cplx* wr;        // roots of unity of the radix: wr[m] = exp(-2 pi i m / R)
+    long long n;
+    long long ns;
+    long long nonzero_len;  // input elements >= this index are zero (first pass of a padded row)
+    int lo_bits;
+};
+
+__device__ __forceinline__ cplx twiddle(const PassArgs& a, long long t) {
+    const cplx h = a.tw_hi[t >> a.lo_bits];
+    const cplx l = a.tw_lo[t & ((1ll << a.lo_bits) - 1)];
+    return cmul(h, l);
+}
+
+template <int R>
+__device__ __forceinline__ void dft_small(cplx (&v)[R], const cplx* __restrict__ wr) {
+    if constexpr (R == 2) {
+        const cplx a = v[0], b = v[1];
+        v[0] = cadd(a, b);
+        v[1] = csub(a, b);
+    } else if constexpr (R == 4) {
+        bfly4(v[0], v[1], v[2], v[3]);
+    } else if constexpr (R == 8) {
+        // n = n1 + 2 n2 (n1 in 0..1, n2 in 0..3), k = 4 k1 + k2
+        cplx y[2][4];
+#pragma unroll
+        for (int n1 = 0; n1 < 2; ++n1) {
+            cplx a0 = v[n1], a1 = v[n1 + 2], a2 = v[n1 + 4], a3 = v[n1 + 6];
+            bfly4(a0, a1, a2, a3);
+            y[n1][0] = a0;
+            y[n1][1] = a1;
+            y[n1][2] = a2;
+            y[n1][3] = a3;
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) {
+            const cplx b1 = (k2 == 0) ? y[1][k2] : cmul(y[1][k2], wr[k2]);
+            v[k2] = cadd(y[0][k2], b1);
+            v[k2 + 4] = csub(y[0][k2], b1);
+        }
+    } else if constexpr (R == 16) {
+        // n = n1 + 4 n2, k = 4 k1 + k2: DFT4 over n2, twiddle W16^(n1 k2), DFT4 over n1
+        cplx y[4][4];
+#pragma unroll
+        for (int n1 = 0; n1 < 4; ++n1) {
+            cplx a0 = v[n1], a1 = v[n1 + 4], a2 = v[n1 + 8], a3 = v[n1 + 12];
+            bfly4(a0, a1, a2, a3);
+            y[n1][0] = a0;
+            y[n1][1] = a1;
+            y[n1][2] = a2;
+            y[n1][3] = a3;
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) {
+            cplx b0 = y[0][k2];
+            cplx b1 = (k2 == 0) ? y[1][k2] : cmul(y[1][k2], wr[(1 * k2) & 15]);
+            cplx b2 = (k2 == 0) ? y[2][k2] : cmul(y[2][k2], wr[(2 * k2) & 15]);
+            cplx b3 = (k2 == 0) ? y[3][k2] : cmul(y[3][k2], wr[(3 * k2) & 15]);
+            bfly4(b0, b1, b2, b3);
+            v[k2] = b0;
+            v[k2 + 4] = b1;
+            v[k2 + 8] = b2;
+            v[k2 + 12] = b3;
+        }
+    } else {
+        // odd radix: out[k] = v0 + sum_q (a_q c_qk + (b_q.im, -b_q.re) s_qk), out[R-k] with -s
+        static_assert(R % 2 == 1, "odd radix expected");
+        constexpr int H = (R - 1) / 2;
+        cplx a[H], b[H];
+#pragma unroll
+        for (int q = 1; q <= H; ++q) {
+            a[q - 1] = cadd(v[q], v[R - q]);
+            b[q - 1] = csub(v[q], v[R - q]);
+        }
+        const cplx v0 = v[0];
+        cplx s0 = v0;
+#pragma unroll
+        for (int q = 0; q < H; ++q) s0 = cadd(s0, a[q]);
+        v[0] = s0;
+#pragma unroll
+        for (int k = 1; k <= H; ++k) {
+            double pr = v0.x, pi = v0.y, qr = 0.0, qi = 0.0;
+#pragma unroll
+            for (int q = 1; q <= H; ++q) {
+                const cplx w = wr[(q * k) % R];   // (cos, -sin)
+                pr = __builtin_fma(a[q - 1].x, w.x, pr);
+                pi = __builtin_fma(a[q - 1].y, w.x, pi);
+                qr = __builtin_fma(b[q - 1].y, -w.y, qr);
+                qi = __builtin_fma(b[q - 1].x, w.y, qi);
+            }
+            v[k] = make_double2(pr + qr, pi + qi);
+            v[R - k] = make_double2(pr - qr, pi - qi);
+        }
+    }
+}
+
+template <int R, int TPB>
+__global__ __launch_bounds__(TPB) void fft_pass_kernel(PassArgs a) {
+    const long long m = a.n / R;
+    const long long j = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (j >= m) return;
+    const long long row = blockIdx.y;
+    const cplx* __restrict__ in = a.in + row * a.n;
+    cplx* __restrict__ out = a.out + row * a.n;
+    const long long k = j % a.ns;
+    cplx v[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const long long idx = j + q * m;
+        v[q] = (idx < a.nonzero_len) ? in[idx] : make_double2(0.0, 0.0);
+    }
+    if (a.ns > 1) {
+        const long long tstep = k * (a.n / (a.ns * R));
+        long long t = 0;
+#pragma unroll
+        for (int q = 1; q < R; ++q) {
+            t += tstep;
+            if (t >= a.n) t -= a.n;
+            v[q] = cmul(v[q], twiddle(a, t));
+        }
+    }
+    dft_small<R>(v, a.wr);
+    const long long j0 = (j / a.ns) * a.ns * R + k;
+#pragma unroll
+    for (int q = 0; q < R; ++q) out[j0 + q * a.ns] = v[q];
+}
+
+// ---- plan -----------------------------------------------------------------------------------
+
+static const int kRadixList[] = {16, 8, 4, 2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31};
+static cplx* g_wr[32] = {nullptr};   // per-radix root tables on the current device
+static int g_wr_device = -1;
+
+static int ensure_roots(int R) {
+    int dev = 0;
+    SGX_HIP(hipGetDevice(&dev));
+    if (g_wr_device != dev) {
+        for (auto& p : g_wr) p = nullptr;   // tables of another device are left allocated there
+        g_wr_device = dev;
+    }
+    if (g_wr[R]) return SGX_OK;
+    std::vector<cplx> w((size_t)R);
+    for (int m = 0; m < R; ++m) {
+        const long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)m / (long double)R;
+        w[(size_t)m] = make_double2((double)cosl(ang), (double)sinl(ang));
+    }
+    SGX_HIP(hipMalloc((void**)&g_wr[R], sizeof(cplx) * (size_t)R));
+    SGX_HIP(hipMemcpy(g_wr[R], w.data(), sizeof(cplx) * (size_t)R, hipMemcpyHostToDevice));
+    return SGX_OK;
+}
+
+int sgx_fft_plan_create(FftPlan* p, int64_t n) {
+    if (p->n == n && p->tw_hi) return SGX_OK;
+    sgx_fft_plan_destroy(p);
+    if (n < 2) {
+        sgx_set_error("FFT length %lld not supported", (long long)n);
+        return SGX_E_ARG;
+    }
+    int64_t rem = n;
+    p->radices.clear();
+    std::vector<int> odd;
+    for (int r : kRadixList) {
+        while (rem % r == 0) {
+            if (r % 2 == 0)
+                p->radices.push_back(r);
+            else
+                odd.push_back(r);
+            rem /= r;
+        }
+    }
+    if (rem != 1) {
+        sgx_set_error("FFT length %lld has a prime factor above 31 (samplesPerCode must factor into 2..31)",
+                      (long long)n);
+        return SGX_E_ARG;
+    }
+    for (int r : odd) p->radices.push_back(r);
+    for (int r : p->radices) {
+        int rc = ensure_roots(r);
+        if (rc != SGX_OK) return rc;
+    }
+    p->lo_bits = (n > (1 << 18)) ? 11 : 8;
+    const int64_t lo_n = 1ll << p->lo_bits;
+    const int64_t hi_n = (n + lo_n - 1) / lo_n + 1;
+    std::vector<cplx> lo((size_t)lo_n), hi((size_t)hi_n);
+    const long double twopi = 2.0L * 3.14159265358979323846264338327950288L;
+    for (int64_t t = 0; t < lo_n; ++t) {
+        const long double ang = -twopi * (long double)t / (long double)n;
+        lo[(size_t)t] = make_double2((double)cosl(ang), (double)sinl(ang));
+    }
+    for (int64_t h = 0; h < hi_n; ++h) {
+        const long double ang = -twopi * (long double)((h << p->lo_bits) % n) / (long double)n;
+        hi[(size_t)h] = make_double2((double)cosl(ang), (double)sinl(ang));
+    }
+    SGX_HIP(hipMalloc((void**)&p->tw_lo, sizeof(cplx) * (size_t)lo_n));
+    SGX_HIP(hipMalloc((void**)&p->tw_hi, sizeof(cplx) * (size_t)hi_n));
+    SGX_HIP(hipMemcpy(p->tw_lo, lo.data(), sizeof(cplx) * (size_t)lo_n, hipMemcpyHostToDevice));
+    SGX_HIP(hipMemcpy(p->tw_hi, hi.data(), sizeof(cplx) * (size_t)hi_n, hipMemcpyHostToDevice));
+    p->n = n;
+    return SGX_OK;
+}
+
+void sgx_fft_plan_destroy(FftPlan* p) {
+    if (p->tw_hi) hipFree(p->tw_hi);
+    if (p->tw_lo) hipFree(p->tw_lo);
+    p->tw_hi = p->tw_lo = nullptr;
+    p->n = 0;
+    p->radices.clear();
+}
+
+template <int R, int TPB>
+static void launch_pass(const PassArgs& a, int64_t rows, hipStream_t st) {
+    const long long m = a.n / R;
+    dim3 grid((unsigned)((m + TPB - 1) / TPB), (unsigned)rows);
+    fft_pass_kernel<R, TPB><<<grid, TPB, 0, st>>>(a);
+}
+
+int sgx_fft_forward(const FftPlan* p, cplx* a, cplx* b, int64_t rows, hipStream_t st, cplx** result,
+                    int64_t nonzero_len) {
+    if (!p->tw_hi || rows < 1 || rows > 65535) {
+        sgx_set_error("sgx_fft_forward: bad plan or row count %lld", (long long)rows);
+        return SGX_E_ARG;
+    }
+    cplx* src = a;
+    cplx* dst = b;
+    long long ns = 1;
+    bool first = true;
+    for (int r : p->radices) {
+        PassArgs pa;
+        pa.in = src;
+        pa.out = dst;
+        pa.tw_hi = p->tw_hi;
+        pa.tw_lo = p->tw_lo;
+        pa.wr = g_wr[r];
+        pa.n = p->n;
+        pa.ns = ns;
+        pa.nonzero_len = first ? nonzero_len : p->n;
+        pa.lo_bits = p->lo_bits;
+        switch (r) {
+            case 16: launch_pass<16, 128>(pa, rows, st); break;
+            case 8: launch_pass<8, 256>(pa, rows, st); break;
+            case 4: launch_pass<4, 256>(pa, rows, st); break;
+            case 2: launch_pass<2, 256>(pa, rows, st); break;
+            case 3: launch_pass<3, 256>(pa, rows, st); break;
+            case 5: launch_pass<5, 256>(pa, rows, st); break;
+            case 7: launch_pass<7, 256>(pa, rows, st); break;
+            case 11: launch_pass<11, 128>(pa, rows, st); break;
+            case 13: launch_pass<13, 128>(pa, rows, st); break;
+            case 17: launch_pass<17, 128>(pa, rows, st); break;
+            case 19: launch_pass<19, 128>(pa, rows, st); break;
+            case 23: launch_pass<23, 64>(pa, rows, st); break;
+            case 29: launch_pass<29, 64>(pa, rows, st); break;
+            case 31: launch_pass<31, 64>(pa, rows, st); break;
+            default:
+                sgx_set_error("radix %d not instantiated", r);
+                return SGX_E_ARG;
+        }
+        ns *= r;
+        first = false;
+        cplx* t = src;
+        src = dst;
+        dst = t;
+    }
+    SGX_HIP(hipGetLastError());
+    *result = src;
+    return SGX_OK;
+}

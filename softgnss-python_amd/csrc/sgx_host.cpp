@@ -1,0 +1,379 @@
+// Host side of libsgx.so: error text, exact host helpers, device context, IF records, RCCL gather.
+// Compiled with -ffp-contract=off: the index math below must round exactly like the reference's
+// numpy expressions.
+#include <dlfcn.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdlib.h>
+
+#include "sgx_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void sgx_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* sgx_version(void) { return SGX_VERSION_STR; }
+
+extern "C" int sgx_last_error(char* buf, size_t n) {
+    if (!buf || n == 0) return SGX_E_ARG;
+    strncpy(buf, g_err, n - 1);
+    buf[n - 1] = 0;
+    return SGX_OK;
+}
+
+// ---- exact host helpers ---------------------------------------------------------------------
+
+// G2 delays of PRN 1..32 (reference initialize.py:251-254 keeps 51 entries; only 32 reachable).
+static const int kG2Delay[32] = {5,   6,   7,   8,   17,  18,  139, 140, 141, 251, 252,
+                                 254, 255, 256, 257, 258, 469, 470, 471, 472, 473, 474,
+                                 509, 512, 513, 514, 515, 516, 859, 860, 861, 862};
+
+// Gold code of PRN index prn0 as +-1 chips. Bit-level statement of initialize.py:234-302:
+// registers start all-ones, output = stage 10, G1 feedback 3^10, G2 feedback 2^3^6^8^9^10,
+// G2 delayed by kG2Delay, chip = +1 where g1^g2 == 1.
+int sgx_host_ca_code(int prn0, int8_t* out) {
+    if (prn0 < 0 || prn0 > 31) return SGX_E_ARG;
+    uint32_t r1 = 0x3FF, r2 = 0x3FF;   // bit i = stage i+1
+    int8_t g1[1023], g2[1023];
+    for (int i = 0; i < 1023; ++i) {
+        g1[i] = (r1 >> 9) & 1;
+        g2[i] = (r2 >> 9) & 1;
+        uint32_t f1 = ((r1 >> 2) ^ (r1 >> 9)) & 1;
+        uint32_t f2 = ((r2 >> 1) ^ (r2 >> 2) ^ (r2 >> 5) ^ (r2 >> 7) ^ (r2 >> 8) ^ (r2 >> 9)) & 1;
+        r1 = ((r1 << 1) | f1) & 0x3FF;
+        r2 = ((r2 << 1) | f2) & 0x3FF;
+    }
+    const int d = kG2Delay[prn0];
+    for (int i = 0; i < 1023; ++i) {
+        int j = i - d;
+        if (j < 0) j += 1023;
+        out[i] = (g1[i] ^ g2[j]) ? 1 : -1;
+    }
+    return SGX_OK;
+}
+
+int64_t sgx_host_samples_per_code(const sgx_settings* s) {
+    // initialize.py:185: long(round(fs / (fc / codeLength))), numpy round = half to even
+    return (int64_t)nearbyint(s->samplingFreq / (s->codeFreqBasis / (double)s->codeLength));
+}
+
+extern "C" int sgx_samples_per_code(const sgx_settings* s, int64_t* n) {
+    SGX_CHECK_ARG(s && n);
+    *n = sgx_host_samples_per_code(s);
+    return SGX_OK;
+}
+
+extern "C" int sgx_generate_ca_code(int32_t prn0, double* out) {
+    SGX_CHECK_ARG(out);
+    int8_t c[1023];
+    if (sgx_host_ca_code(prn0, c) != SGX_OK) {
+        sgx_set_error("prn index %d outside 0..31", prn0);   // reference asserts (initialize.py:250)
+        return SGX_E_ARG;
+    }
+    for (int i = 0; i < 1023; ++i) out[i] = (double)c[i];
+    return SGX_OK;
+}
+
+extern "C" int sgx_make_ca_table(const sgx_settings* s, double* out) {
+    SGX_CHECK_ARG(s && out);
+    const int64_t n = sgx_host_samples_per_code(s);
+    SGX_CHECK_ARG(n > 0 && s->codeLength == 1023);
+    const double ts = 1.0 / s->samplingFreq;
+    const double tc = 1.0 / s->codeFreqBasis;
+    std::vector<int> idx((size_t)n);
+    for (int64_t k = 1; k <= n; ++k) {
+        const double v = (ts * (double)k) / tc;   // initialize.py:222: multiply, then divide
+        idx[(size_t)(k - 1)] = (int)ceil(v) - 1;
+    }
+    idx[(size_t)(n - 1)] = 1022;                  // initialize.py:226
+    for (int p = 0; p < 32; ++p) {
+        int8_t c[1023];
+        sgx_host_ca_code(p, c);
+        double* row = out + (size_t)p * (size_t)n;
+        for (int64_t k = 0; k < n; ++k) {
+            const int j = idx[(size_t)k];
+            if (j < 0 || j > 1022) {
+                sgx_set_error("code index %d out of range at sample %lld", j, (long long)k);
+                return SGX_E_ARG;
+            }
+            row[k] = (double)c[j];
+        }
+    }
+    return SGX_OK;
+}
+
+extern "C" int sgx_calc_loop_coef(double lbw, double zeta, double k, double* tau1, double* tau2) {
+    SGX_CHECK_ARG(tau1 && tau2);
+    const double wn = lbw * 8.0 * zeta / (4.0 * (zeta * zeta) + 1);   // initialize.py:321
+    *tau1 = k / (wn * wn);
+    *tau2 = 2.0 * zeta / wn;
+    return SGX_OK;
+}
+
+// ---- device context --------------------------------------------------------------------------
+
+extern "C" int sgx_device_count(int* n) {
+    SGX_CHECK_ARG(n);
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *n = 0;
+        sgx_set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+        return SGX_E_HIP;
+    }
+    *n = c;
+    return SGX_OK;
+}
+
+extern "C" int sgx_ctx_create(const sgx_settings* s, int device, sgx_ctx** out) {
+    SGX_CHECK_ARG(s && out);
+    SGX_CHECK_ARG(s->codeLength == 1023 && s->samplingFreq > 0 && s->codeFreqBasis > 0);
+    SGX_HIP(hipSetDevice(device));
+    sgx_ctx* c = new sgx_ctx();
+    c->s = *s;
+    c->device = device;
+    c->n_code = sgx_host_samples_per_code(s);
+    memset(&c->timing, 0, sizeof(c->timing));
+    SGX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 6; ++i) SGX_HIP(hipEventCreate(&c->ev[i]));
+    std::vector<int8_t> codes(32 * 1023);
+    for (int p = 0; p < 32; ++p) sgx_host_ca_code(p, codes.data() + p * 1023);
+    SGX_HIP(hipMalloc((void**)&c->d_codes, codes.size()));
+    SGX_HIP(hipMemcpy(c->d_codes, codes.data(), codes.size(), hipMemcpyHostToDevice));
+    SGX_HIP(hipMalloc(&c->d_small, 1 << 20));
+    SGX_HIP(hipHostMalloc(&c->h_small, 1 << 20, hipHostMallocDefault));
+    *out = c;
+    return SGX_OK;
+}
+
+extern "C" int sgx_ctx_destroy(sgx_ctx* c) {
+    if (!c) return SGX_OK;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    sgx_fft_plan_destroy(&c->plan_code);
+    sgx_fft_plan_destroy(&c->plan_fine);
+    hipFree(c->d_codes);
+    hipFree(c->d_fwd);
+    hipFree(c->d_codefd);
+    hipFree(c->d_work[0]);
+    hipFree(c->d_work[1]);
+    hipFree(c->d_pow);
+    hipFree(c->d_fine[0]);
+    hipFree(c->d_fine[1]);
+    hipFree(c->d_small);
+    hipFree(c->d_trk_out);
+    if (c->h_small) hipHostFree(c->h_small);
+    for (int i = 0; i < 6; ++i)
+        if (c->ev[i]) hipEventDestroy(c->ev[i]);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return SGX_OK;
+}
+
+extern "C" int sgx_ctx_sync(sgx_ctx* c) {
+    SGX_CHECK_ARG(c);
+    SGX_HIP(hipSetDevice(c->device));
+    SGX_HIP(hipStreamSynchronize(c->stream));
+    return SGX_OK;
+}
+
+extern "C" int sgx_get_timing(sgx_ctx* c, sgx_timing* out) {
+    SGX_CHECK_ARG(c && out);
+    *out = c->timing;
+    return SGX_OK;
+}
+
+// ---- IF records ------------------------------------------------------------------------------
+
+static int if_alloc(sgx_ctx* c, size_t n, sgx_if** out) {
+    sgx_if* r = new sgx_if();
+    r->n = n;
+    r->device = c->device;
+    hipError_t e = hipMalloc((void**)&r->d, n + SGX_IF_PAD);
+    if (e != hipSuccess) {
+        delete r;
+        sgx_set_error("hipMalloc(%zu) for an IF record failed: %s", n + SGX_IF_PAD, hipGetErrorString(e));
+        return SGX_E_NOMEM;
+    }
+    e = hipMemsetAsync(r->d + n, 0, SGX_IF_PAD, c->stream);
+    if (e != hipSuccess) {
+        hipFree(r->d);
+        delete r;
+        sgx_set_error("hipMemsetAsync failed: %s", hipGetErrorString(e));
+        return SGX_E_HIP;
+    }
+    *out = r;
+    return SGX_OK;
+}
+
+int sgx_if_alloc_internal(sgx_ctx* c, size_t n, sgx_if** out) { return if_alloc(c, n, out); }
+
+extern "C" int sgx_if_upload(sgx_ctx* c, const int8_t* host, size_t n, sgx_if** out) {
+    SGX_CHECK_ARG(c && out && (host || n == 0));
+    SGX_HIP(hipSetDevice(c->device));
+    sgx_if* r = nullptr;
+    int rc = if_alloc(c, n, &r);
+    if (rc != SGX_OK) return rc;
+    if (n) {
+        hipError_t e = hipMemcpyAsync(r->d, host, n, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // caller may free `host` on return
+        if (e != hipSuccess) {
+            hipFree(r->d);
+            delete r;
+            sgx_set_error("H2D copy of the IF record failed: %s", hipGetErrorString(e));
+            return SGX_E_HIP;
+        }
+    }
+    *out = r;
+    return SGX_OK;
+}
+
+extern "C" int sgx_if_download(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n, int8_t* host) {
+    SGX_CHECK_ARG(c && r && host);
+    SGX_CHECK_ARG(offset <= r->n && n <= r->n - offset);
+    SGX_HIP(hipSetDevice(c->device));
+    SGX_HIP(hipMemcpyAsync(host, r->d + offset, n, hipMemcpyDeviceToHost, c->stream));
+    SGX_HIP(hipStreamSynchronize(c->stream));
+    return SGX_OK;
+}
+
+extern "C" int sgx_if_length(const sgx_if* r, size_t* n) {
+    SGX_CHECK_ARG(r && n);
+    *n = r->n;
+    return SGX_OK;
+}
+
+extern "C" int sgx_if_free(sgx_ctx* c, sgx_if* r) {
+    if (!r) return SGX_OK;
+    if (c) {
+        hipSetDevice(c->device);
+        hipStreamSynchronize(c->stream);
+    }
+    hipFree(r->d);
+    delete r;
+    return SGX_OK;
+}
+
+// ---- RCCL peak gather -------------------------------------------------------------------------
+// librccl is opened lazily so that the library loads (and the host helpers work) on machines
+// without a GPU.
+
+struct RcclUid {
+    char internal[128];
+};
+typedef int (*fn_get_uid)(RcclUid*);
+typedef int (*fn_init_rank)(void**, int, RcclUid, int);
+typedef int (*fn_allgather)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef int (*fn_destroy)(void*);
+typedef const char* (*fn_errstr)(int);
+
+static struct {
+    void* h;
+    fn_get_uid get_uid;
+    fn_init_rank init_rank;
+    fn_allgather allgather;
+    fn_destroy destroy;
+    fn_errstr errstr;
+} g_rccl = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+
+static int rccl_load() {
+    if (g_rccl.h) return SGX_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* nm : names) {
+        h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) {
+        sgx_set_error("cannot dlopen librccl: %s", dlerror());
+        return SGX_E_RCCL;
+    }
+    g_rccl.get_uid = (fn_get_uid)dlsym(h, "ncclGetUniqueId");
+    g_rccl.init_rank = (fn_init_rank)dlsym(h, "ncclCommInitRank");
+    g_rccl.allgather = (fn_allgather)dlsym(h, "ncclAllGather");
+    g_rccl.destroy = (fn_destroy)dlsym(h, "ncclCommDestroy");
+    g_rccl.errstr = (fn_errstr)dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.get_uid || !g_rccl.init_rank || !g_rccl.allgather || !g_rccl.destroy) {
+        sgx_set_error("librccl lacks an expected symbol");
+        dlclose(h);
+        return SGX_E_RCCL;
+    }
+    g_rccl.h = h;
+    return SGX_OK;
+}
+
+struct sgx_comm {
+    sgx_ctx* ctx;
+    void* comm;
+    int n_ranks, rank;
+    void* d_send;
+    void* d_recv;
+    size_t cap;
+};
+
+static int rccl_fail(const char* what, int code) {
+    sgx_set_error("%s failed: %s", what, g_rccl.errstr ? g_rccl.errstr(code) : "rccl error");
+    return SGX_E_RCCL;
+}
+
+extern "C" int sgx_comm_unique_id(uint8_t id[128]) {
+    SGX_CHECK_ARG(id);
+    int rc = rccl_load();
+    if (rc != SGX_OK) return rc;
+    RcclUid u;
+    int e = g_rccl.get_uid(&u);
+    if (e != 0) return rccl_fail("ncclGetUniqueId", e);
+    memcpy(id, u.internal, 128);
+    return SGX_OK;
+}
+
+extern "C" int sgx_comm_create(sgx_ctx* c, int32_t n_ranks, int32_t rank, const uint8_t id[128],
+                               sgx_comm** out) {
+    SGX_CHECK_ARG(c && id && out && n_ranks >= 1 && rank >= 0 && rank < n_ranks);
+    int rc = rccl_load();
+    if (rc != SGX_OK) return rc;
+    SGX_HIP(hipSetDevice(c->device));
+    RcclUid u;
+    memcpy(u.internal, id, 128);
+    void* comm = nullptr;
+    int e = g_rccl.init_rank(&comm, n_ranks, u, rank);
+    if (e != 0) return rccl_fail("ncclCommInitRank", e);
+    sgx_comm* m = new sgx_comm();
+    m->ctx = c;
+    m->comm = comm;
+    m->n_ranks = n_ranks;
+    m->rank = rank;
+    m->cap = 1 << 16;
+    SGX_HIP(hipMalloc(&m->d_send, m->cap));
+    SGX_HIP(hipMalloc(&m->d_recv, m->cap * (size_t)n_ranks));
+    *out = m;
+    return SGX_OK;
+}
+
+extern "C" int sgx_comm_allgather(sgx_comm* m, const void* send, void* recv, size_t bytes) {
+    SGX_CHECK_ARG(m && send && recv && bytes > 0 && bytes <= m->cap);
+    sgx_ctx* c = m->ctx;
+    SGX_HIP(hipSetDevice(c->device));
+    SGX_HIP(hipMemcpyAsync(m->d_send, send, bytes, hipMemcpyHostToDevice, c->stream));
+    int e = g_rccl.allgather(m->d_send, m->d_recv, bytes, /*ncclInt8*/ 0, m->comm, c->stream);
+    if (e != 0) return rccl_fail("ncclAllGather", e);
+    SGX_HIP(hipMemcpyAsync(recv, m->d_recv, bytes * (size_t)m->n_ranks, hipMemcpyDeviceToHost, c->stream));
+    SGX_HIP(hipStreamSynchronize(c->stream));
+    return SGX_OK;
+}
+
+extern "C" int sgx_comm_destroy(sgx_comm* m) {
+    if (!m) return SGX_OK;
+    hipSetDevice(m->ctx->device);
+    hipStreamSynchronize(m->ctx->stream);
+    if (m->comm && g_rccl.destroy) g_rccl.destroy(m->comm);
+    hipFree(m->d_send);
+    hipFree(m->d_recv);
+    delete m;
+    return SGX_OK;
+}

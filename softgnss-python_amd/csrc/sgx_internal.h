@@ -1,0 +1,86 @@
+// Internal declarations shared by the translation units of libsgx.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+#include "sgx.h"
+
+#define SGX_VERSION_STR "sgx 0.1 (gfx950)"
+
+void sgx_set_error(const char* fmt, ...);
+
+#define SGX_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            sgx_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,    \
+                          __LINE__);                                                           \
+            return SGX_E_HIP;                                                                  \
+        }                                                                                      \
+    } while (0)
+
+#define SGX_CHECK_ARG(cond)                                                 \
+    do {                                                                    \
+        if (!(cond)) {                                                      \
+            sgx_set_error("bad argument: %s (%s:%d)", #cond, __FILE__, __LINE__); \
+            return SGX_E_ARG;                                               \
+        }                                                                   \
+    } while (0)
+
+typedef double2 cplx;   // complex128 as (re, im)
+
+// Twiddle tables for one FFT length: W_N^t = hi[t >> lo_bits] * lo[t & lo_mask]
+struct FftPlan {
+    int64_t n = 0;
+    int lo_bits = 0;
+    cplx* tw_hi = nullptr;   // device
+    cplx* tw_lo = nullptr;   // device
+    std::vector<int> radices;
+};
+
+struct sgx_if {
+    int8_t* d = nullptr;   // device pointer; allocation is padded by SGX_IF_PAD zero bytes
+    size_t n = 0;
+    int device = 0;
+};
+#define SGX_IF_PAD 256
+
+struct sgx_ctx {
+    sgx_settings s;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    sgx_timing timing;
+    int64_t n_code = 0;          // samplesPerCode
+    int8_t* d_codes = nullptr;   // [32][1023] +-1
+    // acquisition scratch (lazily sized)
+    FftPlan plan_code;           // length samplesPerCode
+    FftPlan plan_fine;           // length 8 * 2^ceil(log2(10 N))
+    cplx* d_fwd = nullptr;       // [n_blocks][n_bins][N] mixed-signal spectra
+    cplx* d_codefd = nullptr;    // [32][N] code spectra
+    cplx* d_work[2] = {nullptr, nullptr};   // ping-pong [rows][N]
+    double* d_pow = nullptr;     // [rows][N] correlation power
+    cplx* d_fine[2] = {nullptr, nullptr};
+    size_t cap_fwd = 0, cap_code = 0, cap_w0 = 0, cap_w1 = 0, cap_pow = 0, cap_f0 = 0, cap_f1 = 0;   // bytes
+    void* d_small = nullptr;     // small result area
+    void* h_small = nullptr;     // pinned mirror
+    // tracking
+    double* d_trk_out = nullptr;
+    size_t trk_out_elems = 0;
+};
+
+// sgx_host.cpp
+int sgx_host_ca_code(int prn0, int8_t* out /*1023*/);
+int64_t sgx_host_samples_per_code(const sgx_settings* s);
+
+// sgx_fft.hip
+int sgx_fft_plan_create(FftPlan* p, int64_t n);
+void sgx_fft_plan_destroy(FftPlan* p);
+// Forward DFT of `rows` contiguous rows of length p->n. Result lands in *result (a or b).
+int sgx_fft_forward(const FftPlan* p, cplx* a, cplx* b, int64_t rows, hipStream_t st, cplx** result,
+                    int64_t nonzero_len);
+
+// sgx_synth.hip / sgx_acq.hip / sgx_trk.hip provide the C-ABI entry points directly.

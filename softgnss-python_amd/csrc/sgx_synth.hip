@@ -1,0 +1,96 @@
+// Synthetic IF generator on the device: bit-identical twin of softgnss-python_amd/synth.py.
+// Integer arithmetic only. HBM-write bound: 16 samples per lane, one 16-byte store each.
+#include "sgx_internal.h"
+
+int sgx_if_alloc_internal(sgx_ctx* c, size_t n, sgx_if** out);
+
+#define GOLDEN 0x9E3779B97F4A7C15ull
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+    z ^= z >> 30;
+    z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27;
+    z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+
+struct SynthArgs {
+    sgx_scene sc;
+};
+
+__global__ __launch_bounds__(256) void synth_kernel(int8_t* __restrict__ out, uint64_t offset, uint64_t n,
+                                                    const int8_t* __restrict__ codes, SynthArgs a) {
+    __shared__ int8_t s_code[SGX_MAX_SATS][1024];
+    __shared__ int16_t s_lut[256];
+    const int nsat = a.sc.n_sats;
+    for (int i = threadIdx.x; i < nsat * 1024; i += blockDim.x) {
+        const int s = i >> 10, k = i & 1023;
+        s_code[s][k] = (k < 1023) ? codes[(a.sc.sats[s].prn - 1) * 1023 + k] : 0;
+    }
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_lut[i] = a.sc.cos_lut[i];
+    __syncthreads();
+
+    const uint64_t groups = (n + 15) / 16;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups;
+         g += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            const uint64_t idx = offset + g * 16 + b;
+            const uint64_t h = splitmix64(a.sc.seed + (idx + 1) * GOLDEN);
+            const int s4 = (int)(h & 0xFF) + (int)((h >> 8) & 0xFF) + (int)((h >> 16) & 0xFF) +
+                           (int)((h >> 24) & 0xFF);
+            int acc = ((s4 - 510) * 35) >> 8;
+            for (int s = 0; s < nsat; ++s) {
+                const sgx_sat& st = a.sc.sats[s];
+                const uint64_t cp = idx * st.code_fcw + st.code_c0;
+                const uint64_t chipw = cp >> 32;
+                const uint32_t chip = (uint32_t)(chipw % 1023ull);
+                const uint64_t bit = chipw / (1023ull * 20ull);
+                const uint64_t navh = splitmix64(st.nav_seed + (bit + 1) * GOLDEN);
+                const int nav = 1 - 2 * (int)(navh & 1);
+                const uint32_t ph = st.car_ph0 + (uint32_t)(idx * (uint64_t)st.car_fcw);
+                const int cv = s_lut[ph >> 24];
+                acc += (st.amp * (int)s_code[s][chip] * nav * cv + 64) >> 7;
+            }
+            acc = acc < -127 ? -127 : (acc > 127 ? 127 : acc);
+            w[b >> 2] |= ((uint32_t)(acc & 0xFF)) << ((b & 3) * 8);
+        }
+        if (g * 16 + 16 <= n) {
+            *reinterpret_cast<uint4*>(out + g * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+        } else {
+            for (int b = 0; b < 16 && g * 16 + b < n; ++b)
+                out[g * 16 + b] = (int8_t)((w[b >> 2] >> ((b & 3) * 8)) & 0xFF);
+        }
+    }
+}
+
+extern "C" int sgx_if_synth(sgx_ctx* c, const sgx_scene* scene, uint64_t offset, size_t n, sgx_if** out) {
+    SGX_CHECK_ARG(c && scene && out);
+    SGX_CHECK_ARG(scene->n_sats >= 0 && scene->n_sats <= SGX_MAX_SATS);
+    for (int s = 0; s < scene->n_sats; ++s) SGX_CHECK_ARG(scene->sats[s].prn >= 1 && scene->sats[s].prn <= 32);
+    SGX_HIP(hipSetDevice(c->device));
+    sgx_if* r = nullptr;
+    int rc = sgx_if_alloc_internal(c, n, &r);
+    if (rc != SGX_OK) return rc;
+    SynthArgs a;
+    a.sc = *scene;
+    const uint64_t groups = (n + 15) / 16;
+    int blocks = (int)((groups + 255) / 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    hipEventRecord(c->ev[0], c->stream);
+    synth_kernel<<<blocks, 256, 0, c->stream>>>(r->d, offset, (uint64_t)n, c->d_codes, a);
+    hipEventRecord(c->ev[1], c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) {
+        sgx_if_free(c, r);
+        sgx_set_error("synth kernel failed: %s", hipGetErrorString(e));
+        return SGX_E_HIP;
+    }
+    hipEventElapsedTime(&c->timing.synth_ms, c->ev[0], c->ev[1]);
+    *out = r;
+    return SGX_OK;
+}

@@ -1,0 +1,146 @@
+"""Settings / Result / TruePosition with the reference's names (reference initialize.py:20-185).
+
+The three helpers the hot path calls - generateCAcode, makeCaTable, calcLoopCoef - are answered
+by libsgx.so's exact host routines (include/sgx.h), not by Python arithmetic.
+"""
+import ctypes as C
+import datetime
+
+import numpy as np
+
+from . import _native
+
+
+class Result(object):
+    """Base of AcquisitionResult / TrackingResult (reference initialize.py:20-46)."""
+
+    def __init__(self, settings):
+        self._settings = settings
+        self._results = None
+        self._channels = None
+
+    @property
+    def settings(self):
+        return self._settings
+
+    @property
+    def channels(self):
+        assert isinstance(self._channels, np.recarray)
+        return self._channels
+
+    @property
+    def results(self):
+        assert isinstance(self._results, np.recarray)
+        return self._results
+
+    @results.setter
+    def results(self, records):
+        assert isinstance(records, np.recarray)
+        self._results = records
+
+    def plot(self):
+        pass
+
+
+class TruePosition(object):
+    """E/N/U holder (reference initialize.py:49-77)."""
+
+    def __init__(self):
+        self.E = None
+        self.N = None
+        self.U = None
+
+
+class Settings(object):
+    """Receiver configuration; attribute names and defaults of reference initialize.py:81-173."""
+
+    def __init__(self):
+        self.msToProcess = 37000.0
+        self.numberOfChannels = 8
+        self.skipNumberOfBytes = 0
+        self.fileName = 'GPSdata-DiscreteComponents-fs38_192-if9_55.bin'
+        self.dataType = 'int8'
+        self.IF = 9548000.0
+        self.samplingFreq = 38192000.0
+        self.codeFreqBasis = 1023000.0
+        self.codeLength = 1023
+        self.skipAcquisition = False
+        self.acqSatelliteList = range(1, 33)
+        self.acqSearchBand = 14.0
+        self.acqThreshold = 2.5
+        self.dllDampingRatio = 0.7
+        self.dllNoiseBandwidth = 2.0
+        self.dllCorrelatorSpacing = 0.5
+        self.pllDampingRatio = 0.7
+        self.pllNoiseBandwidth = 25.0
+        self.navSolPeriod = 500.0
+        self.elevationMask = 10.0
+        self.useTropCorr = True
+        self.truePosition = TruePosition()
+        self.plotTracking = True
+        self._c = 299792458.0
+        self._startOffset = 68.802
+
+    @property
+    def c(self):
+        return self._c
+
+    @property
+    def startOffset(self):
+        return self._startOffset
+
+    @property
+    def samplesPerCode(self):
+        n = C.c_int64(0)
+        st = _native.settings_struct(self)
+        _native.check(_native.lib().sgx_samples_per_code(C.byref(st), C.byref(n)))
+        return int(n.value)
+
+    def makeCaTable(self):
+        """float64[32, samplesPerCode] sampled C/A codes (reference initialize.py:188-231)."""
+        st = _native.settings_struct(self)
+        out = np.empty((32, self.samplesPerCode))
+        _native.check(_native.lib().sgx_make_ca_table(C.byref(st), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def generateCAcode(self, prn):
+        """float64[1023] of +-1 for PRN index 0..31 (reference initialize.py:234-302)."""
+        assert prn in range(0, 32)
+        out = np.empty(1023)
+        _native.check(_native.lib().sgx_generate_ca_code(int(prn), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    @staticmethod
+    def calcLoopCoef(LBW, zeta, k):
+        """(tau1, tau2) of the loop filter (reference initialize.py:304-328)."""
+        t1 = C.c_double(0)
+        t2 = C.c_double(0)
+        _native.check(_native.lib().sgx_calc_loop_coef(float(LBW), float(zeta), float(k), C.byref(t1),
+                                                       C.byref(t2)))
+        return t1.value, t2.value
+
+    def probeData(self, fileNameStr=None):
+        raise NotImplementedError("probeData is a plotting diagnostic outside the accelerated path "
+                                  "(reference initialize.py:330-417)")
+
+    def postProcessing(self, fileNameStr=None):
+        """acquire -> preRun -> track on a record file, the call sequence of reference
+        initialize.py:454-515 without plots and without the navigation solution.
+        Returns (acqResults, trackResults)."""
+        from . import acquisition, tracking
+        name = self.fileName if fileNameStr is None else fileNameStr
+        if not isinstance(name, str):
+            raise TypeError('File name must be a string')
+        with open(name, 'rb') as fid:
+            fid.seek(self.skipNumberOfBytes, 0)
+            data = np.fromfile(fid, self.dataType, 11 * self.samplesPerCode)
+            acqResults = acquisition.AcquisitionResult(self)
+            acqResults.acquire(data)
+            if not np.any(acqResults.carrFreq):
+                raise RuntimeError('No GNSS signals detected, signal processing finished.')
+            acqResults.preRun()
+            trackResults = tracking.TrackingResult(acqResults)
+            start = datetime.datetime.now()
+            trackResults.track(fid)
+            self.lastTrackingSeconds = (datetime.datetime.now() - start).total_seconds()
+        return acqResults, trackResults

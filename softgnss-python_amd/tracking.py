@@ -1,0 +1,97 @@
+"""TrackingResult with the reference's interface (reference tracking.py:6-295).
+
+track(fid) reads the part of the record the channels need, puts it in HBM and runs every
+channel's DLL/PLL loop in ONE launch of the persistent tracking kernel (sgx_track); the 13
+per-millisecond series come back as a record array shaped like the reference's.
+"""
+from __future__ import print_function
+
+import numpy as np
+
+from . import _native, engine
+from .initialize import Result
+from .record import DeviceFile
+
+RESULT_DTYPE = [('status', 'S1'), ('absoluteSample', 'object'), ('codeFreq', 'object'),
+                ('carrFreq', 'object'), ('I_P', 'object'), ('I_E', 'object'), ('I_L', 'object'),
+                ('Q_E', 'object'), ('Q_P', 'object'), ('Q_L', 'object'), ('dllDiscr', 'object'),
+                ('dllDiscrFilt', 'object'), ('pllDiscr', 'object'), ('pllDiscrFilt', 'object'),
+                ('PRN', 'int64')]   # reference tracking.py:285-293
+
+
+class TrackingResult(Result):
+    def __init__(self, acqResult, device=None):
+        self._results = None
+        self._channels = acqResult.channels
+        self._settings = acqResult.settings
+        self._device = device
+        self.series = None          # float64[n_active, 13, ms] in _native.SERIES order
+        self.kernel_ms = None       # HIP-event duration of the tracking kernel
+
+    def _window(self, fid, first, need):
+        """Bytes [first, first+need) of the reference's file, as an HBM record."""
+        ctx = engine.get_context(self._settings, self._device)
+        fid.seek(first, 0)
+        if hasattr(fid, 'fileno'):
+            try:
+                data = np.fromfile(fid, np.int8, need)
+            except (OSError, ValueError, AttributeError):
+                data = np.frombuffer(fid.read(need), dtype=np.int8)
+        else:
+            data = np.frombuffer(fid.read(need), dtype=np.int8)
+        return ctx.upload(data)
+
+    def track(self, fid):
+        """Code and carrier tracking of all channels (reference tracking.py:13-295).
+
+        fid   open binary file of int8 samples (seek/read/tell/close), or a DeviceFile over a
+              record already in HBM.  Each active channel starts at byte
+              skipNumberOfBytes + codePhase (tracking.py:107).
+        On a short record the reference prints a message, closes fid and returns None without
+        setting results (tracking.py:159-163); so does this method.
+        """
+        channel = self._channels
+        settings = self._settings
+        ctx = engine.get_context(settings, self._device)
+        ms = int(settings.msToProcess)            # float in the reference (Q9)
+        nch = int(settings.numberOfChannels)
+        active = [i for i in range(nch) if channel[i].PRN != 0]
+        if not active:
+            self._results = np.recarray((0,), dtype=RESULT_DTYPE)
+            self.series = np.empty((0, _native.NUM_SERIES, ms))
+            return
+        chans = [(int(channel[i].PRN), float(channel[i].acquiredFreq), float(channel[i].codePhase))
+                 for i in active]
+        own = None
+        if isinstance(fid, DeviceFile):
+            rec, file_off = fid.record, fid.file_offset
+        else:
+            n = settings.samplesPerCode
+            first = int(settings.skipNumberOfBytes + min(c[2] for c in chans))
+            last = int(settings.skipNumberOfBytes + max(c[2] for c in chans))
+            need = (last - first) + ms * (n + 2) + n      # a block is at most samplesPerCode + 1 long
+            own = rec = self._window(fid, first, need)
+            file_off = first
+        try:
+            series, done = ctx.track(rec, chans, ms, rec_file_offset=file_off)
+            self.kernel_ms = ctx.timing()["track_ms"]
+        finally:
+            if own is not None:
+                own.free()
+        if np.any(done != ms):
+            print('Not able to read the specified number of samples for tracking, exiting!')
+            fid.close()
+            return None
+        fid.seek(int(series[-1, 0, ms - 1]), 0)    # where the reference's last read left the file
+        self.series = series
+        res = np.recarray((len(active),), dtype=RESULT_DTYPE)
+        for j, i in enumerate(active):
+            res[j].status = channel[i].status
+            res[j].PRN = int(channel[i].PRN)
+            for k, name in enumerate(_native.SERIES):
+                res[j][name] = series[j, k]
+        self._results = res
+        return
+
+    def plot(self):
+        raise NotImplementedError("plotting is outside the accelerated path (reference tracking.py:297-426)")
