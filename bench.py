@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py - IF Msamples/s (and x real-time) through acquisition + tracking on MI355X.
+
+One "step" = the reference's postProcessing hot path on one synthetic 37.0 s int8 record resident
+in HBM: AcquisitionResult.acquire (32 PRNs, 2 x 1 ms coherent blocks, 29 Doppler bins, fine search)
+-> preRun -> TrackingResult.track (8 channels x 37 000 ms).  BASELINE.json configs[1] + configs[2].
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+N > 1 is launched one process per GPU by `python -m torch.distributed.run`; every rank tracks its
+own 8 channels on its own copy of the record (weak scaling, BASELINE.json config 5) and searches
+32/N of the PRNs, the peaks being all-gathered with RCCL (config 4's exchange).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md)
+REALTIME_MSPS = 38.192
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--ms", type=int, default=37000, help="code periods tracked (default: full config)")
+    ap.add_argument("--channels", type=int, default=8, help="tracking channels per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-trk-ms", type=int, default=2500, help="ms of 1-channel oracle tracking timed")
+    ap.add_argument("--cpu-acq-prns", type=int, default=2, help="PRNs of oracle acquisition timed")
+    return ap.parse_args()
+
+
+def cpu_baseline(pkg, scene, n_code, args, total_samples, n_ch, ms):
+    """Time the numpy oracle (a port of the reference's algorithm, as written) on a bounded sample of
+    the same workload and extrapolate linearly to the full step."""
+    from oracle import softgnss_oracle as orc
+    host = pkg.synth.generate(scene, pkg.synth.record_length(n_code, args.cpu_trk_ms))
+    s_acq = orc.OracleSettings(acqSatelliteList=list(range(1, args.cpu_acq_prns + 1)))
+    t0 = time.perf_counter()
+    r = orc.acquire(s_acq, host[:11 * n_code], as_written=True)   # PRN 1 is in the scene: fine search runs
+    t_acq = time.perf_counter() - t0
+    s_trk = orc.OracleSettings(numberOfChannels=1, msToProcess=float(args.cpu_trk_ms))
+    ch = orc.pre_run(s_trk, r)
+    t0 = time.perf_counter()
+    out = orc.track(s_trk, ch, host)
+    t_trk = time.perf_counter() - t0
+    assert out is not None
+    full = t_acq * (32.0 / args.cpu_acq_prns) + t_trk * (n_ch * ms / float(args.cpu_trk_ms))
+    return {"value": total_samples / full / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": "numpy oracle: as-written acquisition of %d PRNs on 11 ms (%.2f s) + 1 channel x %d ms "
+                      "tracking (%.2f s), scaled linearly to 32 PRNs + %d channels x %d ms"
+                      % (args.cpu_acq_prns, t_acq, args.cpu_trk_ms, t_trk, n_ch, ms),
+            "seconds_extrapolated": full}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    pkg = importlib.import_module("softgnss-python_amd")
+    shard = importlib.import_module("softgnss-python_amd.shard")
+    if pkg._native.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: libsgx has no CPU path")
+
+    s = pkg.Settings()
+    s.msToProcess = float(args.ms)
+    s.numberOfChannels = args.channels
+    n_code = s.samplesPerCode
+    ctx = pkg.engine.get_context(s, local)
+
+    # ---- peak gather transport ----------------------------------------------------------------
+    gather = shard.LocalGather()
+    if world > 1:
+        try:
+            uid = [pkg._native.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            gather = shard.RcclGather(pkg._native.Comm(ctx, world, rank, uid[0]))
+            gather.allgather(shard.pack_peaks([], dict(), 1))   # warm the communicator
+        except Exception as e:   # flagged, never silent
+            sys.stderr.write("[bench] rank %d: RCCL gather unavailable (%s); using host gather\n" % (rank, e))
+            gather = shard.HostGather(dist)
+
+    # ---- synthetic record, generated in HBM (bit-identical to softgnss-python_amd/synth.py) --------
+    scene = pkg.synth.Scene.default()
+    rec_len = pkg.synth.record_length(n_code, args.ms)
+    rec = ctx.synth(scene, rec_len)
+    signal = pkg.DeviceSignal(rec, 0, 11 * n_code)
+
+    def device_sync():
+        ctx.sync()
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        except ImportError:
+            pass
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    last = {}
+
+    def step():
+        acq = pkg.AcquisitionResult(s, device=local)
+        shard.acquire_sharded(acq, signal, rank, world, gather)
+        t = ctx.timing()
+        last["acquire_ms"] = t["acquire_ms"]
+        acq.preRun()
+        trk = pkg.TrackingResult(acq, device=local)
+        trk.track(pkg.DeviceFile(rec))
+        if trk.series is None:
+            raise RuntimeError("tracking ran out of record")
+        last["track_ms"] = trk.kernel_ms
+        last["series"] = trk.series
+        last["acq"] = acq
+        return trk
+
+    for _ in range(args.warmup):
+        step()
+    trk_kernel_ms = []
+    acq_ms = []
+    barrier()
+    device_sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        trk_kernel_ms.append(last["track_ms"])
+        acq_ms.append(last["acquire_ms"])
+    device_sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+
+    # ---- accounting ----------------------------------------------------------------------------
+    series = last["series"]
+    n_act = series.shape[0]
+    acq = last["acq"]
+    start_pos = np.array([acq.channels.codePhase[i] for i in range(n_act)])
+    streamed = float(np.sum(series[:, 0, -1] - start_pos))              # sum over channels of sum blksize
+    b_trk = streamed + n_act * args.ms * 13 * 8.0                       # SURVEY.md section 8(d) B_trk
+    k_ms = float(np.mean(trk_kernel_ms))
+    achieved = b_trk / (k_ms * 1e-3) / 1e9
+    samples_per_step = float(rec_len)                                   # IF samples of the record one rank consumes
+    value = world * samples_per_step * args.steps / elapsed / 1e6
+
+    if rank == 0:
+        out = {
+            "metric": "IF Msamples/s through acquisition + tracking (x real-time = value / 38.192)",
+            "value": value, "unit": "Msamples/s", "x_realtime": value / REALTIME_MSPS,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[1]+configs[2]: 32-PRN acquisition (2x1 ms coherent, 29 bins, fine search) "
+                                   "+ %d-channel DLL/PLL tracking x %d ms on one %.3f GB int8 record @38.192 Msps per GPU"
+                                   % (args.channels, args.ms, rec_len / 1e9),
+                       "channels_per_gpu": args.channels, "channels_active_per_gpu": int(n_act), "ms": args.ms,
+                       "prns_per_gpu": len(shard.plan_shards(32, world)[0]), "record_samples": rec_len,
+                       "peak_gather": gather.name},
+            "acquire_ms": float(np.mean(acq_ms)), "track_kernel_ms": k_ms,
+            "us_per_code_period": k_ms * 1e3 / args.ms,
+            "roofline": {"kernel": "trk_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": b_trk,
+                         "note": "8 channels = 8 of 256 CUs busy and 37 000 dependent steps per channel: "
+                                 "latency-bound, see DESIGN.md"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pkg, scene, n_code, args, samples_per_step, args.channels, args.ms)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
