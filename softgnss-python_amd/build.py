@@ -12,7 +12,8 @@ SOURCES = ["sgx_host.cpp", "sgx_synth.hip", "sgx_fft.hip", "sgx_acq.hip", "sgx_t
 HEADERS = [os.path.join(CSRC, "sgx_internal.h"), os.path.join(ROOT, "include", "sgx.h")]
 # -ffp-contract=off: chip-boundary index math must round exactly like the reference's numpy
 # expressions; fused multiply-adds are written explicitly where wanted.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip",
+EXTRA = os.environ.get("SGX_EXTRA_FLAGS", "").split()   # e.g. -DTRK_FINEPROF for the diagnosis build
+FLAGS = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip",
          "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-Wall", "-Wno-unused-result", "-Wno-unused-value"]
 
 

@@ -1,42 +1,65 @@
 // TrackingResult.track on gfx950 (reference tracking.py:13-295).
 //
-// One persistent 512-thread workgroup (8 waves, two per SIMD of one CU) per channel walks the
-// 1-ms code periods in order: every block's length, code ramps and NCO rates depend on the
-// previous block's six correlator sums, so a channel is a chain of `ms` dependent steps;
-// channels are independent and run side by side on different CUs.
+// A channel is a chain of `ms` dependent 1-ms steps: every block's length, code ramps and NCO rates
+// depend on the previous block's six correlator sums.  Channels are independent.  The kernel is
+// persistent: one launch walks all code periods of all channels.
 //
-// Per block (one loop iteration):
-//   map     every lane takes 16 consecutive int8 samples per pass as ONE aligned 16-byte load
-//           (a wave reads 1 KiB contiguous), 5 passes of 8 KiB.  The loads of block k+1 are
-//           issued before the reduce/filter phases of block k, so HBM latency hides behind them.
-//           * code replicas: the three linspace ramps t = fl(fl(i*step)+start) are monotonic
-//             and move 0.43 chip over 16 samples, so a group holds at most ONE chip switch
-//             (prompt at integer t, early/late together at half-integer t).  Chip index at the
-//             group's first sample and the switch sample come from the exact reference
-//             arithmetic (an estimate plus two exact probes), which keeps the indices
-//             bit-identical to code[int64(ceil(linspace(...)))].
-//           * carrier: sample b of a group has phasor G*B_b, G = the lane's group-start phasor
-//             (fp64 "turns" reduction + one sincospi per block, then a rotation per pass) and
-//             B_b = exp(j b delta) a 16-entry per-block table in LDS.  The lane accumulates
-//             sum x_b B_b over the group and over the samples after the switch (5 fp64 ops per
-//             sample), then applies G and the code signs once per group.
-//           * a group in which early and late switch at different samples (fp64 rounding at a
-//             chip boundary) falls back to an exact per-sample loop.
-//   reduce  six fp64 partials per lane -> LDS transpose -> 6 waves fold 8 partials each and
-//           finish with a DPP wave reduction.
-//   filter  wave 0 runs the PLL and prepares the carrier parameters while wave 1 runs the DLL
-//           and prepares block size and code ramps, both with the reference's fp64 operation
-//           order (-ffp-contract=off; fused multiply-adds only where written as __builtin_fma).
-// fp64 everywhere: 1e-7 errors in the sums move the code NCO enough to flip a chip-boundary
-// sample somewhere in a 37 s run, which is a 1e-3 relative blip.
+// Work decomposition
+//   * a block (~38 192 samples) is cut into UNITS of 256 groups x 16 samples (4 KiB of IF);
+//   * `split` workgroups of 256 threads (4 waves, one per SIMD of a CU) cooperate on one channel,
+//     member c takes units c, c+split, ...; split = 1 keeps a channel on one CU (throughput mode,
+//     many channels), split = 10 spreads a channel over ten CUs of one XCD (few channels, latency mode);
+//   * members exchange their six partial sums once per block through HBM/L2 as tagged 8-byte granules
+//     (write-through stores, relaxed agent-scope polls, epoch tags, double-buffered by epoch parity,
+//     bounded spins) and then every member runs the loop filter redundantly, so the next block's
+//     parameters need no broadcast.  Nothing depends on which CU or XCD a member lands on.
+//
+// Per block (one loop iteration)
+//   map     every lane takes 16 consecutive int8 samples of a unit as ONE aligned 16-byte load (a wave
+//           reads 1 KiB contiguous); the load of the lane's next unit (or the next block's first unit)
+//           is issued before the current one is processed, so HBM latency hides behind arithmetic.
+//           * code replicas: the three linspace ramps t = fl(fl(i*step)+start) are monotonic and move
+//             0.43 chip over 16 samples, so a group holds at most ONE chip switch (prompt at integer t,
+//             early/late together at half-integer t).  Chip index at the group's first sample and the
+//             switch sample come from the exact reference arithmetic (an estimate plus two exact
+//             probes), which keeps the indices bit-identical to code[int64(ceil(linspace(...)))].
+//           * carrier: sample b of a group has phasor G*B_b, G = the lane's group-start phasor (fp64
+//             "turns" reduction + one sincospi per block, then a rotation per further unit) and
+//             B_b = exp(j b delta), a 16-entry per-block table held in registers.  The lane accumulates
+//             sum x_b B_b over the group and over the samples after the switch (5 fp64 ops per sample),
+//             then applies G and the code signs once per group.
+//           * a group in which early and late switch at different samples (fp64 rounding at a chip
+//             boundary) falls back to an exact per-sample loop.
+//   reduce  six fp64 partials per lane -> LDS transpose -> 3 waves fold them (DPP) -> exchange.
+//   filter  wave 0 runs the PLL and prepares the carrier parameters while wave 1 runs the DLL and
+//           prepares block size and code ramps, both with the reference's fp64 operation order
+//           (-ffp-contract=off; fused multiply-adds only where written as __builtin_fma).
+// fp64 everywhere: 1e-7 errors in the sums move the code NCO enough to flip a chip-boundary sample
+// somewhere in a 37 s run, which is a 1e-3 relative blip.
 #include <math.h>
 #include <stdlib.h>
 
 #include "sgx_internal.h"
 
-#define TRK_THREADS 512
-#define TRK_PASSES 5                         // ceil((38192+1+15)/16 / 512)
-#define TRK_PASS (TRK_THREADS * 16)          // samples per pass (a power of two)
+#define TRK_THREADS 256
+#define TRK_UNIT (TRK_THREADS * 16)          // samples per unit (a power of two)
+#define TRK_MAX_SPLIT 10                     // 12 granules per member, two per gathering lane
+
+// -DTRK_FINEPROF: fine-grained phase timestamps of (member 0, lane 0); forces waits at every probe, so it
+// is a diagnosis build only (tools/ notes in DESIGN.md); the normal build compiles the probes away.
+#ifdef TRK_FINEPROF
+#define PROBE(k)                                                            \
+    do {                                                                    \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");         \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        const long long t_ = (long long)__builtin_amdgcn_s_memtime();      \
+        fp[k] += t_ - fp_last;                                              \
+        fp_last = t_;                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+    } while (0)
+#else
+#define PROBE(k) do { } while (0)
+#endif
 
 struct TrkConst {
     double fs;
@@ -55,7 +78,9 @@ struct TrkConst {
     long long file_off;
     int ms;
     int n_ch;
-    int split;            // workgroups cooperating on one channel (1..TRK_PASSES)
+    int split;            // workgroups cooperating on one channel
+    int n_units;          // units that can hold the longest block
+    int fast_xcd;         // allow the same-XCD exchange path (SGX_TRK_FASTX=0 disables it)
     int pad;
 };
 
@@ -73,10 +98,11 @@ struct TrkBlock {
     int stop;
     double startE, stepE, startP, stepP, startL, stepL;
     double inv_step;          // ~ 1/step, only used to estimate switch samples
-    double r_hi, r_lo;        // carrier turns per sample (double-double)
-    double rem_turns;         // carrier phase of sample 0, turns
-    double cD, sD;            // rotation over split * TRK_PASS samples (a member's pass stride)
-    double2 B[16];            // (cos, sin)(2 pi b r)
+    // carrier phasors (cos, sin)(2 pi r m), r = turns per sample:
+    double2 B[16];            // m = b                      sample b inside a group
+    double2 W1[16];           // m = 16 a                   group a = tid & 15
+    double2 W2[16];           // m = 256 b                  group row b = tid >> 4
+    double2 W3[16];           // m = 4096 u - head, plus the block's start phase: unit u
 };
 
 // Loop state (LDS): code part owned by wave 1, carrier part by wave 0.
@@ -133,28 +159,62 @@ __device__ __forceinline__ void prep_code(const TrkConst& K, double codeFreq, do
     }
 }
 
-// ---- filter phase, carrier side (wave 0): parameters of a block with rate w and start phase remCarr -----
-__device__ __forceinline__ void prep_carr(const TrkConst& K, double w, double remCarr, TrkBlock& b, int lane) {
-    // trigarg = w * (i/fs) + remCarr (T5); in turns: r*i + remCarr/(2 pi), r = w/(2 pi fs)
+// sin and cos of 2 pi u for u in [0, 2): quarter-turn reduction (exact), Taylor polynomials on |theta| <= pi/4.
+// ~1 ulp; a short dependent chain matters here because this sits on the per-block critical path.
+__device__ __forceinline__ void sincos_turns(double u, double& sn, double& cs) {
+    const double q = rint(u * 4.0);
+    const double f = __builtin_fma(q, -0.25, u);          // exact, |f| <= 1/8
+    const int qi = (int)q & 3;
+    const double th = f * 6.283185307179586476925287;
+    const double t2 = th * th;
+    double ps = -2.8114572543455206e-15;                   // -1/17!
+    ps = __builtin_fma(ps, t2, 7.6471637318198164e-13);    //  1/15!
+    ps = __builtin_fma(ps, t2, -1.6059043836821613e-10);   // -1/13!
+    ps = __builtin_fma(ps, t2, 2.5052108385441720e-08);    //  1/11!
+    ps = __builtin_fma(ps, t2, -2.7557319223985893e-06);   // -1/9!
+    ps = __builtin_fma(ps, t2, 1.9841269841269841e-04);    //  1/7!
+    ps = __builtin_fma(ps, t2, -8.3333333333333332e-03);   // -1/5!
+    ps = __builtin_fma(ps, t2, 1.6666666666666666e-01);    //  1/3!  (sign folded below)
+    double pc = 4.7794773323873853e-14;                    //  1/16!
+    pc = __builtin_fma(pc, t2, -1.1470745597729725e-11);   // -1/14!
+    pc = __builtin_fma(pc, t2, 2.0876756987868100e-09);    //  1/12!
+    pc = __builtin_fma(pc, t2, -2.7557319223985888e-07);   // -1/10!
+    pc = __builtin_fma(pc, t2, 2.4801587301587302e-05);    //  1/8!
+    pc = __builtin_fma(pc, t2, -1.3888888888888889e-03);   // -1/6!
+    pc = __builtin_fma(pc, t2, 4.1666666666666664e-02);    //  1/4!
+    pc = __builtin_fma(pc, t2, -0.5);                      // -1/2!
+    const double s0 = __builtin_fma(-(ps * t2), th, th);   // th - th^3 * (1/3! - ...)
+    const double c0 = __builtin_fma(pc, t2, 1.0);
+    sn = (qi == 0) ? s0 : (qi == 1) ? c0 : (qi == 2) ? -s0 : -c0;
+    cs = (qi == 0) ? c0 : (qi == 1) ? -s0 : (qi == 2) ? -c0 : s0;
+}
+
+// ---- filter phase, carrier side (wave 0): phasor tables of a block with rate w, start phase remCarr and
+// `head` bytes between the 16-byte boundary and the block's first sample -----------------------------------
+__device__ __forceinline__ void prep_carr(const TrkConst& K, double w, double remCarr, int head, TrkBlock& b,
+                                          int lane) {
+    // trigarg = w * (i/fs) + remCarr (T5); in turns: r*i + remCarr/(2 pi), r = w/(2 pi fs) as a double-double
     const double r_hi = w * K.inv_2pifs_hi;
     const double r_lo = __builtin_fma(w, K.inv_2pifs_hi, -r_hi) + w * K.inv_2pifs_lo;
-    // lane b < 16: B_b; lane 16: rotation over a member's pass stride
-    const double mult = (lane == 16) ? (double)TRK_PASS * (double)K.split : (double)lane;
+    const int sel = lane >> 4, idx = lane & 15;
+    const double mult = (sel == 0) ? (double)idx
+                      : (sel == 1) ? (double)(16 * idx)
+                      : (sel == 2) ? (double)(256 * idx)
+                                   : (double)(TRK_UNIT * idx - head);
     const double p = r_hi * mult;
     const double e = __builtin_fma(r_hi, mult, -p) + r_lo * mult;
-    const double u = (p - floor(p)) + e;
+    double u = (p - floor(p)) + e;
+    if (sel == 3) {
+        u += remCarr * K.inv_2pi;        // < 1
+        u -= (u >= 1.0) ? 1.0 : 0.0;
+    }
     double sn, cs;
-    sincospi(2.0 * u, &sn, &cs);
-    if (lane < 16) b.B[lane] = make_double2(cs, sn);
-    if (lane == 16) {
-        b.cD = cs;
-        b.sD = sn;
-    }
-    if (lane == 0) {
-        b.r_hi = r_hi;
-        b.r_lo = r_lo;
-        b.rem_turns = remCarr * K.inv_2pi;
-    }
+    sincos_turns(u, sn, cs);
+    const double2 v = make_double2(cs, sn);
+    if (sel == 0) b.B[idx] = v;
+    else if (sel == 1) b.W1[idx] = v;
+    else if (sel == 2) b.W2[idx] = v;
+    else b.W3[idx] = v;
 }
 
 template <int CTRL>
@@ -165,8 +225,9 @@ __device__ __forceinline__ double dpp_add(double v) {
     return v + __hiloint2double(ohi, olo);
 }
 
-// sum over the 64 lanes of a wave; every lane gets the result (fixed order, deterministic)
-__device__ __forceinline__ double wave_sum(double v) {
+// sums over lanes 0..31 and over lanes 32..63 of a wave (fixed order, deterministic);
+// lanes 0..31 return the first sum, lanes 32..63 the second
+__device__ __forceinline__ double half_wave_sum(double v, int lane) {
     v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
     v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
     v = dpp_add<0x141>(v);   // row_half_mirror
@@ -176,7 +237,32 @@ __device__ __forceinline__ double wave_sum(double v) {
     const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
     const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
     const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
-    return (r0 + r1) + (r2 + r3);
+    return lane < 32 ? (r0 + r1) : (r2 + r3);
+}
+
+// sum over each row of 16 lanes; every lane of a row gets its row's sum (fixed order)
+__device__ __forceinline__ double row_sum(double v) {
+    v = dpp_add<0xB1>(v);
+    v = dpp_add<0x4E>(v);
+    v = dpp_add<0x141>(v);
+    v = dpp_add<0x140>(v);
+    return v;
+}
+
+__device__ __forceinline__ unsigned xcc_id() {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return x & 0xF;
+}
+
+// granule store: `fast` = every member of the channel runs on the same XCD (verified at kernel start), so a
+// plain store that stays in the shared L2 is visible to the others' L1-bypassing loads; otherwise a
+// write-through (agent-scope) store.  Either way ONE aligned 8-byte store per granule.
+__device__ __forceinline__ void granule_store(unsigned long long* p, unsigned long long v, bool fast) {
+    if (fast)
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ uint4 load_group(const int8_t* __restrict__ rec, long long addr, long long limit) {
@@ -196,10 +282,14 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_kernel(const int8_t* __restri
     __shared__ double s_red[6][TRK_THREADS];
     __shared__ double s_tot[6];
     __shared__ TrkState s_st;
-    __shared__ unsigned s_gather[TRK_PASSES * 12];
+    __shared__ double s_rc;                // carrier phase at the end of the current block (wave 3 -> wave 0)
 
     // optional phase profile (SGX_TRK_PROFILE=1): shader cycles of lane 0 in map / wait / reduce / filter
     long long pf_map = 0, pf_wait = 0, pf_red = 0, pf_flt = 0;
+#ifdef TRK_FINEPROF
+    long long fp[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long fp_last = 0;
+#endif
 
     // block -> (channel, member): members of a channel share blockIdx % 8, i.e. (observed) one XCD / one L2;
     // placement only affects speed, the exchange below is agent-scope and placement independent
@@ -215,7 +305,36 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_kernel(const int8_t* __restri
         if (tid == 0 && member == 0) ms_done[ch] = 0;
         return;
     }
-    unsigned long long* __restrict__ xbase = xch + (long long)ch * 2 * TRK_PASSES * 12;
+    // exchange area of the channel: [2 epoch parities][TRK_MAX_SPLIT members][12 granules], then one
+    // placement granule per member
+    unsigned long long* __restrict__ xbase = xch + (long long)ch * (2 * TRK_MAX_SPLIT * 12 + 16);
+    bool fast = false;
+    if (P > 1) {
+        // placement check through the placement-independent path: all members on one XCD?
+        unsigned long long* pl = xbase + 2 * TRK_MAX_SPLIT * 12;
+        const unsigned me = xcc_id();
+        if (tid == 0) __hip_atomic_store(pl + member, 0xC0DE000000000000ull | me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool same = true;
+        if (wave == 0) {
+            unsigned long long x = 0;
+            int budget = 1 << 22;
+            for (;;) {
+                if (lane < P) x = __hip_atomic_load(pl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool ok = lane >= P || (x >> 48) == 0xC0DE;
+                if (__all(ok)) break;
+                if (--budget == 0) {
+                    if (lane == 0) atomicExch(err, 1 + ch);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            same = __all(lane >= P || (unsigned)(x & 0xF) == me);
+            if (lane == 0) s_tot[0] = same ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        fast = (s_tot[0] != 0.0) && (K.fast_xcd != 0);
+        __syncthreads();
+    }
     for (int i = tid; i < 1028; i += TRK_THREADS) {
         int j = i - 1;
         if (j < 0) j = 1022;
@@ -235,22 +354,21 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_kernel(const int8_t* __restri
         s_st.oldCarrNco = s_st.oldCarrErr = 0.0;
     }
     __syncthreads();
-    if (wave == 0) prep_carr(K, s_st.w, s_st.remCarr, s_blk, lane);
+    if (wave == 0) prep_carr(K, s_st.w, s_st.remCarr, (int)(cc.pos0 & 15), s_blk, lane);
     if (wave == 1) prep_code(K, s_st.codeFreq, s_st.remCode, s_st.pos, s_st, s_blk, lane == 0);
     __syncthreads();
 
     const long long limit = K.rec_alloc - 16;
-    uint4 nx[TRK_PASSES];
-    {
-        const long long ab = s_blk.pos & ~15ll;
-#pragma unroll
-        for (int p = 0; p < TRK_PASSES; ++p)
-            if (p % P == member) nx[p] = load_group(rec, ab + (long long)(tid + p * TRK_THREADS) * 16, limit);
-    }
+    const long long lane_off = (long long)(tid + member * TRK_THREADS) * 16;   // byte offset of the lane's first unit
+    uint4 cur = load_group(rec, (s_blk.pos & ~15ll) + lane_off, limit);
     double* __restrict__ o = out + (long long)ch * SGX_NUM_SERIES * K.ms;
+    const double two_pi = 2 * M_PI;
     int done = 0;
     for (int it = 0; it < K.ms; ++it) {
         const long long tk0 = prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
+#ifdef TRK_FINEPROF
+        fp_last = (long long)__builtin_amdgcn_s_memtime();
+#endif
         const long long pos = s_blk.pos;
         const int blk = s_blk.blk;
         if (s_blk.stop) break;   // short read: tracking.py:159-163
@@ -258,20 +376,34 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_kernel(const int8_t* __restri
         const double startP = s_blk.startP, stepP = s_blk.stepP;
         const double startL = s_blk.startL, stepL = s_blk.stepL;
         const double inv_step = s_blk.inv_step;
-        const double cD = s_blk.cD, sD = s_blk.sD;
+        double2 B[16];
+#pragma unroll
+        for (int b = 0; b < 16; ++b) B[b] = s_blk.B[b];
 
         const long long abase = pos & ~15ll;
+        const long long abase_next = (pos + blk) & ~15ll;
         const int head = (int)(pos - abase);              // bytes of the first group before the block
         const int n_groups = (head + blk + 15) >> 4;
         double aIE = 0.0, aQE = 0.0, aIP = 0.0, aQP = 0.0, aIL = 0.0, aQL = 0.0;
-        double gc = 1.0, gs = 0.0;   // carrier phasor at the lane's current group start
+        // carrier phasor of the lane's group inside a unit: W1[tid & 15] * W2[tid >> 4]
+        double lc, ls;
+        {
+            const double2 a = s_blk.W1[tid & 15], c2 = s_blk.W2[tid >> 4];
+            lc = __builtin_fma(a.x, c2.x, -(a.y * c2.y));
+            ls = __builtin_fma(a.x, c2.y, a.y * c2.x);
+        }
 
-#pragma unroll
-        for (int p = 0; p < TRK_PASSES; ++p) {
-            const int g = tid + p * TRK_THREADS;
-            if (p % P == member && g < n_groups) {
+#pragma unroll 1
+        for (int u = member; u < K.n_units; u += P) {
+            // issue the load of the lane's next unit (this block's, or the first one of the next block)
+            const int un = u + P;
+            const uint4 nxt = (un < K.n_units) ? load_group(rec, abase + (long long)(tid + un * TRK_THREADS) * 16, limit)
+                                               : load_group(rec, abase_next + lane_off, limit);
+            const int g = tid + u * TRK_THREADS;
+            PROBE(0);   // block parameters, B table, lane phasor, next-unit load issued, current unit landed
+            if (g < n_groups) {
                 const int i0 = g * 16 - head;             // sample index of byte 0 of this group
-                unsigned wd[4] = {nx[p].x, nx[p].y, nx[p].z, nx[p].w};
+                unsigned wd[4] = {cur.x, cur.y, cur.z, cur.w};
                 if (i0 < 0 || i0 + 16 > blk) {
                     // zero the bytes outside [0, blk): they then add nothing to the sums
 #pragma unroll
@@ -285,27 +417,20 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_kernel(const int8_t* __restri
                         wd[d] &= m;
                     }
                 }
-                if (p < P) {   // the member's first pass of this block
-                    const double r_hi = s_blk.r_hi, r_lo = s_blk.r_lo;
-                    const double di0 = (double)i0;
-                    const double pr = r_hi * di0;
-                    const double er = __builtin_fma(r_hi, di0, -pr);
-                    const double u = (pr - floor(pr)) + ((er + r_lo * di0) + s_blk.rem_turns);
-                    sincospi(2.0 * u, &gs, &gc);
-                } else {
-                    const double nc = __builtin_fma(gc, cD, -(gs * sD));
-                    const double ns = __builtin_fma(gs, cD, gc * sD);
-                    gc = nc;
-                    gs = ns;
-                }
+                // group-start phasor G = (lane part) * W3[u]
+                const double2 w3 = s_blk.W3[u];
+                const double gc = __builtin_fma(lc, w3.x, -(ls * w3.y));
+                const double gs = __builtin_fma(lc, w3.y, ls * w3.x);
                 const int ilo = i0 < 0 ? 0 : i0;
                 int kE, swE, kP, swP, kL, swL;
                 ramp_setup(startE, stepE, inv_step, ilo, kE, swE);
                 ramp_setup(startP, stepP, inv_step, ilo, kP, swP);
                 ramp_setup(startL, stepL, inv_step, ilo, kL, swL);
+                PROBE(1);   // masks, group phasor, three ramp setups
                 const double cE1 = __hiloint2double((int)s_code_hi[kE], 0), cE2 = __hiloint2double((int)s_code_hi[kE + 1], 0);
                 const double cP1 = __hiloint2double((int)s_code_hi[kP], 0), cP2 = __hiloint2double((int)s_code_hi[kP + 1], 0);
                 const double cL1 = __hiloint2double((int)s_code_hi[kL], 0), cL2 = __hiloint2double((int)s_code_hi[kL + 1], 0);
+                PROBE(2);   // code lookups
                 const int iend = i0 + 16;
                 int swmin = swE < swP ? swE : swP;
                 swmin = swL < swmin ? swL : swmin;
@@ -322,9 +447,9 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_kernel(const int8_t* __restri
                         w1 = (w1 >> 8) | (w2 << 24);
                         w2 = (w2 >> 8) | (w3 << 24);
                         w3 >>= 8;
-                        const double2 B = s_blk.B[b];
-                        const double c = __builtin_fma(gc, B.x, -(gs * B.y));
-                        const double s = __builtin_fma(gs, B.x, gc * B.y);
+                        const double2 Bb = s_blk.B[b];
+                        const double c = __builtin_fma(gc, Bb.x, -(gs * Bb.y));
+                        const double s = __builtin_fma(gs, Bb.x, gc * Bb.y);
                         const double xs = s * xd, xc = c * xd;
                         const double cE = i >= swE ? cE2 : cE1;
                         const double cP = i >= swP ? cP2 : cP1;
@@ -344,13 +469,13 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_kernel(const int8_t* __restri
                         const unsigned wv = wd[b >> 2];
                         const int xi = ((b & 3) == 3) ? ((int)wv >> 24) : (int)(signed char)((wv >> (8 * (b & 3))) & 0xFF);
                         const double xd = (double)xi;
-                        const double2 B = s_blk.B[b];
-                        Ac = __builtin_fma(xd, B.x, Ac);
-                        As = __builtin_fma(xd, B.y, As);
+                        Ac = __builtin_fma(xd, B[b].x, Ac);
+                        As = __builtin_fma(xd, B[b].y, As);
                         const double xt = (b >= bsw) ? xd : 0.0;
-                        Tc = __builtin_fma(xt, B.x, Tc);
-                        Ts = __builtin_fma(xt, B.y, Ts);
+                        Tc = __builtin_fma(xt, B[b].x, Tc);
+                        Ts = __builtin_fma(xt, B[b].y, Ts);
                     }
+                    PROBE(3);   // 16-sample accumulation
                     // rotate by the group phasor: cos part -> Q, sin part -> I (tracking.py:205-207)
                     const double allQ = __builtin_fma(gc, Ac, -(gs * As));
                     const double allI = __builtin_fma(gs, Ac, gc * As);
@@ -367,13 +492,8 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_kernel(const int8_t* __restri
                     aQL = __builtin_fma(dL, tlQ, __builtin_fma(cL1, allQ, aQL));
                 }
             }
-        }
-        // prefetch the next block's groups: they land during the reduce and filter phases
-        {
-            const long long ab = (pos + blk) & ~15ll;
-#pragma unroll
-            for (int p = 0; p < TRK_PASSES; ++p)
-                if (p % P == member) nx[p] = load_group(rec, ab + (long long)(tid + p * TRK_THREADS) * 16, limit);
+            cur = nxt;
+            PROBE(4);   // group finalisation
         }
         const long long tk1 = prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
         s_red[0][tid] = aIE;
@@ -382,33 +502,59 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_kernel(const int8_t* __restri
         s_red[3][tid] = aQP;
         s_red[4][tid] = aIL;
         s_red[5][tid] = aQL;
+        // carrier phase at the end of this block (T5) does not need the sums: the otherwise idle wave 3
+        // computes it.  remCarrPhase = trigarg[blk] % (2 pi), trigarg = w*(blk/fs) + rem; exact remainder by FMA
+        if (wave == 3) {
+            const double arg_end = s_st.w * ((double)blk / K.fs) + s_st.remCarr;
+            const double kq = floor(arg_end * K.inv_2pi);
+            double rc = __builtin_fma(-kq, two_pi, arg_end);
+            if (rc < 0.0) rc += two_pi;
+            if (rc >= two_pi) rc -= two_pi;
+            if (lane == 0) s_rc = rc;
+        }
+        PROBE(5);   // partials to LDS, end-of-block carrier phase
         __syncthreads();
+        PROBE(6);   // barrier 1 (waits for the slowest wave)
         const long long tk2 = prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
-        if (wave < 6) {
-            double acc = s_red[wave][lane];
+        if (wave < 3) {
+            // wave w folds values 2w (lanes 0..31) and 2w+1 (lanes 32..63): 8 partials per lane, then DPP
+            const int v = 2 * wave + (lane >> 5), l = lane & 31;
+            double acc = s_red[v][l];
 #pragma unroll
-            for (int k = 1; k < TRK_THREADS / 64; ++k) acc += s_red[wave][lane + 64 * k];
-            acc = wave_sum(acc);
+            for (int k = 1; k < TRK_THREADS / 32; ++k) acc += s_red[v][l + 32 * k];
+            acc = half_wave_sum(acc, lane);
+            PROBE(7);   // local fold
             if (P == 1) {
-                if (lane == 0) s_tot[wave] = acc;
-            } else if (lane == 0) {
+                if (l == 0) s_tot[v] = acc;
+            } else if (l == 0) {
                 // publish this member's partial as two {epoch, 32-bit payload} granules: ONE aligned 8-byte
-                // write-through (sc1) store each, so a reader never sees a torn granule (Guideline 16, R2)
+                // store each, so a reader never sees a torn granule (Guideline 16, R2)
                 const unsigned long long tag = (unsigned long long)(unsigned)(it + 1) << 32;
-                unsigned long long* gp = xbase + ((it & 1) * TRK_PASSES + member) * 12 + 2 * wave;
-                __hip_atomic_store(gp, tag | (unsigned)__double2loint(acc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(gp + 1, tag | (unsigned)__double2hiint(acc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned long long* gp = xbase + ((it & 1) * TRK_MAX_SPLIT + member) * 12 + 2 * v;
+                granule_store(gp, tag | (unsigned)__double2loint(acc), fast);
+                granule_store(gp + 1, tag | (unsigned)__double2hiint(acc), fast);
             }
             if (P > 1 && wave == 0) {
-                // gather every member's granules of this epoch (relaxed agent-scope polls, bounded)
+                // gather every member's granules of this epoch (relaxed, L1-bypassing polls, bounded).
+                // lane = 16*row + c reads member c's value `row` (and value row+4 in rows 0, 1)
                 const unsigned epoch = (unsigned)(it + 1);
-                const unsigned long long* gp = xbase + (it & 1) * TRK_PASSES * 12;
-                const bool mine = lane < 12 * P;
-                unsigned long long x = 0;
+                const int row = lane >> 4, c = lane & 15;
+                const bool mA = c < P, mB = mA && row < 2;
+                const unsigned long long* gA = xbase + ((it & 1) * TRK_MAX_SPLIT + c) * 12 + 2 * row;
+                const unsigned long long* gB = gA + 8;
+                unsigned long long a0 = 0, a1 = 0, b0 = 0, b1 = 0;
                 int budget = 1 << 22;
                 for (;;) {
-                    if (mine) x = __hip_atomic_load(gp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const bool ok = !mine || (unsigned)(x >> 32) == epoch;
+                    if (mA) {
+                        a0 = __hip_atomic_load(gA, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        a1 = __hip_atomic_load(gA + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if (mB) {
+                        b0 = __hip_atomic_load(gB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        b1 = __hip_atomic_load(gB + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    const bool ok = (!mA || ((unsigned)(a0 >> 32) == epoch && (unsigned)(a1 >> 32) == epoch)) &&
+                                    (!mB || ((unsigned)(b0 >> 32) == epoch && (unsigned)(b1 >> 32) == epoch));
                     if (__all(ok)) break;
                     if (--budget == 0) {
                         if (lane == 0) atomicExch(err, 1 + ch);
@@ -416,38 +562,33 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_kernel(const int8_t* __restri
                     }
                     __builtin_amdgcn_s_sleep(1);
                 }
-                if (mine) s_gather[lane] = (unsigned)x;
-                // same wave: LDS accesses are in order
-                if (lane < 6) {
-                    double t = 0.0;
-                    for (int c = 0; c < P; ++c)
-                        t += __hiloint2double((int)s_gather[c * 12 + 2 * lane + 1], (int)s_gather[c * 12 + 2 * lane]);
-                    s_tot[lane] = t;
+                PROBE(8);   // publish + gather (includes waiting for the slowest member)
+                // row sums over the members, same lane layout and order in every member => identical totals
+                const double dA = mA ? __hiloint2double((int)(unsigned)a1, (int)(unsigned)a0) : 0.0;
+                const double dB = mB ? __hiloint2double((int)(unsigned)b1, (int)(unsigned)b0) : 0.0;
+                const double sA = row_sum(dA), sB = row_sum(dB);
+                if (c == 0) {
+                    s_tot[row] = sA;
+                    if (row < 2) s_tot[row + 4] = sB;
                 }
             }
         }
+        PROBE(9);   // totals
         __syncthreads();
+        PROBE(10);  // barrier 2
         const long long tk3 = prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
         const long long m = K.ms;
         const bool more = (it + 1 < K.ms);
         if (wave == 0) {
-            // T7 PLL (tracking.py:223-235) and carrier bookkeeping (T5) for the next block
+            // T7 PLL (tracking.py:223-235); carrier parameters of the next block
             const double I_P = s_tot[2], Q_P = s_tot[3];
-            const double w_old = s_st.w, rem_old = s_st.remCarr;
             const double oldNco = s_st.oldCarrNco, oldErr = s_st.oldCarrErr, basis = s_st.carrBasis;
-            // remCarrPhase = trigarg[blk] % (2 pi) with trigarg = w*(blk/fs) + rem  (exact remainder by FMA)
-            const double two_pi = 2 * M_PI;
-            const double arg_end = w_old * ((double)blk / K.fs) + rem_old;
-            double kq = floor(arg_end / two_pi);
-            double rc = __builtin_fma(-kq, two_pi, arg_end);
-            if (rc < 0.0) rc += two_pi;
-            if (rc >= two_pi) rc -= two_pi;
             const double carrError = atan(Q_P / I_P) / 2.0 / M_PI;
             const double carrNco = oldNco + K.k_carr_a * (carrError - oldErr) + carrError * K.k_carr_b;
             const double carrFreq = basis + carrNco;
             const double w_new = (carrFreq * 2.0) * M_PI;
-            if (more) prep_carr(K, w_new, rc, s_blk, lane);
-            const bool rec_out = (member == 0);
+            const double rc = s_rc;
+            if (more) prep_carr(K, w_new, rc, (int)((pos + blk) & 15), s_blk, lane);
             if (lane == 0) {
                 s_st.w = w_new;
                 s_st.remCarr = rc;
@@ -455,7 +596,7 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_kernel(const int8_t* __restri
                 s_st.oldCarrErr = carrError;
                 s_st.carrFreq = carrFreq;
             }
-            if (lane == 0 && rec_out) {
+            if (lane == 0 && member == 0) {
                 o[2 * m + it] = carrFreq;          // T9 record (tracking.py:255-275)
                 o[3 * m + it] = I_P;
                 o[4 * m + it] = s_tot[0];
@@ -491,7 +632,9 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_kernel(const int8_t* __restri
             if (more) prep_code(K, codeFreq, rem_next, pos_after, s_st, s_blk, lane == 0);
         }
         done = it + 1;
+        PROBE(11);  // loop filter (this wave's side) + next block's parameters
         __syncthreads();   // next block's parameters visible
+        PROBE(12);  // barrier 3 (waits for the other filter wave)
         if (prof && tid == 0) {
             const long long tk4 = (long long)__builtin_amdgcn_s_memtime();
             pf_map += tk1 - tk0;
@@ -506,6 +649,11 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_kernel(const int8_t* __restri
         prof[ch * 4 + 2] = pf_red;
         prof[ch * 4 + 3] = pf_flt;
     }
+#ifdef TRK_FINEPROF
+    if (tid == 0 && prof && member == 0 && ch == 0) {
+        for (int k = 0; k < 13; ++k) printf("[fineprof] probe %2d: %8.1f cycles/block\n", k, (double)fp[k] / K.ms);
+    }
+#endif
     if (tid == 0 && member == 0) ms_done[ch] = done;
 }
 
@@ -525,11 +673,6 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
     SGX_HIP(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const sgx_settings& S = c->s;
-    if (c->n_code + 1 + 15 > (long long)TRK_PASSES * TRK_PASS) {
-        sgx_set_error("samplesPerCode %lld exceeds the tracking kernel's %d samples per block", (long long)c->n_code,
-                      TRK_PASSES * TRK_PASS - 16);
-        return SGX_E_ARG;
-    }
 
     TrkConst K;
     K.fs = S.samplingFreq;
@@ -555,18 +698,28 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
     K.file_off = rec_file_offset;
     K.ms = ms;
     K.n_ch = n_ch;
-    K.pad = 0;
     {
-        // cooperating workgroups per channel: one 512-thread workgroup fills a CU, all of a launch must be
+        // cooperating workgroups per channel: one 256-thread workgroup per CU, all of a launch must be
         // resident at once (they wait for each other), so split * n_ch <= CU count
         int cus = 0;
         SGX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+        // units needed by the longest possible block (samplesPerCode + 2 samples, worst alignment)
+        K.n_units = (int)((c->n_code + 2 + 15 + 15) / 16 + TRK_THREADS - 1) / TRK_THREADS;
         int split = cus / (n_ch > 0 ? ((n_ch + 7) / 8) * 8 : 8);
-        if (split > TRK_PASSES) split = TRK_PASSES;
+        if (split > TRK_MAX_SPLIT) split = TRK_MAX_SPLIT;
+        if (K.n_units > 16) {
+            sgx_set_error("samplesPerCode %lld needs %d units, the tracking kernel holds 16", (long long)c->n_code,
+                          K.n_units);
+            return SGX_E_ARG;
+        }
+        if (split > K.n_units) split = K.n_units;
         if (split < 1) split = 1;
         const char* se = getenv("SGX_TRK_SPLIT");
         if (se && atoi(se) >= 1 && atoi(se) <= split) split = atoi(se);
         K.split = split;
+        const char* fe = getenv("SGX_TRK_FASTX");
+        K.fast_xcd = (fe && fe[0] == '0') ? 0 : 1;
+        K.pad = 0;
     }
 
     std::vector<TrkChan> hc((size_t)n_ch);
@@ -608,7 +761,7 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
     if (want_prof) SGX_HIP(hipMalloc((void**)&d_prof, sizeof(long long) * 4 * (size_t)n_ch));
     unsigned long long* d_xch = nullptr;
     int* d_err = nullptr;
-    const size_t xch_bytes = sizeof(unsigned long long) * (size_t)n_ch * 2 * TRK_PASSES * 12;
+    const size_t xch_bytes = sizeof(unsigned long long) * (size_t)n_ch * (2 * TRK_MAX_SPLIT * 12 + 16);
     SGX_HIP(hipMalloc((void**)&d_xch, xch_bytes));
     SGX_HIP(hipMalloc((void**)&d_err, sizeof(int)));
     SGX_HIP(hipMemsetAsync(d_xch, 0, xch_bytes, st));   // every polled word is zeroed before every launch
