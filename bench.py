@@ -64,6 +64,24 @@ def cpu_baseline(pkg, scene, n_code, args, total_samples, n_ch, ms):
             "seconds_extrapolated": full}
 
 
+def pmc_traffic(channels, ms):
+    """HBM bytes per trk_kernel launch from the committed rocprofv3 PMC passes (profiles/), if they
+    were taken on this workload; None otherwise.  Counters cannot be read from inside the process."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if name.endswith("_pmc_trk_kernel.json"):
+            try:
+                with open(os.path.join(pdir, name)) as f:
+                    d = json.load(f)
+            except (OSError, ValueError):
+                continue
+            w = d.get("workload", {})
+            if w.get("channels") == channels and w.get("ms") == ms:
+                best = (d["hbm_bytes_per_launch"], "profiles/" + name)
+    return best
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -169,6 +187,7 @@ def main():
     value = world * samples_per_step * args.steps / elapsed / 1e6
 
     if rank == 0:
+        traffic = pmc_traffic(args.channels, args.ms)
         out = {
             "metric": "IF Msamples/s through acquisition + tracking (x real-time = value / 38.192)",
             "value": value, "unit": "Msamples/s", "x_realtime": value / REALTIME_MSPS,
@@ -184,10 +203,13 @@ def main():
             "acquire_ms": float(np.mean(acq_ms)), "track_kernel_ms": k_ms,
             "us_per_code_period": k_ms * 1e3 / args.ms,
             "roofline": {"kernel": "trk_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic[0] if traffic else None,
+                         "traffic_source": (traffic[1] + " (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes of this "
+                                            "command; FETCH_SIZE x2, gfx950 correction)") if traffic else None,
                          "algorithmic_bytes_per_launch": b_trk,
-                         "note": "8 channels = 8 of 256 CUs busy and 37 000 dependent steps per channel: "
-                                 "latency-bound, see DESIGN.md"},
+                         "note": "37 000 dependent steps per channel; 8 channels x 10 cooperating CUs = 80 of 256 "
+                                 "CUs busy: latency-bound, not bandwidth-bound (DESIGN.md section 5)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, scene, n_code, args, samples_per_step, args.channels, args.ms)

@@ -1,0 +1,163 @@
+"""CPU-only checks of the boundary and the host logic: the C-ABI library loads and exports every
+symbol include/sgx.h declares, the exact host helpers agree with the goldens captured from the
+reference, device entry points fail loudly without a GPU, and the Python drop-in keeps the
+reference's surface.  No compute kernels run here."""
+import ctypes
+import importlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden, pkg
+
+
+@pytest.fixture(scope="module")
+def built():
+    ge = importlib.import_module("__graft_entry__")
+    ge.build()
+    return pkg()
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "sgx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sgx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    syms = header_symbols()
+    assert len(syms) >= 20
+    lib = ctypes.CDLL(built._native.LIB_PATH)
+    for s in syms:
+        assert hasattr(lib, s), "libsgx.so lacks %s declared in include/sgx.h" % s
+    assert tuple(syms) == built._native.SYMBOLS, "ctypes prototypes and header disagree"
+    assert b"gfx950" in built._native.lib().sgx_version()
+
+
+def test_struct_layouts_match_header(built):
+    n = built._native
+    assert ctypes.sizeof(n.Settings) == 10 * 8 + 8 + 4 + 4
+    assert ctypes.sizeof(n.ChanInit) == 24
+    assert ctypes.sizeof(n.Sat) == 40
+    assert ctypes.sizeof(n.Scene) == 16 + 16 * 40 + 512
+    assert ctypes.sizeof(n.Timing) == 32
+
+
+def test_host_helpers_match_reference_goldens(built):
+    g = load_golden("codes.npz")
+    s = built.Settings()
+    assert s.samplesPerCode == int(g["samples_per_code"])
+    codes = np.stack([s.generateCAcode(p) for p in range(32)])
+    assert np.array_equal(codes.astype(np.int8), g["ca_codes"])
+    t = s.makeCaTable()
+    assert t.shape == (32, 38192)
+    assert np.array_equal(np.packbits(t > 0, axis=1), g["ca_table_bits"])
+    assert s.calcLoopCoef(2.0, 0.7, 1.0) == tuple(g["loop_dll"])
+    assert s.calcLoopCoef(25.0, 0.7, 0.25) == tuple(g["loop_pll"])
+    with pytest.raises(AssertionError):
+        s.generateCAcode(32)                      # reference asserts prn in range(0, 32)
+    out = np.empty(1023)
+    rc = built._native.lib().sgx_generate_ca_code(40, out.ctypes.data_as(ctypes.c_void_p))
+    assert rc == built._native.SGX_E_ARG and "outside 0..31" in built._native.last_error()
+
+
+def test_other_sampling_rate_table(built):
+    """A second front-end (16.3676 Msps) exercises the exact index rule on another N."""
+    from oracle import softgnss_oracle as orc
+    s = built.Settings()
+    s.samplingFreq = 16367600.0
+    s.IF = 4130400.0
+    o = orc.OracleSettings(samplingFreq=16367600.0, IF=4130400.0)
+    assert s.samplesPerCode == o.samplesPerCode == 16368
+    assert np.array_equal(s.makeCaTable(), orc.make_ca_table(o))
+
+
+def test_settings_surface_matches_reference(built):
+    s = built.Settings()
+    want = dict(msToProcess=37000.0, numberOfChannels=8, skipNumberOfBytes=0, dataType='int8', IF=9548000.0,
+                samplingFreq=38192000.0, codeFreqBasis=1023000.0, codeLength=1023, skipAcquisition=False,
+                acqSearchBand=14.0, acqThreshold=2.5, dllDampingRatio=0.7, dllNoiseBandwidth=2.0,
+                dllCorrelatorSpacing=0.5, pllDampingRatio=0.7, pllNoiseBandwidth=25.0, navSolPeriod=500.0,
+                elevationMask=10.0, useTropCorr=True, plotTracking=True)
+    for k, v in want.items():
+        assert getattr(s, k) == v, k
+    assert list(s.acqSatelliteList) == list(range(1, 33))
+    assert s.c == 299792458.0 and s.startOffset == 68.802
+    with pytest.raises(AttributeError):
+        s.c = 1.0
+    r = built.Result(s)
+    with pytest.raises(AssertionError):
+        r.results
+    with pytest.raises(AssertionError):
+        r.results = [1, 2, 3]
+
+
+def test_no_gpu_means_loud_failure(built):
+    if built._native.device_count() > 0:
+        pytest.skip("a GPU is present")
+    s = built.Settings()
+    with pytest.raises(built._native.SgxError):
+        built.engine.get_context(s, 0)
+    a = built.AcquisitionResult(s)
+    with pytest.raises(built._native.SgxError):
+        a.acquire(np.zeros(11 * 38192, dtype=np.int8))
+
+
+def test_product_never_imports_the_oracle():
+    pdir = os.path.join(ROOT, "softgnss-python_amd")
+    for dirpath, _, files in os.walk(pdir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "softgnss_oracle" not in text and "from oracle" not in text, f
+
+
+def test_prerun_matches_reference_golden(built):
+    g = load_golden("acq_default.npz")
+    s = built.Settings()
+    a = built.AcquisitionResult(s)
+    a.results = np.rec.fromarrays([g["carrFreq"], g["codePhase"], g["peakMetric"]],
+                                  names='carrFreq,codePhase,peakMetric')
+    a.preRun()
+    assert np.array_equal(a.channels.PRN, g["ch_PRN"])
+    assert np.array_equal(a.channels.acquiredFreq, g["ch_acquiredFreq"])
+    assert np.array_equal(a.channels.codePhase, g["ch_codePhase"])
+    assert [str(x) for x in a.channels.status] == [str(x) for x in g["ch_status"]]
+    s.numberOfChannels = 3                         # fewer channels than detections: strongest three
+    a.preRun()
+    assert list(a.channels.PRN) == list(g["ch_PRN"][:3])
+    a.showChannelStatus()
+
+
+def test_dropin_module_names(built):
+    import sys
+    d = os.path.join(ROOT, "softgnss-python_amd", "dropin")
+    sys.path.insert(0, d)
+    try:
+        for m in ("initialize", "acquisition", "tracking"):
+            sys.modules.pop(m, None)
+        import acquisition
+        import initialize
+        import tracking
+        assert initialize.Settings is built.Settings
+        assert acquisition.AcquisitionResult is built.AcquisitionResult
+        assert tracking.TrackingResult is built.TrackingResult
+    finally:
+        sys.path.remove(d)
+        for m in ("initialize", "acquisition", "tracking"):
+            sys.modules.pop(m, None)
+
+
+def test_synth_scene_is_integer_and_deterministic(built):
+    sy = built.synth
+    sc = sy.Scene.default()
+    a = sy.generate(sc, 5000, offset=777)
+    b = sy.generate(sc, 9000, offset=0)[777:777 + 5000]
+    assert a.dtype == np.int8 and np.array_equal(a, b)
+    assert np.abs(a).max() <= 127 and 15 < a.std() < 35
+    for sat in sc.sats:
+        assert all(isinstance(v, int) for v in sat.values())
+    st = built._native.scene_struct(sc)
+    assert st.n_sats == 8 and st.sats[0].prn == 1

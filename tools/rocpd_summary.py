@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 (rocpd sqlite) outputs into the small text summaries kept under profiles/.
+
+    python tools/rocpd_summary.py <round-tag> <trace.db> [<fetch.db> <write.db>]
+"""
+import json
+import sqlite3
+import sys
+
+
+def top_kernels(db):
+    c = sqlite3.connect(db)
+    return list(c.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
+
+
+def counter(db, name):
+    c = sqlite3.connect(db)
+    q = ("select kernel_name, sum(value), count(*) from counters_collection where counter_name = ? "
+         "group by kernel_name order by 2 desc")
+    return list(c.execute(q, (name,)))
+
+
+def main():
+    tag, trace = sys.argv[1], sys.argv[2]
+    rows = top_kernels(trace)
+    with open("profiles/%s_kernel_trace_stats.csv" % tag, "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline\n")
+        f.write("kernel,calls,total_us,average_us,percent\n")
+        for n, calls, tot, avg, pct in rows:
+            f.write('"%s",%d,%.3f,%.3f,%.3f\n' % (n, calls, tot, avg, pct))
+    print("kernel trace: %d kernels" % len(rows))
+    if len(sys.argv) >= 5:
+        fetch = counter(sys.argv[3], "FETCH_SIZE")
+        write = counter(sys.argv[4], "WRITE_SIZE")
+        with open("profiles/%s_pmc_hbm.csv" % tag, "w") as f:
+            f.write("# separate passes: rocprofv3 --pmc FETCH_SIZE --kernel-trace / --pmc WRITE_SIZE --kernel-trace, "
+                    "-- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline; raw counter unit = KiB summed over dispatches\n")
+            f.write("counter,kernel,dispatches,raw_sum_KiB\n")
+            for n, v, k in fetch:
+                f.write('FETCH_SIZE,"%s",%d,%.3f\n' % (n, k, v))
+            for n, v, k in write:
+                f.write('WRITE_SIZE,"%s",%d,%.3f\n' % (n, k, v))
+        fk = [r for r in fetch if r[0].startswith("trk_kernel")][0]
+        wk = [r for r in write if r[0].startswith("trk_kernel")][0]
+        fetch_b = fk[1] / fk[2] * 1024.0
+        write_b = wk[1] / wk[2] * 1024.0
+        out = {"kernel": "trk_kernel", "fetch_size_raw_bytes_per_launch": fetch_b,
+               "write_size_raw_bytes_per_launch": write_b,
+               "correction": "gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads "
+                             "(MI355X_MICROARCH.md, HBM section): x2; WRITE_SIZE used as reported",
+               "hbm_bytes_per_launch": 2.0 * fetch_b + write_b,
+               "workload": {"channels": 8, "ms": 37000}}
+        with open("profiles/%s_pmc_trk_kernel.json" % tag, "w") as f:
+            json.dump(out, f, indent=1)
+        print(out)
+
+
+if __name__ == "__main__":
+    main()
