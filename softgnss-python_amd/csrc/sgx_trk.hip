@@ -116,9 +116,11 @@ __device__ __forceinline__ double ramp_at(int i, double step, double start) {
     return (double)i * step + start;   // two roundings, like numpy's y = arange*step; y += start
 }
 
-// chip index at sample ilo and first sample whose chip index is larger (exact reference arithmetic)
+// chip index at sample ilo and first sample whose chip index is larger (exact reference arithmetic).
+// (A one-FMA estimate guarded by near-integer tests was tried: it needs a full-precision 1/step and
+// measured slower than these two exact probes.)
 __device__ __forceinline__ void ramp_setup(double start, double step, double inv_step, int ilo, int& k1,
-                                           int& isw) {
+                                                 int& isw) {
     const double t = ramp_at(ilo, step, start);
     k1 = (int)ceil(t);
     const double kd = (double)k1;
@@ -153,7 +155,9 @@ __device__ __forceinline__ void prep_code(const TrkConst& K, double codeFreq, do
         b.stepL = stepL;
         b.startP = rem;
         b.stepP = stepP;
-        b.inv_step = __builtin_amdgcn_rcp(step);
+        // 1/step: hardware reciprocal estimate + one Newton step; only used to ESTIMATE switch samples
+        const double r0 = __builtin_amdgcn_rcp(step);
+        b.inv_step = __builtin_fma(r0, __builtin_fma(-step, r0, 1.0), r0);
         s.remCode = (t_last + step) - 1023.0;                                // T4
         s.pos = pos + blk;
     }
@@ -283,6 +287,7 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_kernel(const int8_t* __restri
     __shared__ double s_tot[6];
     __shared__ TrkState s_st;
     __shared__ double s_rc;                // carrier phase at the end of the current block (wave 3 -> wave 0)
+    __shared__ double s_out[2][8];         // scalar outputs of a block, staged for wave 2 to store one block later
 
     // optional phase profile (SGX_TRK_PROFILE=1): shader cycles of lane 0 in map / wait / reduce / filter
     long long pf_map = 0, pf_wait = 0, pf_red = 0, pf_flt = 0;
@@ -597,15 +602,9 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_kernel(const int8_t* __restri
                 s_st.carrFreq = carrFreq;
             }
             if (lane == 0 && member == 0) {
-                o[2 * m + it] = carrFreq;          // T9 record (tracking.py:255-275)
-                o[3 * m + it] = I_P;
-                o[4 * m + it] = s_tot[0];
-                o[5 * m + it] = s_tot[4];
-                o[6 * m + it] = s_tot[1];
-                o[7 * m + it] = Q_P;
-                o[8 * m + it] = s_tot[5];
-                o[11 * m + it] = carrError;
-                o[12 * m + it] = carrNco;
+                s_out[it & 1][0] = carrFreq;       // T9 record (tracking.py:255-275), stored by wave 2
+                s_out[it & 1][1] = carrError;
+                s_out[it & 1][2] = carrNco;
             }
         } else if (wave == 1) {
             // T8 DLL (tracking.py:238-251), then block size and ramps of the next block (T1, T3, T4)
@@ -624,12 +623,25 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_kernel(const int8_t* __restri
                 s_st.codeFreq = codeFreq;
             }
             if (lane == 0 && member == 0) {
-                o[0 * m + it] = (double)(pos_after + K.file_off);
-                o[1 * m + it] = codeFreq;
-                o[9 * m + it] = codeError;
-                o[10 * m + it] = codeNco;
+                s_out[it & 1][4] = (double)(pos_after + K.file_off);
+                s_out[it & 1][5] = codeFreq;
+                s_out[it & 1][6] = codeError;
+                s_out[it & 1][7] = codeNco;
             }
             if (more) prep_code(K, codeFreq, rem_next, pos_after, s_st, s_blk, lane == 0);
+        }
+        else if (wave == 2 && member == 0) {
+            // record (T9): the six sums of this block, and the scalar series of the previous block
+            // (staged in LDS by the filter waves, visible since the last barrier) - off the critical path
+            if (lane < 6) {
+                const int series = (lane == 0) ? 4 : (lane == 1) ? 6 : (lane == 2) ? 3 : (lane == 3) ? 7 : (lane == 4) ? 5 : 8;
+                o[series * m + it] = s_tot[lane];      // s_tot order: I_E Q_E I_P Q_P I_L Q_L
+            }
+            if (it > 0 && lane >= 8 && lane < 16 && lane != 11) {
+                const int k = lane - 8;
+                const int series = (k == 0) ? 2 : (k == 1) ? 11 : (k == 2) ? 12 : (k == 4) ? 0 : (k == 5) ? 1 : (k == 6) ? 9 : 10;
+                o[series * m + (it - 1)] = s_out[(it - 1) & 1][k];
+            }
         }
         done = it + 1;
         PROBE(11);  // loop filter (this wave's side) + next block's parameters
@@ -648,6 +660,11 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_kernel(const int8_t* __restri
         prof[ch * 4 + 1] = pf_wait;
         prof[ch * 4 + 2] = pf_red;
         prof[ch * 4 + 3] = pf_flt;
+    }
+    if (wave == 2 && member == 0 && done > 0 && lane >= 8 && lane < 16 && lane != 11) {
+        const int k = lane - 8;
+        const int series = (k == 0) ? 2 : (k == 1) ? 11 : (k == 2) ? 12 : (k == 4) ? 0 : (k == 5) ? 1 : (k == 6) ? 9 : 10;
+        o[series * (long long)K.ms + (done - 1)] = s_out[(done - 1) & 1][k];
     }
 #ifdef TRK_FINEPROF
     if (tid == 0 && prof && member == 0 && ch == 0) {

@@ -227,3 +227,81 @@ def test_track_replicated_channels_identical(default_record):
     for i in range(4, 16):
         assert np.array_equal(series[i], series[i % 4])
     assert _trk_err(series[:4], g["series"][:, :, :60]) < TRK_TOL
+
+
+# ---- full-size, size-independent properties (BASELINE.json config 3 / config 5 shapes) ---------------
+
+@pytest.fixture(scope="module")
+def full_run():
+    """8 channels x 37 000 ms on a 1.41 GB record generated in HBM; default cooperative split."""
+    m = pkg()
+    s = m.Settings()
+    ctx = m.engine.get_context(s, 0)
+    sc = m.synth.Scene.default()
+    rec = ctx.synth(sc, m.synth.record_length(s.samplesPerCode, 37000))
+    a = m.AcquisitionResult(s, device=0)
+    a.acquire(m.DeviceSignal(rec, 0, 11 * s.samplesPerCode))
+    a.preRun()
+    chans = [(int(c.PRN), float(c.acquiredFreq), float(c.codePhase)) for c in a.channels]
+    series, done = ctx.track(rec, chans, 37000)
+    yield m, s, ctx, sc, rec, a, chans, series, done
+    rec.free()
+
+
+def test_full_length_tracking_locks_onto_the_scene(full_run):
+    m, s, ctx, sc, rec, a, chans, series, done = full_run
+    assert np.all(done == 37000)
+    truth = {sat["prn"]: sat for sat in sc.sats}
+    for i, (prn, f0, cp) in enumerate(chans):
+        pos = series[i, 0]
+        d = np.diff(np.r_[cp, pos])
+        assert set(np.unique(d)).issubset({38191.0, 38192.0, 38193.0})       # block sizes
+        sat = truth[prn]
+        f_true = sat["car_fcw"] / 2.0 ** 32 * s.samplingFreq
+        assert abs(np.mean(series[i, 2, 200:]) - f_true) < 1.0                # carrier NCO on the truth (Hz)
+        c_true = sat["code_fcw"] / 2.0 ** 32 * s.samplingFreq
+        assert abs(np.mean(series[i, 1, 2000:]) - c_true) < 0.2               # code NCO on the truth (Hz)
+        ip, qp = series[i, 3, 500:], series[i, 7, 500:]
+        assert np.mean(np.abs(ip)) > 8 * np.mean(np.abs(qp))                  # phase lock: energy in I_P
+        # nav-bit sign changes of I_P happen only on a 20 ms raster
+        flips = np.flatnonzero(np.diff(np.sign(ip)) != 0)
+        assert len(flips) > 100 and len(np.unique(flips % 20)) == 1
+    # total streamed bytes = SURVEY section 8(d) algorithmic figure for config 3
+    streamed = sum(series[i, 0, -1] - chans[i][2] for i in range(8))
+    assert abs(streamed / (8 * 37000 * 38192.0) - 1.0) < 1e-4
+
+
+def test_split_variants_agree_on_the_full_run(full_run):
+    """1 CU per channel vs 10 cooperating CUs, and the placement-independent exchange path: identical
+    block boundaries, sums equal to rounding (different summation order only)."""
+    m, s, ctx, sc, rec, a, chans, series, done = full_run
+    old = {k: os.environ.get(k) for k in ("SGX_TRK_SPLIT", "SGX_TRK_FASTX")}
+    try:
+        for env in ({"SGX_TRK_SPLIT": "1"}, {"SGX_TRK_SPLIT": "10", "SGX_TRK_FASTX": "0"}, {"SGX_TRK_SPLIT": "3"}):
+            os.environ.update(env)
+            ms = 6000
+            s2, d2 = ctx.track(rec, chans, ms)
+            assert np.all(d2 == ms)
+            assert np.array_equal(s2[:, 0], series[:, 0, :ms])
+            assert _trk_err(s2, series[:, :, :ms]) < 1e-9
+            for k in env:
+                os.environ.pop(k)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_many_channels_throughput_mode(full_run):
+    """256 channels (32 replicas of the 8 inits) on one GPU: one CU per channel, replicas bit-identical."""
+    m, s, ctx, sc, rec, a, chans, series, done = full_run
+    many = [chans[i % 8] for i in range(256)]
+    ms = 300
+    s2, d2 = ctx.track(rec, many, ms)
+    assert np.all(d2 == ms)
+    for i in range(8, 256):
+        assert np.array_equal(s2[i], s2[i % 8])
+    assert np.array_equal(s2[:8, 0], series[:, 0, :ms])
+    assert _trk_err(s2[:8], series[:, :, :ms]) < 1e-9
