@@ -118,6 +118,11 @@ int sgx_ctx_destroy(sgx_ctx* c);
 int sgx_ctx_sync(sgx_ctx* c);                     /* hipStreamSynchronize on the context stream */
 int sgx_get_timing(sgx_ctx* c, sgx_timing* out);
 
+/* Optional pinned host memory for the big result buffer of sgx_track (a plain pageable buffer works too,
+ * it only copies slower). */
+int sgx_host_alloc(size_t bytes, void** out);
+int sgx_host_free(void* p);
+
 /* np.fromfile(fid, 'int8', n) replacement: copy n host samples into a new HBM record
  * (initialize.py:481, tracking.py:154). */
 int sgx_if_upload(sgx_ctx* c, const int8_t* host, size_t n, sgx_if** out);

@@ -69,6 +69,8 @@ _PROTOS = {
     "sgx_ctx_destroy": (C.c_int, [_P]),
     "sgx_ctx_sync": (C.c_int, [_P]),
     "sgx_get_timing": (C.c_int, [_P, C.POINTER(Timing)]),
+    "sgx_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(_P)]),
+    "sgx_host_free": (C.c_int, [_P]),
     "sgx_if_upload": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(_P)]),
     "sgx_if_synth": (C.c_int, [_P, C.POINTER(Scene), C.c_uint64, C.c_size_t, C.POINTER(_P)]),
     "sgx_if_download": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P]),
@@ -135,6 +137,47 @@ def scene_struct(scene):
     for i in range(256):
         sc.cos_lut[i] = int(scene.cos_lut[i])
     return sc
+
+
+class _Pinned(object):
+    """Owner of one pinned host allocation; numpy arrays built on it keep it alive through .base."""
+
+    def __init__(self, nbytes):
+        self.ptr = _P()
+        check(lib().sgx_host_alloc(int(nbytes), C.byref(self.ptr)))
+        self.nbytes = int(nbytes)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().sgx_host_free(self.ptr)
+        except Exception:
+            pass
+
+
+_pinned_pool = []   # pinning is slow (ms per 30 MB): allocations whose arrays have died are reused
+
+
+def pinned_empty(shape, dtype=np.float64):
+    """numpy array in pinned host memory (falls back to a pageable array if pinning fails)."""
+    import sys
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    own = None
+    for cand in _pinned_pool:
+        if cand.nbytes >= n and sys.getrefcount(cand) <= 3:   # pool + loop variable + getrefcount argument
+            own = cand
+            break
+    if own is None:
+        try:
+            own = _Pinned(max(n, 1))
+        except Exception:
+            return np.empty(shape, dtype=dtype)
+        _pinned_pool.append(own)
+        if len(_pinned_pool) > 8:
+            _pinned_pool.pop(0)
+    buf = (C.c_char * own.nbytes).from_address(own.ptr.value)
+    buf._owner = own                       # ctypes object keeps the owner, numpy keeps the ctypes object
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
 
 def device_count():
@@ -208,7 +251,7 @@ class Context(object):
         arr = (ChanInit * n)()
         for i, (prn, f, cp) in enumerate(chans):
             arr[i] = ChanInit(float(f), float(cp), int(prn), 0)
-        out = np.empty((n, NUM_SERIES, int(ms)))
+        out = pinned_empty((n, NUM_SERIES, int(ms)))
         done = np.zeros(n, dtype=np.int32)
         check(lib().sgx_track(self._h, rec._h, int(rec_file_offset), C.cast(arr, _P), n, int(ms), _ptr(out),
                               _ptr(done)))

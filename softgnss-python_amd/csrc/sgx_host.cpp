@@ -167,6 +167,7 @@ extern "C" int sgx_ctx_destroy(sgx_ctx* c) {
     hipFree(c->d_fine[1]);
     hipFree(c->d_small);
     hipFree(c->d_trk_out);
+    hipFree(c->d_trk_aux);
     if (c->h_small) hipHostFree(c->h_small);
     for (int i = 0; i < 6; ++i)
         if (c->ev[i]) hipEventDestroy(c->ev[i]);
@@ -185,6 +186,24 @@ extern "C" int sgx_ctx_sync(sgx_ctx* c) {
 extern "C" int sgx_get_timing(sgx_ctx* c, sgx_timing* out) {
     SGX_CHECK_ARG(c && out);
     *out = c->timing;
+    return SGX_OK;
+}
+
+// pinned host memory for result buffers (D2H at full PCIe rate); plain C pointers, caller frees
+extern "C" int sgx_host_alloc(size_t bytes, void** out) {
+    SGX_CHECK_ARG(out && bytes > 0);
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        sgx_set_error("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return SGX_E_NOMEM;
+    }
+    *out = p;
+    return SGX_OK;
+}
+
+extern "C" int sgx_host_free(void* p) {
+    if (p) hipHostFree(p);
     return SGX_OK;
 }
 

@@ -70,6 +70,8 @@ struct sgx_ctx {
     // tracking
     double* d_trk_out = nullptr;
     size_t trk_out_elems = 0;
+    void* d_trk_aux = nullptr;   // per-call device state of sgx_track (channels, done, exchange, err, profile)
+    size_t trk_aux_cap = 0;
 };
 
 // sgx_host.cpp

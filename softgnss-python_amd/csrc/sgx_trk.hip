@@ -36,243 +36,7 @@
 //           (-ffp-contract=off; fused multiply-adds only where written as __builtin_fma).
 // fp64 everywhere: 1e-7 errors in the sums move the code NCO enough to flip a chip-boundary sample
 // somewhere in a 37 s run, which is a 1e-3 relative blip.
-#include <math.h>
-#include <stdlib.h>
-
-#include "sgx_internal.h"
-
-#define TRK_THREADS 256
-#define TRK_UNIT (TRK_THREADS * 16)          // samples per unit (a power of two)
-#define TRK_MAX_SPLIT 10                     // 12 granules per member, two per gathering lane
-
-// -DTRK_FINEPROF: fine-grained phase timestamps of (member 0, lane 0); forces waits at every probe, so it
-// is a diagnosis build only (tools/ notes in DESIGN.md); the normal build compiles the probes away.
-#ifdef TRK_FINEPROF
-#define PROBE(k)                                                            \
-    do {                                                                    \
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");         \
-        __builtin_amdgcn_sched_barrier(0);                                  \
-        const long long t_ = (long long)__builtin_amdgcn_s_memtime();      \
-        fp[k] += t_ - fp_last;                                              \
-        fp_last = t_;                                                       \
-        __builtin_amdgcn_sched_barrier(0);                                  \
-    } while (0)
-#else
-#define PROBE(k) do { } while (0)
-#endif
-
-struct TrkConst {
-    double fs;
-    double code_basis;
-    double code_len;
-    double spacing;
-    double k_code_a;      // tau2code / tau1code
-    double k_code_b;      // PDIcode / tau1code
-    double k_carr_a;      // tau2carr / tau1carr
-    double k_carr_b;      // PDIcarr / tau1carr
-    double inv_2pifs_hi;  // 1 / (2 pi fs) as a double-double
-    double inv_2pifs_lo;
-    double inv_2pi;
-    long long rec_len;
-    long long rec_alloc;  // bytes that may be read (record + zero pad)
-    long long file_off;
-    int ms;
-    int n_ch;
-    int split;            // workgroups cooperating on one channel
-    int n_units;          // units that can hold the longest block
-    int fast_xcd;         // allow the same-XCD exchange path (SGX_TRK_FASTX=0 disables it)
-    int pad;
-};
-
-struct TrkChan {
-    double acquiredFreq;
-    long long pos0;   // record index of the channel's first sample
-    int prn;          // 1-based, 0 = off
-    int pad;
-};
-
-// Per-block parameters: code part written by wave 1, carrier part by wave 0, read by everybody.
-struct TrkBlock {
-    long long pos;
-    int blk;
-    int stop;
-    double startE, stepE, startP, stepP, startL, stepL;
-    double inv_step;          // ~ 1/step, only used to estimate switch samples
-    // carrier phasors (cos, sin)(2 pi r m), r = turns per sample:
-    double2 B[16];            // m = b                      sample b inside a group
-    double2 W1[16];           // m = 16 a                   group a = tid & 15
-    double2 W2[16];           // m = 256 b                  group row b = tid >> 4
-    double2 W3[16];           // m = 4096 u - head, plus the block's start phase: unit u
-};
-
-// Loop state (LDS): code part owned by wave 1, carrier part by wave 0.
-struct TrkState {
-    double codeFreq, remCode, oldCodeNco, oldCodeErr;
-    long long pos;
-    double carrFreq, carrBasis, remCarr, w, oldCarrNco, oldCarrErr;
-};
-
-__device__ __forceinline__ double ramp_at(int i, double step, double start) {
-    return (double)i * step + start;   // two roundings, like numpy's y = arange*step; y += start
-}
-
-// chip index at sample ilo and first sample whose chip index is larger (exact reference arithmetic).
-// (A one-FMA estimate guarded by near-integer tests was tried: it needs a full-precision 1/step and
-// measured slower than these two exact probes.)
-__device__ __forceinline__ void ramp_setup(double start, double step, double inv_step, int ilo, int& k1,
-                                                 int& isw) {
-    const double t = ramp_at(ilo, step, start);
-    k1 = (int)ceil(t);
-    const double kd = (double)k1;
-    // t(i) > kd  <=>  i > (kd-start)/step: the estimate is within one sample of the switch
-    const int cand = (int)ceil((kd - start) * inv_step);
-    const bool at0 = ramp_at(cand, step, start) > kd;
-    const bool atm = ramp_at(cand - 1, step, start) > kd;
-    isw = at0 ? (atm ? cand - 1 : cand) : cand + 1;
-}
-
-// ---- filter phase, code side (wave 1): tracking.py:148-190 scalar part -------------------------------
-__device__ __forceinline__ void prep_code(const TrkConst& K, double codeFreq, double rem, long long pos, TrkState& s,
-                                          TrkBlock& b, bool writer) {
-    const double step = codeFreq / K.fs;                                     // T1
-    const int blk = (int)ceil((K.code_len - rem) / step);
-    const double nb = (double)blk;
-    const double span = nb * step;                                           // blksize * codePhaseStep
-    // T3: np.linspace(start, stop, blk, endpoint=False): delta = stop - start; stepL = delta / blk
-    const double startE = rem - K.spacing;
-    const double stepE = (((span + rem) - K.spacing) - startE) / nb;
-    const double startL = rem + K.spacing;
-    const double stepL = (((span + rem) + K.spacing) - startL) / nb;
-    const double stepP = ((span + rem) - rem) / nb;
-    const double t_last = ramp_at(blk - 1, stepP, rem);
-    if (writer) {
-        b.pos = pos;
-        b.blk = blk;
-        b.stop = (blk <= 0 || pos + blk > K.rec_len) ? 1 : 0;
-        b.startE = startE;
-        b.stepE = stepE;
-        b.startL = startL;
-        b.stepL = stepL;
-        b.startP = rem;
-        b.stepP = stepP;
-        // 1/step: hardware reciprocal estimate + one Newton step; only used to ESTIMATE switch samples
-        const double r0 = __builtin_amdgcn_rcp(step);
-        b.inv_step = __builtin_fma(r0, __builtin_fma(-step, r0, 1.0), r0);
-        s.remCode = (t_last + step) - 1023.0;                                // T4
-        s.pos = pos + blk;
-    }
-}
-
-// sin and cos of 2 pi u for u in [0, 2): quarter-turn reduction (exact), Taylor polynomials on |theta| <= pi/4.
-// ~1 ulp; a short dependent chain matters here because this sits on the per-block critical path.
-__device__ __forceinline__ void sincos_turns(double u, double& sn, double& cs) {
-    const double q = rint(u * 4.0);
-    const double f = __builtin_fma(q, -0.25, u);          // exact, |f| <= 1/8
-    const int qi = (int)q & 3;
-    const double th = f * 6.283185307179586476925287;
-    const double t2 = th * th;
-    double ps = -2.8114572543455206e-15;                   // -1/17!
-    ps = __builtin_fma(ps, t2, 7.6471637318198164e-13);    //  1/15!
-    ps = __builtin_fma(ps, t2, -1.6059043836821613e-10);   // -1/13!
-    ps = __builtin_fma(ps, t2, 2.5052108385441720e-08);    //  1/11!
-    ps = __builtin_fma(ps, t2, -2.7557319223985893e-06);   // -1/9!
-    ps = __builtin_fma(ps, t2, 1.9841269841269841e-04);    //  1/7!
-    ps = __builtin_fma(ps, t2, -8.3333333333333332e-03);   // -1/5!
-    ps = __builtin_fma(ps, t2, 1.6666666666666666e-01);    //  1/3!  (sign folded below)
-    double pc = 4.7794773323873853e-14;                    //  1/16!
-    pc = __builtin_fma(pc, t2, -1.1470745597729725e-11);   // -1/14!
-    pc = __builtin_fma(pc, t2, 2.0876756987868100e-09);    //  1/12!
-    pc = __builtin_fma(pc, t2, -2.7557319223985888e-07);   // -1/10!
-    pc = __builtin_fma(pc, t2, 2.4801587301587302e-05);    //  1/8!
-    pc = __builtin_fma(pc, t2, -1.3888888888888889e-03);   // -1/6!
-    pc = __builtin_fma(pc, t2, 4.1666666666666664e-02);    //  1/4!
-    pc = __builtin_fma(pc, t2, -0.5);                      // -1/2!
-    const double s0 = __builtin_fma(-(ps * t2), th, th);   // th - th^3 * (1/3! - ...)
-    const double c0 = __builtin_fma(pc, t2, 1.0);
-    sn = (qi == 0) ? s0 : (qi == 1) ? c0 : (qi == 2) ? -s0 : -c0;
-    cs = (qi == 0) ? c0 : (qi == 1) ? -s0 : (qi == 2) ? -c0 : s0;
-}
-
-// ---- filter phase, carrier side (wave 0): phasor tables of a block with rate w, start phase remCarr and
-// `head` bytes between the 16-byte boundary and the block's first sample -----------------------------------
-__device__ __forceinline__ void prep_carr(const TrkConst& K, double w, double remCarr, int head, TrkBlock& b,
-                                          int lane) {
-    // trigarg = w * (i/fs) + remCarr (T5); in turns: r*i + remCarr/(2 pi), r = w/(2 pi fs) as a double-double
-    const double r_hi = w * K.inv_2pifs_hi;
-    const double r_lo = __builtin_fma(w, K.inv_2pifs_hi, -r_hi) + w * K.inv_2pifs_lo;
-    const int sel = lane >> 4, idx = lane & 15;
-    const double mult = (sel == 0) ? (double)idx
-                      : (sel == 1) ? (double)(16 * idx)
-                      : (sel == 2) ? (double)(256 * idx)
-                                   : (double)(TRK_UNIT * idx - head);
-    const double p = r_hi * mult;
-    const double e = __builtin_fma(r_hi, mult, -p) + r_lo * mult;
-    double u = (p - floor(p)) + e;
-    if (sel == 3) {
-        u += remCarr * K.inv_2pi;        // < 1
-        u -= (u >= 1.0) ? 1.0 : 0.0;
-    }
-    double sn, cs;
-    sincos_turns(u, sn, cs);
-    const double2 v = make_double2(cs, sn);
-    if (sel == 0) b.B[idx] = v;
-    else if (sel == 1) b.W1[idx] = v;
-    else if (sel == 2) b.W2[idx] = v;
-    else b.W3[idx] = v;
-}
-
-template <int CTRL>
-__device__ __forceinline__ double dpp_add(double v) {
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    const int olo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
-    const int ohi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
-    return v + __hiloint2double(ohi, olo);
-}
-
-// sums over lanes 0..31 and over lanes 32..63 of a wave (fixed order, deterministic);
-// lanes 0..31 return the first sum, lanes 32..63 the second
-__device__ __forceinline__ double half_wave_sum(double v, int lane) {
-    v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
-    v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
-    v = dpp_add<0x141>(v);   // row_half_mirror
-    v = dpp_add<0x140>(v);   // row_mirror: every lane of a row of 16 now holds the row sum
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
-    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
-    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
-    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
-    return lane < 32 ? (r0 + r1) : (r2 + r3);
-}
-
-// sum over each row of 16 lanes; every lane of a row gets its row's sum (fixed order)
-__device__ __forceinline__ double row_sum(double v) {
-    v = dpp_add<0xB1>(v);
-    v = dpp_add<0x4E>(v);
-    v = dpp_add<0x141>(v);
-    v = dpp_add<0x140>(v);
-    return v;
-}
-
-__device__ __forceinline__ unsigned xcc_id() {
-    unsigned x;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
-    return x & 0xF;
-}
-
-// granule store: `fast` = every member of the channel runs on the same XCD (verified at kernel start), so a
-// plain store that stays in the shared L2 is visible to the others' L1-bypassing loads; otherwise a
-// write-through (agent-scope) store.  Either way ONE aligned 8-byte store per granule.
-__device__ __forceinline__ void granule_store(unsigned long long* p, unsigned long long v, bool fast) {
-    if (fast)
-        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    else
-        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ __forceinline__ uint4 load_group(const int8_t* __restrict__ rec, long long addr, long long limit) {
-    if (addr > limit) addr = limit;   // never read past the allocation (data of a stopped block is unused)
-    return *reinterpret_cast<const uint4*>(rec + addr);
-}
+#include "sgx_trk_common.h"
 
 __global__ __launch_bounds__(TRK_THREADS) void trk_kernel(const int8_t* __restrict__ rec,
                                                           const int8_t* __restrict__ codes,
@@ -588,7 +352,7 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_kernel(const int8_t* __restri
             // T7 PLL (tracking.py:223-235); carrier parameters of the next block
             const double I_P = s_tot[2], Q_P = s_tot[3];
             const double oldNco = s_st.oldCarrNco, oldErr = s_st.oldCarrErr, basis = s_st.carrBasis;
-            const double carrError = atan(Q_P / I_P) / 2.0 / M_PI;
+            const double carrError = div_rn(atan(Q_P / I_P) / 2.0, M_PI, K.inv_pi);   // atan(Q/I) / 2 / pi
             const double carrNco = oldNco + K.k_carr_a * (carrError - oldErr) + carrError * K.k_carr_b;
             const double carrFreq = basis + carrNco;
             const double w_new = (carrFreq * 2.0) * M_PI;
@@ -656,10 +420,10 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_kernel(const int8_t* __restri
         }
     }
     if (tid == 0 && prof && member == 0) {
-        prof[ch * 4 + 0] = pf_map;
-        prof[ch * 4 + 1] = pf_wait;
-        prof[ch * 4 + 2] = pf_red;
-        prof[ch * 4 + 3] = pf_flt;
+        prof[ch * 64 + 0] = pf_map;
+        prof[ch * 64 + 1] = pf_wait;
+        prof[ch * 64 + 2] = pf_red;
+        prof[ch * 64 + 3] = pf_flt;
     }
     if (wave == 2 && member == 0 && done > 0 && lane >= 8 && lane < 16 && lane != 11) {
         const int k = lane - 8;
@@ -673,6 +437,11 @@ __global__ __launch_bounds__(TRK_THREADS) void trk_kernel(const int8_t* __restri
 #endif
     if (tid == 0 && member == 0) ms_done[ch] = done;
 }
+
+// sgx_trk_spec.hip
+void sgx_trk_spec_launch(int n_blocks, hipStream_t st, const int8_t* rec, const int8_t* codes, const void* chans,
+                         double* out, int* done, const TrkConst& K, long long* prof, unsigned long long* xch,
+                         int* err);
 
 // tracking.py:65-94: series start as zeros (absoluteSample, I/Q) or +Inf (the others)
 __global__ __launch_bounds__(256) void trk_fill_kernel(double* __restrict__ out, long long ms, long long total) {
@@ -736,7 +505,10 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
         K.split = split;
         const char* fe = getenv("SGX_TRK_FASTX");
         K.fast_xcd = (fe && fe[0] == '0') ? 0 : 1;
-        K.pad = 0;
+        K.nb_base = (int)c->n_code - 3;
+        for (int k = 0; k < 8; ++k) K.inv_nb[k] = 1.0 / (double)(K.nb_base + k);
+        K.inv_fs = 1.0 / S.samplingFreq;
+        K.inv_pi = 1.0 / M_PI;
     }
 
     std::vector<TrkChan> hc((size_t)n_ch);
@@ -765,28 +537,46 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
         }
         c->trk_out_elems = elems;
     }
-    TrkChan* d_ch = nullptr;
-    int* d_done = nullptr;
-    SGX_HIP(hipMalloc((void**)&d_ch, sizeof(TrkChan) * (size_t)n_ch));
-    SGX_HIP(hipMalloc((void**)&d_done, sizeof(int) * (size_t)n_ch));
+    // device-side call state lives in one cached allocation: [channels | done | exchange | err | profile]
+    const size_t sz_ch = ((sizeof(TrkChan) * (size_t)n_ch + 255) / 256) * 256;
+    const size_t sz_done = ((sizeof(int) * (size_t)n_ch + 255) / 256) * 256;
+    const size_t xch_bytes = sizeof(unsigned long long) * (size_t)n_ch * (2 * TRK_MAX_SPLIT * 12 + 16);
+    const size_t sz_xch = ((xch_bytes + 255) / 256) * 256;
+    const size_t sz_prof = sizeof(long long) * 64 * (size_t)n_ch;
+    const size_t need = sz_ch + sz_done + sz_xch + 256 + sz_prof;
+    if (c->trk_aux_cap < need) {
+        if (c->d_trk_aux) hipFree(c->d_trk_aux);
+        c->d_trk_aux = nullptr;
+        c->trk_aux_cap = 0;
+        if (hipMalloc(&c->d_trk_aux, need) != hipSuccess) {
+            sgx_set_error("hipMalloc of %zu tracking state bytes failed", need);
+            return SGX_E_NOMEM;
+        }
+        c->trk_aux_cap = need;
+    }
+    char* aux = (char*)c->d_trk_aux;
+    TrkChan* d_ch = (TrkChan*)aux;
+    int* d_done = (int*)(aux + sz_ch);
+    unsigned long long* d_xch = (unsigned long long*)(aux + sz_ch + sz_done);
+    int* d_err = (int*)(aux + sz_ch + sz_done + sz_xch);
     SGX_HIP(hipMemcpyAsync(d_ch, hc.data(), sizeof(TrkChan) * (size_t)n_ch, hipMemcpyHostToDevice, st));
-    SGX_HIP(hipMemsetAsync(d_done, 0, sizeof(int) * (size_t)n_ch, st));
+    SGX_HIP(hipMemsetAsync(aux + sz_ch, 0, sz_done + sz_xch + 256, st));   // done, every polled word, err
     trk_fill_kernel<<<(unsigned)((elems + 255) / 256), 256, 0, st>>>(c->d_trk_out, ms, (long long)elems);
-    long long* d_prof = nullptr;
     const char* pe = getenv("SGX_TRK_PROFILE");
     const bool want_prof = pe && pe[0] == '1';
-    if (want_prof) SGX_HIP(hipMalloc((void**)&d_prof, sizeof(long long) * 4 * (size_t)n_ch));
-    unsigned long long* d_xch = nullptr;
-    int* d_err = nullptr;
-    const size_t xch_bytes = sizeof(unsigned long long) * (size_t)n_ch * (2 * TRK_MAX_SPLIT * 12 + 16);
-    SGX_HIP(hipMalloc((void**)&d_xch, xch_bytes));
-    SGX_HIP(hipMalloc((void**)&d_err, sizeof(int)));
-    SGX_HIP(hipMemsetAsync(d_xch, 0, xch_bytes, st));   // every polled word is zeroed before every launch
-    SGX_HIP(hipMemsetAsync(d_err, 0, sizeof(int), st));
+    long long* d_prof = want_prof ? (long long*)(aux + sz_ch + sz_done + sz_xch + 256) : nullptr;
     const int n_blocks = ((n_ch + 7) / 8) * 8 * K.split;
+    // SGX_TRK_SPEC=1 selects the experimental speculative pipeline (sgx_trk_spec.hip; needs exactly one unit
+    // per member).  It reproduces the cooperative kernel's results but measured slower.
+    const char* sp = getenv("SGX_TRK_SPEC");
+    const bool use_spec = (K.split > 1 && K.split == K.n_units) && (sp && sp[0] == '1');
+    if (want_prof) SGX_HIP(hipMemsetAsync(d_prof, 0, sizeof(long long) * 64 * (size_t)n_ch, st));
     hipEventRecord(c->ev[3], st);
-    trk_kernel<<<n_blocks, TRK_THREADS, 0, st>>>(r->d, c->d_codes, d_ch, c->d_trk_out, d_done, K, d_prof, d_xch,
-                                                 d_err);
+    if (use_spec)
+        sgx_trk_spec_launch(n_blocks, st, r->d, c->d_codes, d_ch, c->d_trk_out, d_done, K, d_prof, d_xch, d_err);
+    else
+        trk_kernel<<<n_blocks, TRK_THREADS, 0, st>>>(r->d, c->d_codes, d_ch, c->d_trk_out, d_done, K, d_prof, d_xch,
+                                                     d_err);
     hipEventRecord(c->ev[4], st);
     hipError_t e = hipGetLastError();
     int h_err = 0;
@@ -795,18 +585,29 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
     if (e == hipSuccess) e = hipMemcpyAsync(ms_done, d_done, sizeof(int) * (size_t)n_ch, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (want_prof && e == hipSuccess) {
-        std::vector<long long> hp(4 * (size_t)n_ch);
+        std::vector<long long> hp(64 * (size_t)n_ch);
         hipMemcpy(hp.data(), d_prof, sizeof(long long) * hp.size(), hipMemcpyDeviceToHost);
+        if (use_spec) {
+            for (int i = 0; i < n_ch && i < 1; ++i) {
+                const long long* q = &hp[64 * i];
+                const double d = (double)ms;
+                fprintf(stderr, "[sgx trk profile] ch %d spec: exact %lld/%lld wave-blocks\n", i, q[63], 4ll * ms);
+                for (int mm = 0; mm < 2; ++mm) {
+                    const long long* c2 = q + 8 * mm;
+                    fprintf(stderr, "   CAR member %d: bookkeeping %.0f | wait-partials %.0f | rowsum+publish %.0f | poll %.0f | totals %.0f | PLL %.0f | tables+stores %.0f  (sum %.0f)\n",
+                            mm * 5, c2[0] / d, c2[1] / d, c2[4] / d, c2[5] / d, c2[2] / d, c2[6] / d, c2[3] / d,
+                            (c2[0] + c2[1] + c2[2] + c2[3] + c2[4] + c2[5] + c2[6]) / d);
+                }
+                fprintf(stderr, "   COD: wait-totals %.0f | DLL+params %.0f | prediction+stores %.0f\n", q[16] / d, q[18] / d, q[17] / d);
+                fprintf(stderr, "   MAP w2: wait-params %.0f finalize %.0f fold %.0f wait-pred %.0f shadow %.0f | w4: wait-params %.0f finalize %.0f fold %.0f wait-pred %.0f shadow %.0f\n",
+                        q[24] / d, q[25] / d, q[26] / d, q[27] / d, q[28] / d, q[32] / d, q[33] / d, q[34] / d, q[35] / d, q[36] / d);
+            }
+        } else
         for (int i = 0; i < n_ch && i < 4; ++i)
             fprintf(stderr, "[sgx trk profile] ch %d cycles/block: map %.0f wait %.0f reduce %.0f filter %.0f\n", i,
-                    (double)hp[4 * i] / ms, (double)hp[4 * i + 1] / ms, (double)hp[4 * i + 2] / ms,
-                    (double)hp[4 * i + 3] / ms);
+                    (double)hp[64 * i] / ms, (double)hp[64 * i + 1] / ms, (double)hp[64 * i + 2] / ms,
+                    (double)hp[64 * i + 3] / ms);
     }
-    if (d_prof) hipFree(d_prof);
-    hipFree(d_ch);
-    hipFree(d_done);
-    hipFree(d_xch);
-    hipFree(d_err);
     if (e != hipSuccess) {
         sgx_set_error("tracking kernel failed: %s", hipGetErrorString(e));
         return SGX_E_HIP;

@@ -161,3 +161,34 @@ def test_synth_scene_is_integer_and_deterministic(built):
         assert all(isinstance(v, int) for v in sat.values())
     st = built._native.scene_struct(sc)
     assert st.n_sats == 8 and st.sats[0].prn == 1
+
+
+def test_reciprocal_division_identity_used_by_the_kernels():
+    """csrc/sgx_trk_common.h div_rn: a*y with two FMA corrections (y = RN(1/b)) equals IEEE a/b for the
+    divisors on the tracking path (pi, fs, block lengths).  Emulated with exact rational arithmetic."""
+    import math
+    import random
+    from fractions import Fraction as F
+
+    def rn(x):
+        return float(x)          # Fraction -> nearest double, ties to even
+
+    def fma(a, b, c):
+        return rn(F(a) * F(b) + F(c))
+
+    def div_rn(a, b, y):
+        q0 = rn(F(a) * F(y))
+        q1 = fma(fma(-q0, b, a), y, q0)
+        return fma(fma(-q1, b, a), y, q1)
+
+    random.seed(7)
+    for b in (math.pi, 38192000.0, 16367600.0, 38189.0, 38191.0, 38192.0, 38193.0, 38196.0, 16368.0):
+        y = rn(F(1) / F(b))
+        for _ in range(1500):
+            if b == math.pi:
+                a = random.uniform(-0.25, 0.25) * random.choice([1.0, 1e-3, 1e-7])
+            elif b > 1e6:
+                a = 1023000.0 + random.uniform(-60.0, 60.0)
+            else:
+                a = 1023.0 + random.uniform(-2e-3, 2e-3)
+            assert div_rn(a, b, y) == rn(F(a) / F(b))

@@ -305,3 +305,23 @@ def test_many_channels_throughput_mode(full_run):
         assert np.array_equal(s2[i], s2[i % 8])
     assert np.array_equal(s2[:8, 0], series[:, 0, :ms])
     assert _trk_err(s2[:8], series[:, :, :ms]) < 1e-9
+
+
+def test_speculative_pipeline_agrees_with_cooperative_kernel(full_run):
+    """SGX_TRK_SPEC=1 (shadow map + exact correction, sgx_trk_spec.hip) must reproduce the default kernel:
+    identical block boundaries, sums equal to rounding, over a long run including the pull-in transient."""
+    m, s, ctx, sc, rec, a, chans, series, done = full_run
+    old = os.environ.get("SGX_TRK_SPEC")
+    try:
+        os.environ["SGX_TRK_SPEC"] = "1"
+        ms = 12000
+        s2, d2 = ctx.track(rec, chans, ms)
+    finally:
+        if old is None:
+            os.environ.pop("SGX_TRK_SPEC", None)
+        else:
+            os.environ["SGX_TRK_SPEC"] = old
+    assert np.all(d2 == ms)
+    assert np.array_equal(s2[:, 0], series[:, 0, :ms])
+    assert _trk_err(s2, series[:, :, :ms]) < 1e-9
+    assert np.max(np.abs(s2[:, 1:3] - series[:, 1:3, :ms])) < 1e-6
