@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--ms", type=int, default=37000, help="code periods tracked (default: full config)")
     ap.add_argument("--channels", type=int, default=8, help="tracking channels per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--many-channels", type=int, default=1024,
+                    help="extra leg at N=1: channels of the many-channel (bandwidth-regime) tracking run, 0 = skip")
+    ap.add_argument("--many-ms", type=int, default=500)
     ap.add_argument("--cpu-trk-ms", type=int, default=2500, help="ms of 1-channel oracle tracking timed")
     ap.add_argument("--cpu-acq-prns", type=int, default=2, help="PRNs of oracle acquisition timed")
     return ap.parse_args()
@@ -211,6 +214,20 @@ def main():
                          "note": "37 000 dependent steps per channel; 8 channels x 10 cooperating CUs = 80 of 256 "
                                  "CUs busy: latency-bound, not bandwidth-bound (DESIGN.md section 5)"},
         }
+        if world == 1 and args.many_channels > 0:
+            # the same kernel where bandwidth, not the 37 000-step dependency chain, is the limit: one CU per
+            # channel (two channels per CU), replicas of the acquired channels, HIP-event kernel time
+            chans = [(int(c.PRN), float(c.acquiredFreq), float(c.codePhase)) for c in acq.channels if c.PRN != 0]
+            many = [chans[i % len(chans)] for i in range(args.many_channels)]
+            ctx.track(rec, many, 20)
+            ser, dn = ctx.track(rec, many, args.many_ms)
+            t_ms = ctx.timing()["track_ms"]
+            b_many = float(np.sum(ser[:, 0, -1] - np.array([c[2] for c in many]))) + len(many) * args.many_ms * 13 * 8.0
+            out["roofline_many_channels"] = {
+                "kernel": "trk_kernel", "bound": "hbm", "channels": len(many), "ms": args.many_ms,
+                "achieved": b_many / (t_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": b_many / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": t_ms,
+                "note": "same kernel, split=1: channels x ms code periods of independent work (VALU-bound fp64)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, scene, n_code, args, samples_per_step, args.channels, args.ms)
         print(json.dumps(out))
