@@ -89,7 +89,7 @@ def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("SGX_DEVICE", os.environ.get("LOCAL_RANK", "0")))   # one process per GPU
     if world != args.gpus and world > 1:
         args.gpus = world
     dist = None

@@ -122,6 +122,35 @@ __global__ __launch_bounds__(256) void acq_power_kernel(const cplx* __restrict__
     }
 }
 
+// finish the fused last pass: per-workgroup (max, first index) partials -> one per row
+__global__ __launch_bounds__(64) void acq_rowmax_finish_kernel(const double* __restrict__ pmax,
+                                                               const int* __restrict__ parg, int nblk,
+                                                               double* __restrict__ rowmax, int* __restrict__ rowarg) {
+    const int row = blockIdx.x;
+    double best = -1.0;
+    int arg = 0;
+    for (int b = threadIdx.x; b < nblk; b += 64) {
+        const double v = pmax[(long long)row * nblk + b];
+        const int i = parg[(long long)row * nblk + b];
+        if (v > best || (v == best && i < arg)) {
+            best = v;
+            arg = i;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_down(best, o);
+        const int oi = __shfl_down(arg, o);
+        if (ov > best || (ov == best && oi < arg)) {
+            best = ov;
+            arg = oi;
+        }
+    }
+    if (threadIdx.x == 0) {
+        rowmax[row] = best;
+        rowarg[row] = arg;
+    }
+}
+
 struct SecondArgs {
     int row[32];          // power row to search, -1 = skip
     int lo0[32], hi0[32]; // first index range [lo0, hi0)
@@ -148,6 +177,33 @@ __global__ __launch_bounds__(256) void acq_second_kernel(const double* __restric
     if (threadIdx.x == 0) out[p] = s_v[0];
 }
 
+// the same on a recomputed complex correlation row: |z|^2 / N^2 formed on the fly, identical arithmetic to
+// the fused last pass, so peak / second peak is a ratio of consistently rounded values
+__global__ __launch_bounds__(256) void acq_second_cplx_kernel(const cplx* __restrict__ Z, double* __restrict__ out,
+                                                              long long n, double inv_n, SecondArgs a) {
+    const int p = blockIdx.x;
+    double best = -1.0;
+    if (a.row[p] >= 0) {
+        const cplx* __restrict__ zrow = Z + (long long)a.row[p] * n;
+        for (int i = a.lo0[p] + threadIdx.x; i < a.hi0[p]; i += 256) {
+            const double re = zrow[i].x * inv_n, im = zrow[i].y * inv_n;
+            best = fmax(best, re * re + im * im);
+        }
+        for (int i = a.lo1[p] + threadIdx.x; i < a.hi1[p]; i += 256) {
+            const double re = zrow[i].x * inv_n, im = zrow[i].y * inv_n;
+            best = fmax(best, re * re + im * im);
+        }
+    }
+    __shared__ double s_v[256];
+    s_v[threadIdx.x] = best;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) s_v[threadIdx.x] = fmax(s_v[threadIdx.x], s_v[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[p] = s_v[0];
+}
+
 // integer sum of the record window (mean for acquisition.py:59)
 __global__ __launch_bounds__(256) void acq_sum_kernel(const int8_t* __restrict__ x, long long n,
                                                       long long* __restrict__ out) {
@@ -158,32 +214,41 @@ __global__ __launch_bounds__(256) void acq_sum_kernel(const int8_t* __restrict__
     if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long*)out, (unsigned long long)acc);
 }
 
-// acquisition.py:170-177 (A9): xCarrier = (x - mean)[c : c+10N] * code[floor((ts*k)/tc1) mod 1023]
+// acquisition.py:170-177 (A9): xCarrier = (x - mean)[c : c+10N] * code[floor((ts*k)/tc1) mod 1023].
+// Two detected PRNs share one complex row (first -> real part, second -> imaginary part): the two real-input
+// spectra are separated again in the argmax kernel, which halves the 2^22-point FFT work.
 __global__ __launch_bounds__(256) void acq_fine_prep_kernel(const int8_t* __restrict__ x,
                                                             const int8_t* __restrict__ codes, cplx* __restrict__ out,
                                                             long long len, long long row_stride, double mean,
                                                             double ts, double tc1, const int* __restrict__ det_prn,
-                                                            const int* __restrict__ det_phase) {
+                                                            const int* __restrict__ det_phase, int n_det) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= len) return;
-    const int d = blockIdx.y;
+    const int r = blockIdx.y;
     const double v = floor((ts * (double)(i + 1)) / tc1);
     const int chip = (int)((long long)v % 1023);
-    const double xv = (double)x[det_phase[d] + i] - mean;
-    out[(long long)d * row_stride + i] = make_double2(xv * (double)codes[det_prn[d] * 1023 + chip], 0.0);
+    const int d0 = 2 * r, d1 = 2 * r + 1;
+    const double a = ((double)x[det_phase[d0] + i] - mean) * (double)codes[det_prn[d0] * 1023 + chip];
+    const double b = (d1 < n_det) ? ((double)x[det_phase[d1] + i] - mean) * (double)codes[det_prn[d1] * 1023 + chip] : 0.0;
+    out[(long long)r * row_stride + i] = make_double2(a, b);
 }
 
-// acquisition.py:182-187: argmax of |X[4 : uniq-5]| (first occurrence); per-block partial results
+// acquisition.py:182-187: argmax of |X_d[4 : uniq-5]| (first occurrence) for detection d, where the row holds
+// Z = FFT(x_a + i x_b):  X_a[k] = (Z[k] + conj(Z[M-k]))/2,  X_b[k] = (Z[k] - conj(Z[M-k]))/(2i).
+// Only the argmax is observable, so the common factor 1/4 of |.|^2 is dropped.
 __global__ __launch_bounds__(256) void acq_fine_argmax_kernel(const cplx* __restrict__ X, long long row_stride,
                                                               long long lo, long long hi,
                                                               double* __restrict__ pv, long long* __restrict__ pi) {
     const int d = blockIdx.y;
-    const cplx* __restrict__ row = X + (long long)d * row_stride;
+    const cplx* __restrict__ row = X + (long long)(d >> 1) * row_stride;
+    const double sgn = (d & 1) ? -1.0 : 1.0;
     double best = -1.0;
     long long arg = lo;
     for (long long i = lo + (long long)blockIdx.x * 256 + threadIdx.x; i < hi; i += (long long)gridDim.x * 256) {
         const cplx z = row[i];
-        const double v = z.x * z.x + z.y * z.y;
+        const cplx w = row[row_stride - i];           // i >= 4 > 0, so M - i is inside the row
+        const double re = z.x + sgn * w.x, im = z.y - sgn * w.y;   // z +- conj(w)
+        const double v = re * re + im * im;
         if (v > best) {
             best = v;
             arg = i;
@@ -271,7 +336,8 @@ extern "C" int sgx_acquire(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n_
     if ((rc = ensure_buf((void**)&c->d_work[1], &c->cap_w1, work_rows * row_bytes)) != SGX_OK) return rc;
     if ((rc = ensure_buf((void**)&c->d_fwd, &c->cap_fwd, (size_t)rows_fwd * row_bytes)) != SGX_OK) return rc;
     if ((rc = ensure_buf((void**)&c->d_codefd, &c->cap_code, (size_t)n_prn * row_bytes)) != SGX_OK) return rc;
-    if ((rc = ensure_buf((void**)&c->d_pow, &c->cap_pow, work_rows * sizeof(double) * (size_t)N)) != SGX_OK) return rc;
+    const size_t pow_need = noncoh ? work_rows * sizeof(double) * (size_t)N : (size_t)ACQ_MAX_ROWS * 64 * 12 + 4096;
+    if ((rc = ensure_buf((void**)&c->d_pow, &c->cap_pow, pow_need)) != SGX_OK) return rc;
 
     char* dsm = (char*)c->d_small;
     char* hsm = (char*)c->h_small;
@@ -283,9 +349,15 @@ extern "C" int sgx_acquire(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n_
     double* d_second = (double*)(dsm + 1024 + 12 * 4096);
     int* d_detprn = (int*)(dsm + 1024 + 12 * 4096 + 512);
     int* d_detph = d_detprn + 32;
+    const int nblk_last = sgx_fft_last_pass_blocks(&c->plan_code);
+    int2* d_map = (int2*)(dsm + 200000);
     double* d_pv = (double*)(dsm + 65536);
     long long* d_pi = (long long*)(dsm + 65536 + 8 * 32 * 256);
 
+    // per-workgroup maxima of the fused last pass live in the (otherwise unused) power buffer
+    double* d_pmax = c->d_pow;
+    int* d_parg = (int*)(c->d_pow + (size_t)ACQ_MAX_ROWS * 64);
+    SGX_CHECK_ARG(nblk_last <= 64);
     hipEventRecord(c->ev[0], st);
     SGX_HIP(hipMemsetAsync(d_sum, 0, 8, st));
     SGX_HIP(hipMemcpyAsync(d_prn, prn0, sizeof(int) * (size_t)n_prn, hipMemcpyHostToDevice, st));
@@ -324,14 +396,30 @@ extern "C" int sgx_acquire(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n_
     for (int p0 = 0; p0 < n_prn && status == SGX_OK; p0 += prn_chunk) {
         const int np = (p0 + prn_chunk <= n_prn) ? prn_chunk : (n_prn - p0);
         const int rows = np * rows_per_prn;
-        dim3 grid((unsigned)((N + 255) / 256), (unsigned)rows);
-        acq_mul_kernel<<<grid, 256, 0, st>>>(c->d_fwd, c->d_codefd, c->d_work[0], N, rows_per_prn, p0);
-        cplx* res = nullptr;
-        rc = sgx_fft_forward(&c->plan_code, c->d_work[0], c->d_work[1], rows, st, &res, N);
-        if (rc != SGX_OK) return rc;
         const int rows_out = noncoh ? np * n_bins : rows;
-        acq_power_kernel<<<rows_out, 256, 0, st>>>(res, c->d_pow, d_rowmax, d_rowarg, N, inv_n, n_bins, n_blocks,
-                                                   noncoh ? 1 : 0);
+        cplx* res = nullptr;
+        if (noncoh) {
+            // extension path: the blocks' powers are summed per sample, so rows are materialised
+            dim3 grid((unsigned)((N + 255) / 256), (unsigned)rows);
+            acq_mul_kernel<<<grid, 256, 0, st>>>(c->d_fwd, c->d_codefd, c->d_work[0], N, rows_per_prn, p0);
+            rc = sgx_fft_forward(&c->plan_code, c->d_work[0], c->d_work[1], rows, st, &res, N);
+            if (rc != SGX_OK) return rc;
+            acq_power_kernel<<<rows_out, 256, 0, st>>>(res, c->d_pow, d_rowmax, d_rowarg, N, inv_n, n_bins, n_blocks, 1);
+        } else {
+            // reference path, fused: conj(X)*F formed in the first radix pass, |.|^2 and the per-workgroup
+            // maxima taken in the last one; no product rows, no power rows
+            FftFuse fu;
+            fu.mul_x = c->d_fwd;
+            fu.mul_f = c->d_codefd;
+            fu.rows_per_prn = rows_per_prn;
+            fu.prn_base = p0;
+            fu.pmax = d_pmax;
+            fu.parg = d_parg;
+            fu.inv_n = inv_n;
+            rc = sgx_fft_forward_fused(&c->plan_code, c->d_work[0], c->d_work[1], rows, st, &res, N, &fu);
+            if (rc != SGX_OK) return rc;
+            acq_rowmax_finish_kernel<<<rows, 64, 0, st>>>(d_pmax, d_parg, nblk_last, d_rowmax, d_rowarg);
+        }
         double* h_rowmax = (double*)(hsm + 1024);
         int* h_rowarg = (int*)(hsm + 1024 + 8 * 4096);
         SGX_HIP(hipMemcpyAsync(h_rowmax, d_rowmax, sizeof(double) * (size_t)rows_out, hipMemcpyDeviceToHost, st));
@@ -407,7 +495,25 @@ extern "C" int sgx_acquire(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n_
             }
         }
         if (status != SGX_OK) break;
-        acq_second_kernel<<<np, 256, 0, st>>>(c->d_pow, d_second, N, sa);
+        if (noncoh) {
+            acq_second_kernel<<<np, 256, 0, st>>>(c->d_pow, d_second, N, sa);
+        } else {
+            // recompute only the np rows the second-peak search reads (one per PRN)
+            int2* h_map = (int2*)(hsm + 200000);
+            for (int pi = 0; pi < np; ++pi) {
+                h_map[pi] = make_int2(sa.row[pi] % rows_per_prn, p0 + pi);   // row = (pi*blocks + b)*bins + k
+                sa.row[pi] = pi;
+            }
+            SGX_HIP(hipMemcpyAsync(d_map, h_map, sizeof(int2) * (size_t)np, hipMemcpyHostToDevice, st));
+            FftFuse fu;
+            fu.mul_x = c->d_fwd;
+            fu.mul_f = c->d_codefd;
+            fu.row_map = d_map;
+            cplx* r2 = nullptr;
+            rc = sgx_fft_forward_fused(&c->plan_code, c->d_work[0], c->d_work[1], np, st, &r2, N, &fu);
+            if (rc != SGX_OK) return rc;
+            acq_second_cplx_kernel<<<np, 256, 0, st>>>(r2, d_second, N, inv_n, sa);
+        }
         double* h_second = (double*)(hsm + 1024 + 12 * 4096);
         SGX_HIP(hipMemcpyAsync(h_second, d_second, sizeof(double) * (size_t)np, hipMemcpyDeviceToHost, st));
         SGX_HIP(hipStreamSynchronize(st));
@@ -445,9 +551,10 @@ extern "C" int sgx_acquire(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n_
         }
         rc = sgx_fft_plan_create(&c->plan_fine, npts);
         if (rc != SGX_OK) return rc;
-        if ((rc = ensure_buf((void**)&c->d_fine[0], &c->cap_f0, (size_t)n_det * sizeof(cplx) * (size_t)npts)) != SGX_OK)
+        const int n_rows = (n_det + 1) / 2;   // two real signals per complex row
+        if ((rc = ensure_buf((void**)&c->d_fine[0], &c->cap_f0, (size_t)n_rows * sizeof(cplx) * (size_t)npts)) != SGX_OK)
             return rc;
-        if ((rc = ensure_buf((void**)&c->d_fine[1], &c->cap_f1, (size_t)n_det * sizeof(cplx) * (size_t)npts)) != SGX_OK)
+        if ((rc = ensure_buf((void**)&c->d_fine[1], &c->cap_f1, (size_t)n_rows * sizeof(cplx) * (size_t)npts)) != SGX_OK)
             return rc;
         long long h_sum = 0;
         SGX_HIP(hipMemcpyAsync(&h_sum, d_sum, 8, hipMemcpyDeviceToHost, st));
@@ -456,11 +563,11 @@ extern "C" int sgx_acquire(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n_
         SGX_HIP(hipStreamSynchronize(st));
         const double mean = (double)h_sum / (double)n_samples;   // longSignal.mean(), acquisition.py:59
         const double tc1 = 1.0 / S.codeFreqBasis;
-        dim3 grid((unsigned)((len + 255) / 256), (unsigned)n_det);
+        dim3 grid((unsigned)((len + 255) / 256), (unsigned)n_rows);
         acq_fine_prep_kernel<<<grid, 256, 0, st>>>(x, c->d_codes, c->d_fine[0], len, npts, mean, ts, tc1, d_detprn,
-                                                   d_detph);
+                                                   d_detph, n_det);
         cplx* res = nullptr;
-        rc = sgx_fft_forward(&c->plan_fine, c->d_fine[0], c->d_fine[1], n_det, st, &res, len);
+        rc = sgx_fft_forward(&c->plan_fine, c->d_fine[0], c->d_fine[1], n_rows, st, &res, len);
         if (rc != SGX_OK) return rc;
         const int nblk = 256;
         dim3 g2((unsigned)nblk, (unsigned)n_det);

@@ -39,6 +39,16 @@ struct PassArgs {
     long long ns;
     long long nonzero_len;  // input elements >= this index are zero (first pass of a padded row)
     int lo_bits;
+    // MODE 1 (first pass): input row r is conj(mul_x[bk]) * mul_f[prn] instead of in[r]
+    const cplx* mul_x;
+    const cplx* mul_f;
+    const int2* row_map;    // (bk, prn) per row, or null: bk = r % rows_per_prn, prn = prn_base + r / rows_per_prn
+    int rows_per_prn;
+    int prn_base;
+    // MODE 2 (last pass): nothing is stored; |V|^2 * inv_n^2 is reduced to one (max, first index) per workgroup
+    double* pmax;           // [rows][gridDim.x]
+    int* parg;
+    double inv_n;
 };
 
 __device__ __forceinline__ cplx twiddle(const PassArgs& a, long long t) {
@@ -129,20 +139,44 @@ __device__ __forceinline__ void dft_small(cplx (&v)[R], const cplx* __restrict__
     }
 }
 
-template <int R, int TPB>
+// MODE 0: plain pass.  MODE 1: first pass of the correlation batch, the pointwise product conj(X) * F is formed
+// on load (no separate multiply kernel, no product buffer).  MODE 2: last pass of the correlation batch, the
+// outputs are squared, scaled and max-reduced in place (no output rows, no separate power kernel).
+template <int R, int TPB, int MODE>
 __global__ __launch_bounds__(TPB) void fft_pass_kernel(PassArgs a) {
     const long long m = a.n / R;
     const long long j = (long long)blockIdx.x * TPB + threadIdx.x;
-    if (j >= m) return;
     const long long row = blockIdx.y;
+    const bool live = j < m;
+    if (MODE != 2 && !live) return;
     const cplx* __restrict__ in = a.in + row * a.n;
     cplx* __restrict__ out = a.out + row * a.n;
     const long long k = j % a.ns;
     cplx v[R];
+    if (MODE == 1) {
+        int bk, prn;
+        if (a.row_map) {
+            const int2 rm = a.row_map[row];
+            bk = rm.x;
+            prn = rm.y;
+        } else {
+            bk = (int)(row % a.rows_per_prn);
+            prn = a.prn_base + (int)(row / a.rows_per_prn);
+        }
+        const cplx* __restrict__ px = a.mul_x + (long long)bk * a.n;
+        const cplx* __restrict__ pf = a.mul_f + (long long)prn * a.n;
 #pragma unroll
-    for (int q = 0; q < R; ++q) {
-        const long long idx = j + q * m;
-        v[q] = (idx < a.nonzero_len) ? in[idx] : make_double2(0.0, 0.0);
+        for (int q = 0; q < R; ++q) {
+            const long long idx = j + q * m;
+            const cplx xv = px[idx], fv = pf[idx];
+            v[q] = make_double2(__builtin_fma(xv.x, fv.x, xv.y * fv.y), __builtin_fma(xv.x, fv.y, -(xv.y * fv.x)));
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const long long idx = j + q * m;
+            v[q] = (live && idx < a.nonzero_len) ? in[idx] : make_double2(0.0, 0.0);
+        }
     }
     if (a.ns > 1) {
         const long long tstep = k * (a.n / (a.ns * R));
@@ -156,6 +190,44 @@ __global__ __launch_bounds__(TPB) void fft_pass_kernel(PassArgs a) {
     }
     dft_small<R>(v, a.wr);
     const long long j0 = (j / a.ns) * a.ns * R + k;
+    if (MODE == 2) {
+        // acquisition.py:124-126 abs(ifft(.))**2 for this thread's outputs, then (max, FIRST index)
+        double best = -1.0;
+        int arg = 0;
+        if (live) {
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const double re = v[q].x * a.inv_n, im = v[q].y * a.inv_n;
+                const double pw = re * re + im * im;
+                const int idx = (int)(j0 + q * a.ns);
+                if (pw > best || (pw == best && idx < arg)) {
+                    best = pw;
+                    arg = idx;
+                }
+            }
+        }
+        __shared__ double s_v[TPB];
+        __shared__ int s_i[TPB];
+        s_v[threadIdx.x] = best;
+        s_i[threadIdx.x] = arg;
+        __syncthreads();
+        for (int st = TPB / 2; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) {
+                const double ov = s_v[threadIdx.x + st];
+                const int oi = s_i[threadIdx.x + st];
+                if (ov > s_v[threadIdx.x] || (ov == s_v[threadIdx.x] && oi < s_i[threadIdx.x])) {
+                    s_v[threadIdx.x] = ov;
+                    s_i[threadIdx.x] = oi;
+                }
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            a.pmax[row * gridDim.x + blockIdx.x] = s_v[0];
+            a.parg[row * gridDim.x + blockIdx.x] = s_i[0];
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < R; ++q) out[j0 + q * a.ns] = v[q];
 }
@@ -243,14 +315,31 @@ void sgx_fft_plan_destroy(FftPlan* p) {
 }
 
 template <int R, int TPB>
-static void launch_pass(const PassArgs& a, int64_t rows, hipStream_t st) {
+static void launch_pass(const PassArgs& a, int64_t rows, hipStream_t st, int mode) {
     const long long m = a.n / R;
     dim3 grid((unsigned)((m + TPB - 1) / TPB), (unsigned)rows);
-    fft_pass_kernel<R, TPB><<<grid, TPB, 0, st>>>(a);
+    if (mode == 1)
+        fft_pass_kernel<R, TPB, 1><<<grid, TPB, 0, st>>>(a);
+    else if (mode == 2)
+        fft_pass_kernel<R, TPB, 2><<<grid, TPB, 0, st>>>(a);
+    else
+        fft_pass_kernel<R, TPB, 0><<<grid, TPB, 0, st>>>(a);
+}
+
+int sgx_fft_last_pass_blocks(const FftPlan* p) {
+    const int r = p->radices.back();
+    const int tpb = (r == 16 || (r >= 11 && r <= 19)) ? 128 : (r >= 23 ? 64 : 256);
+    const long long m = p->n / r;
+    return (int)((m + tpb - 1) / tpb);
 }
 
 int sgx_fft_forward(const FftPlan* p, cplx* a, cplx* b, int64_t rows, hipStream_t st, cplx** result,
                     int64_t nonzero_len) {
+    return sgx_fft_forward_fused(p, a, b, rows, st, result, nonzero_len, nullptr);
+}
+
+int sgx_fft_forward_fused(const FftPlan* p, cplx* a, cplx* b, int64_t rows, hipStream_t st, cplx** result,
+                          int64_t nonzero_len, const FftFuse* fuse) {
     if (!p->tw_hi || rows < 1 || rows > 65535) {
         sgx_set_error("sgx_fft_forward: bad plan or row count %lld", (long long)rows);
         return SGX_E_ARG;
@@ -259,8 +348,37 @@ int sgx_fft_forward(const FftPlan* p, cplx* a, cplx* b, int64_t rows, hipStream_
     cplx* dst = b;
     long long ns = 1;
     bool first = true;
+    const size_t n_pass = p->radices.size();
+    size_t ipass = 0;
     for (int r : p->radices) {
+        const bool last = (++ipass == n_pass);
+        int mode = 0;
         PassArgs pa;
+        pa.mul_x = pa.mul_f = nullptr;
+        pa.row_map = nullptr;
+        pa.rows_per_prn = 1;
+        pa.prn_base = 0;
+        pa.pmax = nullptr;
+        pa.parg = nullptr;
+        pa.inv_n = 0.0;
+        if (fuse && first && fuse->mul_x) {
+            mode = 1;
+            pa.mul_x = fuse->mul_x;
+            pa.mul_f = fuse->mul_f;
+            pa.row_map = fuse->row_map;
+            pa.rows_per_prn = fuse->rows_per_prn;
+            pa.prn_base = fuse->prn_base;
+        }
+        if (fuse && last && fuse->pmax) {
+            if (mode == 1) {
+                sgx_set_error("single-pass FFT cannot fuse both ends");
+                return SGX_E_ARG;
+            }
+            mode = 2;
+            pa.pmax = fuse->pmax;
+            pa.parg = fuse->parg;
+            pa.inv_n = fuse->inv_n;
+        }
         pa.in = src;
         pa.out = dst;
         pa.tw_hi = p->tw_hi;
@@ -271,20 +389,20 @@ int sgx_fft_forward(const FftPlan* p, cplx* a, cplx* b, int64_t rows, hipStream_
         pa.nonzero_len = first ? nonzero_len : p->n;
         pa.lo_bits = p->lo_bits;
         switch (r) {
-            case 16: launch_pass<16, 128>(pa, rows, st); break;
-            case 8: launch_pass<8, 256>(pa, rows, st); break;
-            case 4: launch_pass<4, 256>(pa, rows, st); break;
-            case 2: launch_pass<2, 256>(pa, rows, st); break;
-            case 3: launch_pass<3, 256>(pa, rows, st); break;
-            case 5: launch_pass<5, 256>(pa, rows, st); break;
-            case 7: launch_pass<7, 256>(pa, rows, st); break;
-            case 11: launch_pass<11, 128>(pa, rows, st); break;
-            case 13: launch_pass<13, 128>(pa, rows, st); break;
-            case 17: launch_pass<17, 128>(pa, rows, st); break;
-            case 19: launch_pass<19, 128>(pa, rows, st); break;
-            case 23: launch_pass<23, 64>(pa, rows, st); break;
-            case 29: launch_pass<29, 64>(pa, rows, st); break;
-            case 31: launch_pass<31, 64>(pa, rows, st); break;
+            case 16: launch_pass<16, 128>(pa, rows, st, mode); break;
+            case 8: launch_pass<8, 256>(pa, rows, st, mode); break;
+            case 4: launch_pass<4, 256>(pa, rows, st, mode); break;
+            case 2: launch_pass<2, 256>(pa, rows, st, mode); break;
+            case 3: launch_pass<3, 256>(pa, rows, st, mode); break;
+            case 5: launch_pass<5, 256>(pa, rows, st, mode); break;
+            case 7: launch_pass<7, 256>(pa, rows, st, mode); break;
+            case 11: launch_pass<11, 128>(pa, rows, st, mode); break;
+            case 13: launch_pass<13, 128>(pa, rows, st, mode); break;
+            case 17: launch_pass<17, 128>(pa, rows, st, mode); break;
+            case 19: launch_pass<19, 128>(pa, rows, st, mode); break;
+            case 23: launch_pass<23, 64>(pa, rows, st, mode); break;
+            case 29: launch_pass<29, 64>(pa, rows, st, mode); break;
+            case 31: launch_pass<31, 64>(pa, rows, st, mode); break;
             default:
                 sgx_set_error("radix %d not instantiated", r);
                 return SGX_E_ARG;

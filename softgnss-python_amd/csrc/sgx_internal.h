@@ -85,4 +85,19 @@ void sgx_fft_plan_destroy(FftPlan* p);
 int sgx_fft_forward(const FftPlan* p, cplx* a, cplx* b, int64_t rows, hipStream_t st, cplx** result,
                     int64_t nonzero_len);
 
+// Optional fusion of the acquisition's pointwise kernels into the first / last radix pass.
+struct FftFuse {
+    const cplx* mul_x = nullptr;   // first pass input = conj(mul_x[bk]) * mul_f[prn]
+    const cplx* mul_f = nullptr;
+    const int2* row_map = nullptr; // device (bk, prn) per row, or null for the regular batch layout
+    int rows_per_prn = 1;
+    int prn_base = 0;
+    double* pmax = nullptr;        // last pass: per-workgroup (max, first index) of |.|^2 * inv_n^2
+    int* parg = nullptr;
+    double inv_n = 0.0;
+};
+int sgx_fft_forward_fused(const FftPlan* p, cplx* a, cplx* b, int64_t rows, hipStream_t st, cplx** result,
+                          int64_t nonzero_len, const FftFuse* fuse);
+int sgx_fft_last_pass_blocks(const FftPlan* p);
+
 // sgx_synth.hip / sgx_acq.hip / sgx_trk.hip provide the C-ABI entry points directly.
