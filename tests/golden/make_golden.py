@@ -202,6 +202,39 @@ def main():
                             ch_codePhase=acq_t.channels.codePhase)
         print("trk_default.npz", series.shape)
 
+        # ---- 9: a second front end (16.3676 Msps, IF 4.1304 MHz, N = 16368 = 2^4*3*11*31) ----------------
+        s2 = initialize.Settings()
+        s2.samplingFreq = 16367600.0
+        s2.IF = 4130400.0
+        s2.msToProcess = 250.0
+        s2.numberOfChannels = 3
+        s2.acqSatelliteList = range(1, 13)
+        n2 = s2.samplesPerCode
+        sc2 = synth.Scene.make(0x16360001, s2.samplingFreq, s2.IF, [2, 5, 9], [2100, -1800, 650], [4000, 9000, 15555],
+                               [8, 7, 7])
+        rec2 = synth.generate(sc2, synth.record_length(n2, 250))
+        acq2 = acquisition.AcquisitionResult(s2)
+        fb2, fi2 = traced_acquire(acq2, rec2[:11 * n2])
+        npts2 = int(8 * 2 ** np.ceil(np.log2(10 * n2)))
+        det2 = acq2.carrFreq > 0
+        fi2[det2] = np.round(acq2.carrFreq[det2] * npts2 / s2.samplingFreq).astype(np.int64)
+        with Quiet():
+            acq2.preRun()
+        trk_b = tracking.TrackingResult(acq2)
+        fid2 = as_file(tmp, "rec2.bin", rec2)
+        with Quiet():
+            trk_b.track(fid2)
+        rb = trk_b.results
+        series2 = np.stack([np.stack([np.asarray(rb[i][k], dtype=np.float64) for k in names]) for i in range(len(rb))])
+        np.savez_compressed(os.path.join(HERE, "rate2.npz"), scene=scene_json(sc2), n_samples=np.int64(len(rec2)),
+                            samples_per_code=np.int64(n2), ms=np.int64(250),
+                            ca_table_bits=np.packbits(s2.makeCaTable() > 0, axis=1),
+                            carrFreq=acq2.carrFreq, codePhase=acq2.codePhase, peakMetric=acq2.peakMetric,
+                            freqBin=fb2, fineIdx=fi2, ch_PRN=acq2.channels.PRN,
+                            ch_acquiredFreq=acq2.channels.acquiredFreq, ch_codePhase=acq2.channels.codePhase,
+                            series=series2, PRN=np.array([int(x.PRN) for x in rb]))
+        print("rate2.npz", n2, np.flatnonzero(det2) + 1, series2.shape)
+
         trk2 = tracking.TrackingResult(acq_t)
         short = as_file(tmp, "short.bin", rec[:100 * n])
         with Quiet():

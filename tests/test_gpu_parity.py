@@ -325,3 +325,43 @@ def test_speculative_pipeline_agrees_with_cooperative_kernel(full_run):
     assert np.array_equal(s2[:, 0], series[:, 0, :ms])
     assert _trk_err(s2, series[:, :, :ms]) < 1e-9
     assert np.max(np.abs(s2[:, 1:3] - series[:, 1:3, :ms])) < 1e-6
+
+
+def test_second_front_end_golden():
+    """Another samplesPerCode (16368 = 2^4*3*11*31: other FFT radices, 5 tracking units instead of 10)."""
+    g = load_golden("rate2.npz")
+    m = pkg()
+    s = m.Settings()
+    s.samplingFreq = 16367600.0
+    s.IF = 4130400.0
+    s.msToProcess = 250.0
+    s.numberOfChannels = 3
+    s.acqSatelliteList = range(1, 13)
+    n = s.samplesPerCode
+    assert n == 16368
+    rec = m.synth.generate(scene_from_json(g["scene"]), int(g["n_samples"]))
+    a = m.AcquisitionResult(s, device=0)
+    a.acquire(rec[:11 * n])
+    assert np.array_equal(a.codePhase, g["codePhase"])
+    assert np.array_equal(a.carrFreq, g["carrFreq"])
+    assert np.array_equal(a.internals["freqBin"][:12], g["freqBin"][:12])
+    assert np.allclose(a.peakMetric, g["peakMetric"], rtol=1e-9, atol=0)
+    a.preRun()
+    assert np.array_equal(a.channels.PRN, g["ch_PRN"])
+    for env in ({}, {"SGX_TRK_SPLIT": "1"}, {"SGX_TRK_SPEC": "1"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            t = m.TrackingResult(a, device=0)
+            with tempfile.NamedTemporaryFile(suffix=".bin") as f:
+                rec.tofile(f.name)
+                with open(f.name, "rb") as fid:
+                    t.track(fid)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        assert np.array_equal(t.series[:, 0], g["series"][:, 0])
+        assert _trk_err(t.series, g["series"]) < TRK_TOL

@@ -111,3 +111,26 @@ def test_track_short_read_returns_none(default_record):
     ch = dict(PRN=gt["ch_PRN"], acquiredFreq=gt["ch_acquiredFreq"], codePhase=gt["ch_codePhase"],
               status=['T'] * 4)
     assert orc.track(s, ch, default_record[:int(g["n_samples"])]) is None
+
+
+def test_second_front_end_matches_reference():
+    """16.3676 Msps / IF 4.1304 MHz (samplesPerCode 16368): table, acquisition of 12 PRNs, preRun and
+    3 channels x 250 ms of tracking, all bit-for-bit against the reference's outputs."""
+    g = load_golden("rate2.npz")
+    synth = pkg("synth")
+    s = orc.OracleSettings(samplingFreq=16367600.0, IF=4130400.0, msToProcess=250.0, numberOfChannels=3,
+                           acqSatelliteList=range(1, 13))
+    n = s.samplesPerCode
+    assert n == int(g["samples_per_code"]) == 16368
+    assert np.array_equal(np.packbits(orc.make_ca_table(s) > 0, axis=1), g["ca_table_bits"])
+    rec = synth.generate(scene_from_json(g["scene"]), int(g["n_samples"]))
+    r = orc.acquire(s, rec[:11 * n])
+    for k in ("carrFreq", "codePhase", "peakMetric", "freqBin"):
+        assert np.array_equal(r[k], g[k]), k
+    det = g["carrFreq"] > 0
+    assert list(np.flatnonzero(det) + 1) == [2, 5, 9]
+    assert np.array_equal(r["fineIdx"][det], g["fineIdx"][det])
+    ch = orc.pre_run(s, r)
+    assert np.array_equal(ch["PRN"], g["ch_PRN"]) and np.array_equal(ch["codePhase"], g["ch_codePhase"])
+    out = orc.track(s, ch, rec)
+    assert np.array_equal(orc.stack_series(out), g["series"])
