@@ -126,6 +126,11 @@ int sgx_host_free(void* p);
 /* np.fromfile(fid, 'int8', n) replacement: copy n host samples into a new HBM record
  * (initialize.py:481, tracking.py:154). */
 int sgx_if_upload(sgx_ctx* c, const int8_t* host, size_t n, sgx_if** out);
+/* The same straight from the record file (the reference's fid, initialize.py:466-481 / tracking.py:107,154):
+ * bytes [file_offset, file_offset + n) of `path` (raw headerless int8 samples) are streamed through two
+ * pinned staging buffers, the next pread overlapping the previous chunk's H2D copy.  A file shorter than
+ * requested yields a shorter record (tracking then reports the reference's short-read exit). */
+int sgx_if_upload_file(sgx_ctx* c, const char* path, uint64_t file_offset, size_t n, sgx_if** out);
 /* Generate samples [offset, offset+n) of a synthetic scene directly in HBM. */
 int sgx_if_synth(sgx_ctx* c, const sgx_scene* scene, uint64_t offset, size_t n, sgx_if** out);
 int sgx_if_download(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n, int8_t* host);

@@ -72,6 +72,7 @@ _PROTOS = {
     "sgx_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(_P)]),
     "sgx_host_free": (C.c_int, [_P]),
     "sgx_if_upload": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(_P)]),
+    "sgx_if_upload_file": (C.c_int, [_P, C.c_char_p, C.c_uint64, C.c_size_t, C.POINTER(_P)]),
     "sgx_if_synth": (C.c_int, [_P, C.POINTER(Scene), C.c_uint64, C.c_size_t, C.POINTER(_P)]),
     "sgx_if_download": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P]),
     "sgx_if_length": (C.c_int, [_P, C.POINTER(C.c_size_t)]),
@@ -225,6 +226,14 @@ class Context(object):
         h = _P()
         check(lib().sgx_if_upload(self._h, _ptr(a), a.size, C.byref(h)))
         return Record(self, h, a.size)
+
+    def upload_file(self, path, file_offset, n):
+        """Stream bytes [file_offset, file_offset+n) of a raw int8 record file into HBM."""
+        h = _P()
+        check(lib().sgx_if_upload_file(self._h, os.fsencode(path), int(file_offset), int(n), C.byref(h)))
+        ln = C.c_size_t(0)
+        check(lib().sgx_if_length(h, C.byref(ln)))
+        return Record(self, h, int(ln.value))
 
     def synth(self, scene, n, offset=0):
         h = _P()

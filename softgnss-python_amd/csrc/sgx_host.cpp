@@ -2,6 +2,10 @@
 // Compiled with -ffp-contract=off: the index math below must round exactly like the reference's
 // numpy expressions.
 #include <dlfcn.h>
+#include <errno.h>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdlib.h>
@@ -247,6 +251,77 @@ extern "C" int sgx_if_upload(sgx_ctx* c, const int8_t* host, size_t n, sgx_if** 
             sgx_set_error("H2D copy of the IF record failed: %s", hipGetErrorString(e));
             return SGX_E_HIP;
         }
+    }
+    *out = r;
+    return SGX_OK;
+}
+
+// Streaming ingest: pread() into one pinned buffer while the other is in flight.
+extern "C" int sgx_if_upload_file(sgx_ctx* c, const char* path, uint64_t file_offset, size_t n, sgx_if** out) {
+    SGX_CHECK_ARG(c && path && out);
+    SGX_HIP(hipSetDevice(c->device));
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) {
+        sgx_set_error("cannot open %s: %s", path, strerror(errno));
+        return SGX_E_ARG;
+    }
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) {
+        close(fd);
+        sgx_set_error("fstat(%s) failed: %s", path, strerror(errno));
+        return SGX_E_ARG;
+    }
+    size_t avail = ((uint64_t)sb.st_size > file_offset) ? (size_t)((uint64_t)sb.st_size - file_offset) : 0;
+    if (avail > n) avail = n;
+    sgx_if* r = nullptr;
+    int rc = if_alloc(c, avail, &r);
+    if (rc != SGX_OK) {
+        close(fd);
+        return rc;
+    }
+    const size_t chunk = 32u << 20;
+    void* stage[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipHostMalloc(&stage[i], chunk, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+    }
+    size_t off = 0;
+    int k = 0;
+    bool io_fail = false;
+    while (e == hipSuccess && off < avail) {
+        const size_t len = (avail - off < chunk) ? (avail - off) : chunk;
+        e = hipEventSynchronize(done[k]);   // the copy that last used this staging buffer has finished
+        if (e != hipSuccess) break;
+        size_t got = 0;
+        while (got < len) {
+            const ssize_t m = pread(fd, (char*)stage[k] + got, len - got, (off_t)(file_offset + off + got));
+            if (m <= 0) {
+                io_fail = true;
+                break;
+            }
+            got += (size_t)m;
+        }
+        if (io_fail) break;
+        e = hipMemcpyAsync(r->d + off, stage[k], len, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipEventRecord(done[k], c->stream);
+        off += len;
+        k ^= 1;
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    for (int i = 0; i < 2; ++i) {
+        if (done[i]) hipEventDestroy(done[i]);
+        if (stage[i]) hipHostFree(stage[i]);
+    }
+    close(fd);
+    if (e != hipSuccess || io_fail) {
+        sgx_if_free(c, r);
+        if (io_fail)
+            sgx_set_error("read error on %s at byte %llu: %s", path, (unsigned long long)(file_offset + off), strerror(errno));
+        else
+            sgx_set_error("streaming upload of %s failed: %s", path, hipGetErrorString(e));
+        return io_fail ? SGX_E_ARG : SGX_E_HIP;
     }
     *out = r;
     return SGX_OK;

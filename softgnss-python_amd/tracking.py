@@ -6,6 +6,8 @@ per-millisecond series come back as a record array shaped like the reference's.
 """
 from __future__ import print_function
 
+import os
+
 import numpy as np
 
 from . import _native, engine
@@ -31,6 +33,10 @@ class TrackingResult(Result):
     def _window(self, fid, first, need):
         """Bytes [first, first+need) of the reference's file, as an HBM record."""
         ctx = engine.get_context(self._settings, self._device)
+        # a real file on disk: stream it natively (pinned double buffering, no numpy copy of the record)
+        name = getattr(fid, 'name', None)
+        if isinstance(name, (str, bytes)) and os.path.isfile(name) and self._settings.dataType == 'int8':
+            return ctx.upload_file(name, first, need)
         fid.seek(first, 0)
         if hasattr(fid, 'fileno'):
             try:

@@ -365,3 +365,20 @@ def test_second_front_end_golden():
                     os.environ[k] = v
         assert np.array_equal(t.series[:, 0], g["series"][:, 0])
         assert _trk_err(t.series, g["series"]) < TRK_TOL
+
+
+def test_streaming_file_ingest_matches_file_bytes():
+    """sgx_if_upload_file: several 32 MiB chunks, an unaligned offset, a short file."""
+    m, s, ctx = _ctx()
+    rng = np.random.default_rng(5)
+    data = rng.integers(-128, 128, size=(32 << 20) * 2 + 12345, dtype=np.int8)
+    with tempfile.NamedTemporaryFile(suffix=".bin") as f:
+        data.tofile(f.name)
+        for off, n in ((0, data.size), (777, (32 << 20) + 99), (data.size - 1000, 5000)):
+            rec = ctx.upload_file(f.name, off, n)
+            want = data[off:off + n]
+            assert len(rec) == want.size
+            assert np.array_equal(rec.download(), want)
+            rec.free()
+    with pytest.raises(m._native.SgxError):
+        ctx.upload_file("/nonexistent/record.bin", 0, 10)
