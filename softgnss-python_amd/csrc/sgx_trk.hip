@@ -134,16 +134,33 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
         hc[(size_t)i].pos0 = p0;
     }
     const size_t elems = (size_t)n_ch * SGX_NUM_SERIES * (size_t)ms;
-    if (c->trk_out_elems < elems) {
-        if (c->d_trk_out) hipFree(c->d_trk_out);
-        c->d_trk_out = nullptr;
-        c->trk_out_elems = 0;
-        hipError_t e = hipMalloc((void**)&c->d_trk_out, elems * sizeof(double));
-        if (e != hipSuccess) {
-            sgx_set_error("hipMalloc of %zu tracking output bytes failed", elems * sizeof(double));
-            return SGX_E_NOMEM;
+    // If the caller's result buffer is pinned host memory (sgx_host_alloc; the Python binding's is), the kernel's
+    // record stores - 104 bytes per channel per millisecond, issued by an otherwise idle wave - go straight to it
+    // over PCIe: no device staging buffer, no D2H copy and no prefill pass after the kernel.
+    double* d_out = nullptr;
+    bool direct = false;
+    {
+        hipPointerAttribute_t pa;
+        if (hipPointerGetAttributes(&pa, out) == hipSuccess && pa.type == hipMemoryTypeHost && pa.devicePointer) {
+            d_out = (double*)pa.devicePointer;
+            direct = true;
+        } else {
+            (void)hipGetLastError();   // a pageable pointer is not an error
         }
-        c->trk_out_elems = elems;
+    }
+    if (!direct) {
+        if (c->trk_out_elems < elems) {
+            if (c->d_trk_out) hipFree(c->d_trk_out);
+            c->d_trk_out = nullptr;
+            c->trk_out_elems = 0;
+            hipError_t e = hipMalloc((void**)&c->d_trk_out, elems * sizeof(double));
+            if (e != hipSuccess) {
+                sgx_set_error("hipMalloc of %zu tracking output bytes failed", elems * sizeof(double));
+                return SGX_E_NOMEM;
+            }
+            c->trk_out_elems = elems;
+        }
+        d_out = c->d_trk_out;
     }
     // device-side call state lives in one cached allocation: [channels | done | exchange | err | profile]
     const size_t sz_ch = ((sizeof(TrkChan) * (size_t)n_ch + 255) / 256) * 256;
@@ -169,7 +186,7 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
     int* d_err = (int*)(aux + sz_ch + sz_done + sz_xch);
     SGX_HIP(hipMemcpyAsync(d_ch, hc.data(), sizeof(TrkChan) * (size_t)n_ch, hipMemcpyHostToDevice, st));
     SGX_HIP(hipMemsetAsync(aux + sz_ch, 0, sz_done + sz_xch + 256, st));   // done, every polled word, err
-    trk_fill_kernel<<<(unsigned)((elems + 255) / 256), 256, 0, st>>>(c->d_trk_out, ms, (long long)elems);
+    if (!direct) trk_fill_kernel<<<(unsigned)((elems + 255) / 256), 256, 0, st>>>(d_out, ms, (long long)elems);
     const char* pe = getenv("SGX_TRK_PROFILE");
     const bool want_prof = pe && pe[0] == '1';
     long long* d_prof = want_prof ? (long long*)(aux + sz_ch + sz_done + sz_xch + 256) : nullptr;
@@ -181,17 +198,17 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
     if (want_prof) SGX_HIP(hipMemsetAsync(d_prof, 0, sizeof(long long) * 64 * (size_t)n_ch, st));
     hipEventRecord(c->ev[3], st);
     if (use_spec)
-        sgx_trk_spec_launch(n_blocks, st, r->d, c->d_codes, d_ch, c->d_trk_out, d_done, K, d_prof, d_xch, d_err);
+        sgx_trk_spec_launch(n_blocks, st, r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err);
     else if (K.split == 1 && n_ch > 128)
-        sgx_trk_tp_launch(n_blocks, st, r->d, c->d_codes, d_ch, c->d_trk_out, d_done, K, d_prof, d_xch, d_err);
+        sgx_trk_tp_launch(n_blocks, st, r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err);
     else
-        trk_kernel<<<n_blocks, TRK_THREADS, 0, st>>>(r->d, c->d_codes, d_ch, c->d_trk_out, d_done, K, d_prof, d_xch,
+        trk_kernel<<<n_blocks, TRK_THREADS, 0, st>>>(r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch,
                                                         d_err);
     hipEventRecord(c->ev[4], st);
     hipError_t e = hipGetLastError();
     int h_err = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(out, c->d_trk_out, elems * sizeof(double), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && !direct) e = hipMemcpyAsync(out, d_out, elems * sizeof(double), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(ms_done, d_done, sizeof(int) * (size_t)n_ch, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (want_prof && e == hipSuccess) {
@@ -221,6 +238,18 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
     if (e != hipSuccess) {
         sgx_set_error("tracking kernel failed: %s", hipGetErrorString(e));
         return SGX_E_HIP;
+    }
+    if (direct) {
+        // entries never reached keep the reference's initial values (tracking.py:65-94): zeros or +Inf
+        for (int i = 0; i < n_ch; ++i) {
+            const int dn = (ch[i].prn == 0) ? 0 : ms_done[i];
+            if (dn >= ms) continue;
+            for (int sidx = 0; sidx < SGX_NUM_SERIES; ++sidx) {
+                const bool zero = (sidx == 0) || (sidx >= 3 && sidx <= 8);
+                double* row = out + ((size_t)i * SGX_NUM_SERIES + (size_t)sidx) * (size_t)ms;
+                for (int t = dn; t < ms; ++t) row[t] = zero ? 0.0 : INFINITY;
+            }
+        }
     }
     if (h_err != 0) {
         sgx_set_error("tracking kernel: channel %d timed out waiting for a cooperating workgroup (split %d); "
