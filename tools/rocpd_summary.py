@@ -24,7 +24,7 @@ def main():
     tag, trace = sys.argv[1], sys.argv[2]
     rows = top_kernels(trace)
     with open("profiles/%s_kernel_trace_stats.csv" % tag, "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline\n")
+        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --many-channels 0\n")
         f.write("kernel,calls,total_us,average_us,percent\n")
         for n, calls, tot, avg, pct in rows:
             f.write('"%s",%d,%.3f,%.3f,%.3f\n' % (n, calls, tot, avg, pct))
