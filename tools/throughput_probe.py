@@ -8,7 +8,7 @@ ms = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 rec = ctx.synth(sc, m.synth.record_length(s.samplesPerCode, ms))
 a = m.AcquisitionResult(s, device=0); a.acquire(m.DeviceSignal(rec, 0, 11 * s.samplesPerCode)); a.preRun()
 ch8 = [(int(c.PRN), float(c.acquiredFreq), float(c.codePhase)) for c in a.channels]
-for n in (8, 24, 64, 128, 256, 512, 1024):
+for n in (8, 256, 512, 1024, 2048, 4096):
     chans = [ch8[i % 8] for i in range(n)]
     ctx.track(rec, chans, 50)
     series, done = ctx.track(rec, chans, ms)
