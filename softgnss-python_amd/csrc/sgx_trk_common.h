@@ -260,3 +260,77 @@ __device__ __forceinline__ uint4 load_group(const int8_t* __restrict__ rec, long
     return *reinterpret_cast<const uint4*>(rec + addr);
 }
 
+// ---- chip-lane maps (sgx_trk_tp.hip: one lane per prompt chip; sgx_trk_chip.hip: one lane per half chip) ----
+#define TP_RUN 20   // samples per run handled by the unrolled path
+
+// first sample i with T(i) = fl(fl(i*step)+start) > thr (exact reference arithmetic; see ramp_setup)
+__device__ __forceinline__ int first_above(double start, double step, double inv_step, double thr) {
+    const int cand = (int)ceil((thr - start) * inv_step);
+    const bool at0 = ramp_at(cand, step, start) > thr;
+    const bool atm = ramp_at(cand - 1, step, start) > thr;
+    return at0 ? (atm ? cand - 1 : cand) : cand + 1;
+}
+
+// carrier tables for block-relative sample indices: phasor(i) = W3[i>>12] * W2[(i>>8)&15] * W1[(i>>4)&15] * B[i&15]
+struct TpCarr {
+    double2 B[32];    // (cos, sin)(2 pi r k), k = 0..31
+    double2 W1[16];   // k = 16 a
+    double2 W2[16];   // k = 256 b
+    double2 W3[16];   // k = 4096 u, plus the block's start phase
+};
+
+__device__ __forceinline__ void tp_tables(const TrkConst& K, double w, double remCarr, TpCarr& t, int lane, int round) {
+    const double r_hi = w * K.inv_2pifs_hi;
+    const double r_lo = __builtin_fma(w, K.inv_2pifs_hi, -r_hi) + w * K.inv_2pifs_lo;
+    double mult;
+    if (round == 0)
+        mult = (lane < 32) ? (double)lane : (lane < 48) ? (double)(16 * (lane - 32)) : (double)(256 * (lane - 48));
+    else
+        mult = (double)(4096 * (lane & 15));
+    const double p = r_hi * mult;
+    const double e = __builtin_fma(r_hi, mult, -p) + r_lo * mult;
+    double u = (p - floor(p)) + e;
+    if (round == 1) {
+        u += remCarr * K.inv_2pi;
+        u -= (u >= 1.0) ? 1.0 : 0.0;
+    }
+    double sn, cs;
+    sincos_turns(u, sn, cs);
+    const double2 v = make_double2(cs, sn);
+    if (round == 0) {
+        if (lane < 32) t.B[lane] = v;
+        else if (lane < 48) t.W1[lane - 32] = v;
+        else t.W2[lane - 48] = v;
+    } else if (lane < 16) {
+        t.W3[lane] = v;
+    }
+}
+
+__device__ __forceinline__ double2 cmul2(double2 a, double2 b) {
+    return make_double2(__builtin_fma(a.x, b.x, -(a.y * b.y)), __builtin_fma(a.x, b.y, a.y * b.x));
+}
+
+struct __attribute__((packed, aligned(4))) U4a { unsigned x, y, z, w; };   // dword-aligned 16-byte load
+struct __attribute__((packed, aligned(4))) U2a { unsigned x, y; };
+
+// 20 bytes starting at record byte `addr` (any alignment), bytes >= len zeroed: five dwords
+__device__ __forceinline__ void load_run(const int8_t* __restrict__ rec, long long addr, long long limit, int len,
+                                         unsigned (&w)[5]) {
+    long long a4 = addr & ~3ll;
+    if (a4 > limit) a4 = limit;
+    const unsigned sh = (unsigned)(addr & 3);
+    const U4a q = *reinterpret_cast<const U4a*>(rec + a4);
+    const U2a q2 = *reinterpret_cast<const U2a*>(rec + a4 + 16);
+    w[0] = __builtin_amdgcn_alignbyte(q.y, q.x, sh);
+    w[1] = __builtin_amdgcn_alignbyte(q.z, q.y, sh);
+    w[2] = __builtin_amdgcn_alignbyte(q.w, q.z, sh);
+    w[3] = __builtin_amdgcn_alignbyte(q2.x, q.w, sh);
+    w[4] = __builtin_amdgcn_alignbyte(q2.y, q2.x, sh);
+#pragma unroll
+    for (int d = 0; d < 5; ++d) {
+        int keep = len - 4 * d;                      // bytes of this dword inside the run
+        keep = keep < 0 ? 0 : (keep > 4 ? 4 : keep);
+        w[d] &= (keep >= 4) ? 0xFFFFFFFFu : ((1u << (8 * keep)) - 1u);
+    }
+}
+
