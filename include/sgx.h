@@ -82,9 +82,10 @@ typedef struct sgx_sat {
 typedef struct sgx_scene {
     uint64_t seed;
     int32_t n_sats;
-    int32_t reserved;
+    int32_t nav_mode;                      /* 0: hash navigation bits; 1: nav_bits tables (2048 bits per satellite) */
     sgx_sat sats[SGX_MAX_SATS];
     int16_t cos_lut[256];
+    uint8_t nav_bits[SGX_MAX_SATS][256];   /* bit b of satellite s = (nav_bits[s][b >> 3] >> (b & 7)) & 1 */
 } sgx_scene;
 
 /* Timings of the last call, measured with HIP events on the context's stream. */
@@ -165,6 +166,19 @@ int sgx_acquire(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n_samples,
 int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset,
               const sgx_chan_init* ch, int32_t n_ch, int32_t ms,
               double* out, int32_t* ms_done);
+
+/* ---- next row: bit sync + preamble search on the tracking output (postNavigation.py:443-631) ----------------
+ * NavigationResult.findPreambles: I_P is [n_ch][ms] float64 (row i = i-th record of the tracking results);
+ * firstSubFrame[ch] = ms index of the first verified TLM preamble, 0 = none (then the reference drops the
+ * channel from its active list).  The sign correlation against the 160-ms preamble runs on the device, the
+ * 6000-ms spacing test and the TLM/HOW parity checks (navPartyChk) on the host.  SGX_E_RANGE where the
+ * reference's numpy code raises on a slice cut short by the record ends (candidate within 40 ms of the start
+ * or 1200 ms of the end); sgx_last_error() then starts with "ValueError" or "IndexError" accordingly. */
+int sgx_find_preambles(sgx_ctx* c, const double* I_P, int32_t n_ch, int32_t ms, int32_t search_start,
+                       int32_t* firstSubFrame);
+/* NavigationResult.navPartyChk (postNavigation.py:443-521): ndat32 = D29* D30* d1..d24 D25..D30 as +-1;
+ * flips d1..d24 in place when D30* != 1 like the reference; status +1 / -1 (parity ok) or 0. */
+int sgx_nav_parity_check(double* ndat32, int32_t* status);
 
 /* ---- RCCL peak gather (multi-GPU acquisition shard) ------------------
  * One process per GPU.  Rank 0 calls sgx_comm_unique_id and ships the 128 bytes to the other

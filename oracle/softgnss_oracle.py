@@ -327,3 +327,63 @@ def track(s, channels, record, ms=None):
 def stack_series(tracks):
     """[n_active, 13, ms] float64 view of track() output in SERIES order."""
     return np.stack([np.stack([t[k] for k in SERIES]) for t in tracks])
+
+
+# ---- next row (SURVEY.md section 8(f) item 1): bit sync + preamble search on the tracking output ----------
+
+PREAMBLE_BITS = (1, -1, -1, -1, 1, -1, 1, 1)     # postNavigation.py:552
+
+
+def nav_party_chk(ndat):
+    """Parity status of one GPS word: +1 / -1 (passed, data polarity) or 0 (failed).
+    Follows postNavigation.py:443-521 (ICD-200C table 20-XIV with +-1 for bits, products for XOR).
+    ndat: 32 values of +-1 = D29*, D30*, d1..d24, D25..D30; like the reference it flips d1..d24 IN PLACE
+    when D30* is not +1."""
+    if ndat[1] != 1:
+        ndat[2:26] *= (-1)
+    rows = ((0, 2, 3, 4, 6, 7, 11, 12, 13, 14, 15, 18, 19, 21, 24),
+            (1, 3, 4, 5, 7, 8, 12, 13, 14, 15, 16, 19, 20, 22, 25),
+            (0, 2, 4, 5, 6, 8, 9, 13, 14, 15, 16, 17, 20, 21, 23),
+            (1, 3, 5, 6, 7, 9, 10, 14, 15, 16, 17, 18, 21, 22, 24),
+            (1, 2, 4, 6, 7, 8, 10, 11, 15, 16, 17, 18, 19, 22, 23, 25),
+            (0, 4, 6, 7, 9, 10, 11, 12, 14, 16, 20, 23, 24, 25))
+    parity = np.array([np.prod([ndat[i] for i in r]) for r in rows])
+    if (parity == ndat[26:]).sum() == 6:
+        return -1 * ndat[1]
+    return 0
+
+
+def preamble_correlation(i_p, search_start=0):
+    """c[t] = sum_k sign(I_P)[t+k] * preamble_ms[k] for t = 0..L-1, the window running off the end.
+    Equals np.correlate(bits, zero-padded preamble, 'full')[L-1:2L] of postNavigation.py:573-583, computed
+    with 160 taps instead of L."""
+    bits = np.asarray(i_p, dtype=np.float64)[search_start:].copy()
+    bits[bits > 0] = 1
+    bits[bits <= 0] = -1
+    pre = np.kron(np.array(PREAMBLE_BITS, dtype=np.float64), np.ones(20))
+    return np.correlate(np.r_[bits, np.zeros(pre.size - 1)], pre, mode='valid')
+
+
+def find_preambles(i_p_rows, statuses, n_channels, search_start=0):
+    """First subframe start (ms index) per channel and the channels that have one.
+    Follows postNavigation.py:524-631: |correlation| > 153, a second candidate exactly 6000 ms later, parity
+    of the TLM and HOW words on 20-ms sums.  Quirk kept: row `channelNr` of the results is used for the
+    channelNr-th active channel."""
+    first = np.zeros(n_channels, dtype=int)
+    active = np.array([i for i, st in enumerate(statuses) if st != '-'], dtype=int)
+    for ch in range(len(active)):
+        ip = np.asarray(i_p_rows[ch], dtype=np.float64)
+        c = preamble_correlation(ip, search_start)
+        index = (np.abs(c) > 153).nonzero()[0] + search_start
+        for i in range(len(index)):
+            if ((index - index[i]) == 6000).any():
+                bits = ip[index[i] - 40:index[i] + 20 * 60].copy()
+                bits = bits.reshape(20, -1, order='F').sum(0)     # ValueError like the reference if cut short
+                bits[bits > 0] = 1
+                bits[bits <= 0] = -1
+                if nav_party_chk(bits[:32]) != 0 and nav_party_chk(bits[30:62]) != 0:
+                    first[ch] = index[i]
+                    break
+        if first[ch] == 0:
+            active = np.setdiff1d(active, ch)
+    return first, active

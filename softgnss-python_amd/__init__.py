@@ -16,7 +16,8 @@ from . import _native, engine, synth   # noqa: F401
 from .acquisition import AcquisitionResult   # noqa: F401
 from .initialize import Result, Settings, TruePosition   # noqa: F401
 from .record import DeviceFile, DeviceSignal   # noqa: F401
+from .postNavigation import NavigationResult   # noqa: F401
 from .tracking import TrackingResult   # noqa: F401
 
-__all__ = ["Settings", "Result", "TruePosition", "AcquisitionResult", "TrackingResult", "DeviceFile",
+__all__ = ["Settings", "Result", "TruePosition", "AcquisitionResult", "TrackingResult", "NavigationResult", "DeviceFile",
            "DeviceSignal", "synth", "engine"]

@@ -45,8 +45,8 @@ class Sat(C.Structure):
 
 
 class Scene(C.Structure):
-    _fields_ = [("seed", C.c_uint64), ("n_sats", C.c_int32), ("reserved", C.c_int32),
-                ("sats", Sat * MAX_SATS), ("cos_lut", C.c_int16 * 256)]
+    _fields_ = [("seed", C.c_uint64), ("n_sats", C.c_int32), ("nav_mode", C.c_int32),
+                ("sats", Sat * MAX_SATS), ("cos_lut", C.c_int16 * 256), ("nav_bits", (C.c_uint8 * 256) * MAX_SATS)]
 
 
 class Timing(C.Structure):
@@ -80,6 +80,8 @@ _PROTOS = {
     "sgx_acquire": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, C.c_int32, C.c_int32, C.c_int32,
                               _P, _P, _P, _P, _P]),
     "sgx_track": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, C.c_int32, _P, _P]),
+    "sgx_find_preambles": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "sgx_nav_parity_check": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "sgx_comm_unique_id": (C.c_int, [_P]),
     "sgx_comm_create": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.POINTER(_P)]),
     "sgx_comm_allgather": (C.c_int, [_P, _P, _P, C.c_size_t]),
@@ -137,6 +139,13 @@ def scene_struct(scene):
                          s["amp"])
     for i in range(256):
         sc.cos_lut[i] = int(scene.cos_lut[i])
+    tab = getattr(scene, "nav_bits", None)
+    sc.nav_mode = 0 if tab is None else 1
+    if tab is not None:
+        for i in range(len(scene.sats)):
+            packed = np.packbits(np.asarray(tab[i], dtype=np.uint8), bitorder="little")
+            for j in range(256):
+                sc.nav_bits[i][j] = int(packed[j])
     return sc
 
 
@@ -253,6 +262,17 @@ class Context(object):
         check(lib().sgx_acquire(self._h, rec._h, int(offset), int(n_samples), _ptr(prn), n, int(n_blocks),
                                 1 if noncoh else 0, _ptr(carr), _ptr(cph), _ptr(met), _ptr(fb), _ptr(fi)))
         return dict(carrFreq=carr, codePhase=cph, peakMetric=met, freqBin=fb, fineIdx=fi)
+
+    def find_preambles(self, i_p, search_start=0):
+        """i_p: float64[n_ch, ms] -> int array firstSubFrame[n_ch] (0 = no verified preamble)."""
+        a = np.ascontiguousarray(i_p, dtype=np.float64)
+        out = np.zeros(a.shape[0], dtype=np.int32)
+        rc = lib().sgx_find_preambles(self._h, _ptr(a), a.shape[0], a.shape[1], int(search_start), _ptr(out))
+        if rc == SGX_E_RANGE:      # the exceptions the reference's numpy code raises on a record cut short
+            msg = last_error()
+            raise (IndexError if msg.startswith("IndexError") else ValueError)(msg)
+        check(rc)
+        return out.astype(int)
 
     def track(self, rec, chans, ms, rec_file_offset=0):
         """chans: sequence of (prn, acquiredFreq, codePhase). Returns (series[n_ch,13,ms], ms_done)."""

@@ -1,0 +1,148 @@
+// Bit synchronisation + preamble search on the tracking output (reference postNavigation.py:443-631,
+// SURVEY.md section 8(f) item 1): the step that consumes I_P right after TrackingResult.track.
+//
+//   device  c[ch][t] = sum_{k<160} sign(I_P[ch][t+k]) * preamble_ms[k]   (the reference correlates against a
+//           preamble zero-padded to the full record length, O(L^2); only 160 taps are non-zero)
+//   host    candidates |c| > 153 in increasing order, a partner exactly 6000 ms later, parity of the TLM and
+//           HOW words on 20-ms sums (navPartyChk) - a few dozen candidates per channel.
+#include <math.h>
+
+#include "sgx_internal.h"
+
+#define NAV_TAPS 160
+
+__global__ __launch_bounds__(256) void nav_corr_kernel(const double* __restrict__ ip, short* __restrict__ corr,
+                                                       int ms, int start) {
+    __shared__ signed char s_b[256 + NAV_TAPS];
+    const int ch = blockIdx.y;
+    const int len = ms - start;
+    const int t0 = blockIdx.x * 256;
+    const double* __restrict__ row = ip + (long long)ch * ms + start;
+    for (int i = threadIdx.x; i < 256 + NAV_TAPS; i += 256) {
+        const int t = t0 + i;
+        s_b[i] = (t < len) ? (row[t] > 0.0 ? 1 : -1) : 0;   // bits > 0 -> 1, <= 0 -> -1; past the end: 0
+    }
+    __syncthreads();
+    const int t = t0 + threadIdx.x;
+    if (t >= len) return;
+    const int pre[8] = {1, -1, -1, -1, 1, -1, 1, 1};   // postNavigation.py:552
+    int acc = 0;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        int sum = 0;
+#pragma unroll
+        for (int k = 0; k < 20; ++k) sum += s_b[threadIdx.x + 20 * b + k];
+        acc += pre[b] * sum;
+    }
+    corr[(long long)ch * ms + start + t] = (short)acc;
+}
+
+// postNavigation.py:443-521 on +-1 values; flips d1..d24 in place like the reference
+static int parity_status(double* ndat) {
+    if (ndat[1] != 1)
+        for (int i = 2; i < 26; ++i) ndat[i] *= -1;
+    static const int rows[6][17] = {{0, 2, 3, 4, 6, 7, 11, 12, 13, 14, 15, 18, 19, 21, 24, -1},
+                                    {1, 3, 4, 5, 7, 8, 12, 13, 14, 15, 16, 19, 20, 22, 25, -1},
+                                    {0, 2, 4, 5, 6, 8, 9, 13, 14, 15, 16, 17, 20, 21, 23, -1},
+                                    {1, 3, 5, 6, 7, 9, 10, 14, 15, 16, 17, 18, 21, 22, 24, -1},
+                                    {1, 2, 4, 6, 7, 8, 10, 11, 15, 16, 17, 18, 19, 22, 23, 25, -1},
+                                    {0, 4, 6, 7, 9, 10, 11, 12, 14, 16, 20, 23, 24, 25, -1}};
+    int ok = 0;
+    for (int p = 0; p < 6; ++p) {
+        double v = 1.0;
+        for (int j = 0; rows[p][j] >= 0; ++j) v *= ndat[rows[p][j]];
+        ok += (v == ndat[26 + p]);
+    }
+    return ok == 6 ? (int)(-1 * ndat[1]) : 0;
+}
+
+extern "C" int sgx_nav_parity_check(double* ndat32, int32_t* status) {
+    SGX_CHECK_ARG(ndat32 && status);
+    *status = parity_status(ndat32);
+    return SGX_OK;
+}
+
+extern "C" int sgx_find_preambles(sgx_ctx* c, const double* I_P, int32_t n_ch, int32_t ms, int32_t search_start,
+                                  int32_t* firstSubFrame) {
+    SGX_CHECK_ARG(c && I_P && firstSubFrame && n_ch >= 1 && ms >= 1 && search_start >= 0 && search_start < ms);
+    SGX_HIP(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const size_t n = (size_t)n_ch * (size_t)ms;
+    double* d_ip = nullptr;
+    short* d_c = nullptr;
+    SGX_HIP(hipMalloc((void**)&d_ip, n * sizeof(double)));
+    hipError_t e = hipMalloc((void**)&d_c, n * sizeof(short));
+    if (e != hipSuccess) {
+        hipFree(d_ip);
+        sgx_set_error("hipMalloc failed in sgx_find_preambles");
+        return SGX_E_NOMEM;
+    }
+    std::vector<short> corr(n);
+    e = hipMemcpyAsync(d_ip, I_P, n * sizeof(double), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        dim3 grid((unsigned)((ms - search_start + 255) / 256), (unsigned)n_ch);
+        nav_corr_kernel<<<grid, 256, 0, st>>>(d_ip, d_c, ms, search_start);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(corr.data(), d_c, n * sizeof(short), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipFree(d_ip);
+    hipFree(d_c);
+    if (e != hipSuccess) {
+        sgx_set_error("preamble correlation failed: %s", hipGetErrorString(e));
+        return SGX_E_HIP;
+    }
+    for (int ch = 0; ch < n_ch; ++ch) {
+        firstSubFrame[ch] = 0;
+        const double* ip = I_P + (size_t)ch * ms;
+        const short* cc = corr.data() + (size_t)ch * ms;
+        std::vector<int> index;
+        for (int t = search_start; t < ms; ++t)
+            if (abs((int)cc[t]) > 153) index.push_back(t);   // postNavigation.py:583
+        for (size_t i = 0; i < index.size(); ++i) {
+            bool partner = false;
+            for (size_t j = 0; j < index.size() && !partner; ++j) partner = (index[j] - index[i] == 6000);
+            if (!partner) continue;
+            // Python slice I_P[index-40 : index+1200]: a negative start counts from the end, the stop is clipped
+            const int lo = index[i] - 40, hi = index[i] + 20 * 60;
+            const int a0 = lo < 0 ? (ms + lo > 0 ? ms + lo : 0) : lo;
+            const int a1 = hi < ms ? hi : ms;
+            const int len = a1 > a0 ? a1 - a0 : 0;
+            if (len % 20 != 0) {   // reshape(20, -1) of a slice cut short by the end of the record
+                sgx_set_error("ValueError: cannot reshape array of size %d into shape (20,newaxis) "
+                              "(preamble candidate at %d ms, reference postNavigation.py:600-602)", len, index[i]);
+                return SGX_E_RANGE;
+            }
+            const int words = len / 20;
+            if (words < 32) {      // navPartyChk indexes past the end of a word shorter than 32 bits
+                sgx_set_error("IndexError: %d-bit slice around the preamble candidate at %d ms "
+                              "(reference postNavigation.py:443-521, 615)", words, index[i]);
+                return SGX_E_RANGE;
+            }
+            double bits[62];
+            for (int w = 0; w < 62 && w < words; ++w) {
+                double sum = 0.0;
+                for (int k = 0; k < 20; ++k) sum += ip[a0 + 20 * w + k];   // reshape(20,-1,'F').sum(0)
+                bits[w] = sum > 0 ? 1.0 : -1.0;
+            }
+            double w1[32], w2[32];
+            memcpy(w1, bits, sizeof(w1));
+            // the reference checks views of ONE array: the first check's in-place flip of bits[2:26] is seen
+            // by the second check only where the views overlap (bits 30, 31)
+            const int s1 = parity_status(w1);
+            memcpy(bits, w1, sizeof(w1));
+            if (s1 != 0 && words < 62) {
+                sgx_set_error("IndexError: %d-bit slice, second word incomplete, candidate at %d ms "
+                              "(reference postNavigation.py:615)", words, index[i]);
+                return SGX_E_RANGE;
+            }
+            memcpy(w2, bits + 30, sizeof(w2));
+            const int s2 = (s1 != 0) ? parity_status(w2) : 0;
+            if (s1 != 0 && s2 != 0) {
+                firstSubFrame[ch] = index[i];
+                break;
+            }
+        }
+    }
+    return SGX_OK;
+}

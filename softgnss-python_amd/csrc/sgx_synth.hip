@@ -15,20 +15,25 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
     return z;
 }
 
-struct SynthArgs {
-    sgx_scene sc;
+struct SynthArgs {   // the scene without its navigation tables (kernel arguments are limited to 4 KiB)
+    uint64_t seed;
+    int32_t n_sats;
+    int32_t nav_mode;
+    sgx_sat sats[SGX_MAX_SATS];
+    int16_t cos_lut[256];
 };
 
 __global__ __launch_bounds__(256) void synth_kernel(int8_t* __restrict__ out, uint64_t offset, uint64_t n,
-                                                    const int8_t* __restrict__ codes, SynthArgs a) {
+                                                    const int8_t* __restrict__ codes,
+                                                    const uint8_t* __restrict__ nav_bits, SynthArgs a) {
     __shared__ int8_t s_code[SGX_MAX_SATS][1024];
     __shared__ int16_t s_lut[256];
-    const int nsat = a.sc.n_sats;
+    const int nsat = a.n_sats;
     for (int i = threadIdx.x; i < nsat * 1024; i += blockDim.x) {
         const int s = i >> 10, k = i & 1023;
-        s_code[s][k] = (k < 1023) ? codes[(a.sc.sats[s].prn - 1) * 1023 + k] : 0;
+        s_code[s][k] = (k < 1023) ? codes[(a.sats[s].prn - 1) * 1023 + k] : 0;
     }
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_lut[i] = a.sc.cos_lut[i];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_lut[i] = a.cos_lut[i];
     __syncthreads();
 
     const uint64_t groups = (n + 15) / 16;
@@ -38,18 +43,24 @@ __global__ __launch_bounds__(256) void synth_kernel(int8_t* __restrict__ out, ui
 #pragma unroll
         for (int b = 0; b < 16; ++b) {
             const uint64_t idx = offset + g * 16 + b;
-            const uint64_t h = splitmix64(a.sc.seed + (idx + 1) * GOLDEN);
+            const uint64_t h = splitmix64(a.seed + (idx + 1) * GOLDEN);
             const int s4 = (int)(h & 0xFF) + (int)((h >> 8) & 0xFF) + (int)((h >> 16) & 0xFF) +
                            (int)((h >> 24) & 0xFF);
             int acc = ((s4 - 510) * 35) >> 8;
             for (int s = 0; s < nsat; ++s) {
-                const sgx_sat& st = a.sc.sats[s];
+                const sgx_sat& st = a.sats[s];
                 const uint64_t cp = idx * st.code_fcw + st.code_c0;
                 const uint64_t chipw = cp >> 32;
                 const uint32_t chip = (uint32_t)(chipw % 1023ull);
                 const uint64_t bit = chipw / (1023ull * 20ull);
-                const uint64_t navh = splitmix64(st.nav_seed + (bit + 1) * GOLDEN);
-                const int nav = 1 - 2 * (int)(navh & 1);
+                int nav;
+                if (a.nav_mode) {
+                    const unsigned tb = (unsigned)(bit & 2047);
+                    nav = 2 * (int)((nav_bits[s * 256 + (tb >> 3)] >> (tb & 7)) & 1) - 1;
+                } else {
+                    const uint64_t navh = splitmix64(st.nav_seed + (bit + 1) * GOLDEN);
+                    nav = 1 - 2 * (int)(navh & 1);
+                }
                 const uint32_t ph = st.car_ph0 + (uint32_t)(idx * (uint64_t)st.car_fcw);
                 const int cv = s_lut[ph >> 24];
                 acc += (st.amp * (int)s_code[s][chip] * nav * cv + 64) >> 7;
@@ -75,13 +86,19 @@ extern "C" int sgx_if_synth(sgx_ctx* c, const sgx_scene* scene, uint64_t offset,
     int rc = sgx_if_alloc_internal(c, n, &r);
     if (rc != SGX_OK) return rc;
     SynthArgs a;
-    a.sc = *scene;
+    a.seed = scene->seed;
+    a.n_sats = scene->n_sats;
+    a.nav_mode = scene->nav_mode;
+    memcpy(a.sats, scene->sats, sizeof(a.sats));
+    memcpy(a.cos_lut, scene->cos_lut, sizeof(a.cos_lut));
+    uint8_t* d_nav = (uint8_t*)c->d_small + 512 * 1024;   // upper half of the context's small device area
+    SGX_HIP(hipMemcpyAsync(d_nav, scene->nav_bits, sizeof(scene->nav_bits), hipMemcpyHostToDevice, c->stream));
     const uint64_t groups = (n + 15) / 16;
     int blocks = (int)((groups + 255) / 256);
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (blocks < 1) blocks = 1;
     hipEventRecord(c->ev[0], c->stream);
-    synth_kernel<<<blocks, 256, 0, c->stream>>>(r->d, offset, (uint64_t)n, c->d_codes, a);
+    synth_kernel<<<blocks, 256, 0, c->stream>>>(r->d, offset, (uint64_t)n, c->d_codes, d_nav, a);
     hipEventRecord(c->ev[1], c->stream);
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipGetLastError();

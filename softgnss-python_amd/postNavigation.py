@@ -1,0 +1,65 @@
+"""NavigationResult with the reference's interface, limited to the stage next to the accelerated path:
+bit synchronisation and preamble search on the tracking output (reference postNavigation.py:443-631).
+
+findPreambles() and navPartyChk() are answered by libsgx.so (sgx_find_preambles, sgx_nav_parity_check).
+Ephemeris decoding, pseudoranges and the position solution (postNavigate, calculatePseudoranges, plot) stay
+in the reference: they are scalar, millisecond-rate code outside this engine's scope.
+"""
+from __future__ import print_function
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native, engine
+from .initialize import Result
+
+
+class NavigationResult(Result):
+    def __init__(self, trackResult, device=None):
+        self._results = trackResult.results
+        self._channels = trackResult.channels
+        self._settings = trackResult.settings
+        self._solutions = None
+        self._eph = None
+        self._device = device
+
+    @staticmethod
+    def navPartyChk(ndat):
+        """Parity status of a GPS word (+1 / -1 passed, 0 failed); ndat = 32 values of +-1 (D29*, D30*, d1..d24,
+        D25..D30), d1..d24 flipped in place when D30* != 1 (reference postNavigation.py:443-521)."""
+        buf = np.ascontiguousarray(ndat, dtype=np.float64)
+        st = C.c_int32(0)
+        _native.check(_native.lib().sgx_nav_parity_check(buf.ctypes.data_as(C.c_void_p), C.byref(st)))
+        ndat[...] = buf          # the reference mutates its argument
+        return st.value
+
+    def findPreambles(self):
+        """(firstSubFrame, activeChnList) as in reference postNavigation.py:524-631."""
+        assert isinstance(self._results, np.recarray)
+        trackResults = self._results
+        settings = self._settings
+        firstSubFrame = np.zeros(settings.numberOfChannels, dtype=int)
+        activeChnList = (trackResults.status != b'-').nonzero()[0] if trackResults.status.dtype.kind == "S" \
+            else (trackResults.status != '-').nonzero()[0]
+        n_act = len(activeChnList)
+        if n_act:
+            # quirk kept: row channelNr of the results serves the channelNr-th active channel
+            i_p = np.stack([np.asarray(trackResults[k].I_P, dtype=np.float64) for k in range(n_act)])
+            ctx = engine.get_context(settings, self._device)
+            firstSubFrame[:n_act] = ctx.find_preambles(i_p, 0)
+        for channelNr in range(n_act):
+            if firstSubFrame[channelNr] == 0:
+                activeChnList = np.setdiff1d(activeChnList, channelNr)
+                print('Could not find valid preambles in channel %2d !' % channelNr)
+        return firstSubFrame, activeChnList
+
+    def postNavigate(self):
+        raise NotImplementedError("ephemeris decoding and the position solution stay in the reference "
+                                  "(postNavigation.py:75-305): scalar code outside this engine's scope")
+
+    def calculatePseudoranges(self, msOfTheSignal, channelList):
+        raise NotImplementedError("outside this engine's scope (reference postNavigation.py:27-72)")
+
+    def plot(self):
+        raise NotImplementedError("plotting is outside the accelerated path (reference postNavigation.py:307-439)")

@@ -12,12 +12,15 @@ sample(n) = clip( noise(n) + sum_sat round(A * ca[chip(n)] * nav(n) * cosLUT[pha
   phase32(n) : 32-bit carrier NCO, (ph0 + n * car_fcw) mod 2^32
   chip(n)    : 32.32 fixed-point code NCO, ((n * code_fcw + code_c0) >> 32) mod 1023
   nav(n)     : +-1 from splitmix64(nav_seed + (bit+1)*GOLDEN) & 1, one bit per 20 code periods
+               (hash mode), or 2*table[bit mod 2048]-1 (structured mode: 300-bit subframes with the TLM
+               preamble and IS-GPS-200 parity, so that the reference's findPreambles has something to find)
 """
 import numpy as np
 
 GOLDEN = 0x9E3779B97F4A7C15
 MASK64 = (1 << 64) - 1
 MAX_SATS = 16
+NAV_TABLE_BITS = 2048     # per-satellite navigation bit table (structured mode), repeats after 40.96 s
 NOISE_MUL = 35
 NOISE_SHIFT = 8
 L1_HZ = 1575.42e6
@@ -61,10 +64,50 @@ def ca_code_bits(prn0):
     return (1 - 2 * (g1 ^ g2 ^ 1)).astype(np.int8)
 
 
+def gps_parity(d, d29s, d30s):
+    """IS-GPS-200 Table 20-XIV: 30 transmitted bits of a word from its 24 data bits d[0..23] and the last two
+    transmitted bits of the previous word."""
+    D = [b ^ d30s for b in d]
+
+    def x(*idx):
+        v = 0
+        for i in idx:
+            v ^= d[i - 1]
+        return v
+
+    D.append(d29s ^ x(1, 2, 3, 5, 6, 10, 11, 12, 13, 14, 17, 18, 20, 23))
+    D.append(d30s ^ x(2, 3, 4, 6, 7, 11, 12, 13, 14, 15, 18, 19, 21, 24))
+    D.append(d29s ^ x(1, 3, 4, 5, 7, 8, 12, 13, 14, 15, 16, 19, 20, 22))
+    D.append(d30s ^ x(2, 4, 5, 6, 8, 9, 13, 14, 15, 16, 17, 20, 21, 23))
+    D.append(d30s ^ x(1, 3, 5, 6, 7, 9, 10, 14, 15, 16, 17, 18, 21, 22, 24))
+    D.append(d29s ^ x(3, 5, 6, 8, 9, 10, 11, 13, 15, 19, 22, 23, 24))
+    return D
+
+
+def subframe_bits(seed, first_boundary=100, n_bits=NAV_TABLE_BITS):
+    """Bit table whose subframes (10 words x 30 bits, word 1 starting with the preamble 10001011) start at
+    table positions first_boundary + 300 k; every word carries valid parity."""
+    import random
+    rng = random.Random(int(seed))
+    out = []
+    d29s = d30s = 0
+    n_sub = (n_bits + 300) // 300 + 2
+    for _ in range(n_sub):
+        for wno in range(10):
+            d = [rng.randint(0, 1) for _ in range(24)]
+            if wno == 0:
+                d[:8] = [1, 0, 0, 0, 1, 0, 1, 1]
+            w = gps_parity(d, d29s, d30s)
+            d29s, d30s = w[28], w[29]
+            out.extend(w)
+    skip = 300 - (first_boundary % 300)     # table bit 0 is `skip` bits into a subframe
+    return np.array(out[skip:skip + n_bits], dtype=np.uint8)
+
+
 class Scene(object):
     """Integer description of a synthetic record. All fields are plain Python ints."""
 
-    def __init__(self, seed, sats, fs, cos_lut=None):
+    def __init__(self, seed, sats, fs, cos_lut=None, nav_bits=None):
         self.seed = int(seed) & MASK64
         self.fs = float(fs)
         self.sats = sats  # list of dicts: prn, amp, car_fcw, car_ph0, code_fcw, code_c0, nav_seed
@@ -73,6 +116,13 @@ class Scene(object):
             cos_lut = np.round(127.0 * np.cos(2.0 * np.pi * (k + 0.5) / 256.0)).astype(np.int16)
         self.cos_lut = np.asarray(cos_lut, dtype=np.int16)
         assert len(self.sats) <= MAX_SATS
+        # structured navigation data: uint8[n_sats, NAV_TABLE_BITS] of 0/1, or None for hash bits
+        self.nav_bits = None if nav_bits is None else np.asarray(nav_bits, dtype=np.uint8).reshape(len(sats), NAV_TABLE_BITS)
+
+    def with_subframes(self, first_boundary=100):
+        """Same scene with structured navigation data (subframes + parity) instead of hash bits."""
+        tab = np.stack([subframe_bits(self.seed * 131 + s["prn"], first_boundary) for s in self.sats])
+        return Scene(self.seed, self.sats, self.fs, self.cos_lut, tab)
 
     @staticmethod
     def make(seed, fs, IF, prns, dopplers, code_starts, amps, fc=1.023e6):
@@ -116,13 +166,16 @@ def generate(scene, n, offset=0, chunk=1 << 21):
             s4 = ((h & np.uint64(0xFF)) + ((h >> np.uint64(8)) & np.uint64(0xFF)) +
                   ((h >> np.uint64(16)) & np.uint64(0xFF)) + ((h >> np.uint64(24)) & np.uint64(0xFF)))
             acc = ((s4.astype(np.int64) - 510) * NOISE_MUL) >> NOISE_SHIFT
-            for s in scene.sats:
+            for si, s in enumerate(scene.sats):
                 cp = idx * np.uint64(s["code_fcw"]) + np.uint64(s["code_c0"])
                 chipw = cp >> np.uint64(32)
                 chip = (chipw % np.uint64(1023)).astype(np.int64)
                 bit = chipw // np.uint64(1023 * 20)
-                navh = splitmix64(np.uint64(s["nav_seed"]) + (bit + np.uint64(1)) * g)
-                nav = 1 - 2 * (navh & np.uint64(1)).astype(np.int64)
+                if scene.nav_bits is not None:
+                    nav = 2 * scene.nav_bits[si][(bit % np.uint64(NAV_TABLE_BITS)).astype(np.int64)].astype(np.int64) - 1
+                else:
+                    navh = splitmix64(np.uint64(s["nav_seed"]) + (bit + np.uint64(1)) * g)
+                    nav = 1 - 2 * (navh & np.uint64(1)).astype(np.int64)
                 ph = (np.uint64(s["car_ph0"]) + idx * np.uint64(s["car_fcw"])) & np.uint64(0xFFFFFFFF)
                 c = lut[(ph >> np.uint64(24)).astype(np.int64)]
                 acc += (s["amp"] * codes[s["prn"]][chip] * nav * c + 64) >> 7

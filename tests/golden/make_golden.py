@@ -30,10 +30,18 @@ synth = importlib.import_module("softgnss-python_amd.synth")
 
 def load_reference():
     tmp = tempfile.mkdtemp(prefix="refpy3_")
-    for f in ("initialize.py", "acquisition.py", "tracking.py"):
+    for f in ("initialize.py", "acquisition.py", "tracking.py", "postNavigation.py", "ephemeris.py"):
         shutil.copy(os.path.join(REF, f), tmp)
+    shutil.copytree(os.path.join(REF, "geoFunctions"), os.path.join(tmp, "geoFunctions"))
     subprocess.run([sys.executable, "-m", "lib2to3", "-w", "-n", tmp], check=True,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    # Python-2 integer division that lib2to3 leaves alone (postNavigation.py:581): "/" of two ints was floor
+    # division; the throw-away copy gets "//" there, nothing else is edited
+    pn = os.path.join(tmp, "postNavigation.py")
+    src = open(pn).read()
+    assert "xcorrLength = (len(tlmXcorrResult) + 1) / 2" in src
+    open(pn, "w").write(src.replace("xcorrLength = (len(tlmXcorrResult) + 1) / 2",
+                                    "xcorrLength = (len(tlmXcorrResult) + 1) // 2"))
     np.int = int
     np.long = int
     np.Inf = np.inf
@@ -234,6 +242,38 @@ def main():
                             ch_acquiredFreq=acq2.channels.acquiredFreq, ch_codePhase=acq2.channels.codePhase,
                             series=series2, PRN=np.array([int(x.PRN) for x in rb]))
         print("rate2.npz", n2, np.flatnonzero(det2) + 1, series2.shape)
+
+        # ---- 10: bit sync / preamble search (postNavigation.findPreambles) on structured navigation data ----
+        if os.environ.get("SGX_GOLDEN_NAV", "1") == "1":
+            with Quiet():
+                import postNavigation
+            s3 = initialize.Settings()
+            s3.samplingFreq = 16367600.0
+            s3.IF = 4130400.0
+            s3.msToProcess = 10000.0
+            s3.numberOfChannels = 2
+            s3.acqSatelliteList = range(1, 13)
+            n3 = s3.samplesPerCode
+            sc3 = synth.Scene.make(0x4E415601, s3.samplingFreq, s3.IF, [4, 10], [1500, -2600], [3000, 11111],
+                                   [8, 7]).with_subframes(100)
+            rec3 = synth.generate(sc3, synth.record_length(n3, 10000))
+            acq3 = acquisition.AcquisitionResult(s3)
+            with Quiet():
+                acq3.acquire(rec3[:11 * n3])
+                acq3.preRun()
+            trk3 = tracking.TrackingResult(acq3)
+            fid3 = as_file(tmp, "rec3.bin", rec3)
+            with Quiet():
+                trk3.track(fid3)
+                nav = postNavigation.NavigationResult(trk3)
+                first, active = nav.findPreambles()
+            ip = np.stack([np.asarray(trk3.results[i].I_P, dtype=np.float64) for i in range(len(trk3.results))])
+            np.savez_compressed(os.path.join(HERE, "nav_preambles.npz"), scene=scene_json(sc3), subframes_at=np.int64(100),
+                                n_samples=np.int64(len(rec3)), ms=np.int64(10000), I_P=ip,
+                                ch_PRN=acq3.channels.PRN, ch_acquiredFreq=acq3.channels.acquiredFreq,
+                                ch_codePhase=acq3.channels.codePhase,
+                                firstSubFrame=np.asarray(first), activeChnList=np.asarray(active))
+            print("nav_preambles.npz", first, active)
 
         trk2 = tracking.TrackingResult(acq_t)
         short = as_file(tmp, "short.bin", rec[:100 * n])

@@ -382,3 +382,87 @@ def test_streaming_file_ingest_matches_file_bytes():
             rec.free()
     with pytest.raises(m._native.SgxError):
         ctx.upload_file("/nonexistent/record.bin", 0, 10)
+
+
+# ---- next row: bit sync + preamble search on the tracking output -------------------
+
+def _nav_settings(m, nch=2):
+    s = m.Settings()
+    s.samplingFreq = 16367600.0
+    s.IF = 4130400.0
+    s.msToProcess = 10000.0
+    s.numberOfChannels = nch
+    return s
+
+
+def _nav_scene(m, g):
+    return scene_from_json(g["scene"]).with_subframes(int(g["subframes_at"]))
+
+
+def test_device_generator_matches_host_generator_with_subframes():
+    g = load_golden("nav_preambles.npz")
+    m, s, ctx = _ctx()
+    sc = _nav_scene(m, g)
+    for off, n in ((0, 70001), (16368 * 20 * 2047 + 11, 16368 * 45), (16368 * 1999 - 300, 50000)):
+        rec = ctx.synth(sc, n, offset=off)
+        assert np.array_equal(rec.download(), m.synth.generate(sc, n, offset=off))
+        rec.free()
+
+
+def test_find_preambles_on_reference_series():
+    """Product vs the reference's own findPreambles result on the reference tracker's I_P (committed fixture),
+    plus oracle agreement on perturbed copies (sign-scrambled channel, heavy noise, shifted search start)."""
+    g = load_golden("nav_preambles.npz")
+    m, s0, ctx = _ctx()
+    got = ctx.find_preambles(g["I_P"])
+    assert np.array_equal(got, g["firstSubFrame"])
+    rng = np.random.default_rng(11)
+    scr = g["I_P"][1] * rng.choice([-1.0, 1.0], size=g["I_P"].shape[1])
+    noisy = g["I_P"][0] + rng.normal(0.0, 1.5 * np.std(g["I_P"][0]), size=g["I_P"].shape[1])
+    x = np.stack([g["I_P"][0], scr, noisy, -g["I_P"][1], g["I_P"][0][:]])
+    want, _ = orc.find_preambles(x, ['T'] * 5, 5)
+    assert np.array_equal(ctx.find_preambles(x), want)
+    assert want[0] == 1999 and want[1] == 0 and want[3] == 1999
+    for start in (0, 1999, 2000, 2400):
+        w2, _ = orc.find_preambles(x[:1], ['T'], 1, search_start=start)
+        assert np.array_equal(ctx.find_preambles(x[:1], start), w2)
+    # records cut short around a candidate: whatever the reference's numpy code does (result or exception type)
+    full = g["I_P"][:1]
+    for lo, hi in ((1979, 10000), (1960, 10000), (1959, 10000), (0, 9150), (2000, 9250), (2000, 9199),
+                   (2000, 9200), (2000, 9210), (7000, 10000), (1990, 8630), (1990, 8640)):
+        cut = full[:, lo:hi]
+        try:
+            want = orc.find_preambles(cut, ['T'], 1)[0]
+        except (ValueError, IndexError) as e:
+            with pytest.raises(type(e)):
+                ctx.find_preambles(cut)
+        else:
+            assert np.array_equal(ctx.find_preambles(cut), want), (lo, hi)
+
+
+def test_navigation_result_end_to_end_from_gpu_tracking():
+    """acquire -> preRun -> track -> findPreambles, all through the product, on the structured-navigation scene
+    the fixture was made from: same subframe start as the reference found on its own tracker's output."""
+    g = load_golden("nav_preambles.npz")
+    m = pkg()
+    s = _nav_settings(m)
+    ctx = m.engine.get_context(s, 0)
+    sc = _nav_scene(m, g)
+    rec = ctx.synth(sc, int(g["n_samples"]))
+    a = m.AcquisitionResult(s, device=0)
+    a._channels = np.rec.fromarrays([g["ch_PRN"], g["ch_acquiredFreq"], g["ch_codePhase"], ['T', 'T']],
+                                    names='PRN,acquiredFreq,codePhase,status')
+    t = m.TrackingResult(a, device=0)
+    t.track(m.DeviceFile(rec))
+    rec.free()
+    ip = np.stack([np.asarray(t.results[k].I_P, dtype=np.float64) for k in range(2)])
+    scale = np.sqrt(np.mean(g["I_P"] ** 2))
+    assert np.max(np.abs(ip - g["I_P"])) / scale < TRK_TOL
+    nav = m.NavigationResult(t, device=0)
+    first, active = nav.findPreambles()
+    assert np.array_equal(first, g["firstSubFrame"]) and np.array_equal(active, g["activeChnList"])
+    # an inactive channel is skipped, and the reference's row-index quirk is kept (row 0 serves the only active one)
+    t.results[0].status = b'-'
+    first2, active2 = nav.findPreambles()
+    w2, a2 = orc.find_preambles(ip, ['-', 'T'], 2)
+    assert np.array_equal(first2, w2) and np.array_equal(active2, a2)

@@ -134,3 +134,29 @@ def test_second_front_end_matches_reference():
     assert np.array_equal(ch["PRN"], g["ch_PRN"]) and np.array_equal(ch["codePhase"], g["ch_codePhase"])
     out = orc.track(s, ch, rec)
     assert np.array_equal(orc.stack_series(out), g["series"])
+
+
+def test_find_preambles_matches_reference():
+    """postNavigation.findPreambles / navPartyChk restated; golden = the reference's own result on the I_P
+    series of its own tracker (structured navigation data, subframes every 6000 ms)."""
+    g = load_golden("nav_preambles.npz")
+    first, active = orc.find_preambles(g["I_P"], ['T', 'T'], 2)
+    assert np.array_equal(first, g["firstSubFrame"]) and list(first) == [1999, 1999]
+    assert np.array_equal(active, g["activeChnList"])
+    # a channel without preambles (scrambled signs) drops out of the active list
+    rng = np.random.default_rng(3)
+    noise = g["I_P"][1] * rng.choice([-1.0, 1.0], size=g["I_P"].shape[1])
+    first2, active2 = orc.find_preambles(np.stack([g["I_P"][0], noise]), ['T', 'T'], 2)
+    assert first2[0] == 1999 and first2[1] == 0 and list(active2) == [0]
+
+
+def test_nav_parity_check_on_generated_words():
+    synth = pkg("synth")
+    bits = synth.subframe_bits(77, first_boundary=0, n_bits=900).astype(np.float64) * 2 - 1
+    for w in range(1, 29):
+        ndat = bits[30 * w - 2:30 * w + 30].copy()
+        st = orc.nav_party_chk(ndat)
+        assert st in (1, -1) and st == -ndat[1]
+        bad = bits[30 * w - 2:30 * w + 30].copy()
+        bad[7] *= -1
+        assert orc.nav_party_chk(bad) == 0
