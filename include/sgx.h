@@ -180,6 +180,12 @@ int sgx_find_preambles(sgx_ctx* c, const double* I_P, int32_t n_ch, int32_t ms, 
  * flips d1..d24 in place when D30* != 1 like the reference; status +1 / -1 (parity ok) or 0. */
 int sgx_nav_parity_check(double* ndat32, int32_t* status);
 
+/* The bit integration at the head of postNavigate (postNavigation.py:125-138): I_P[start-20 : start+30000] of one
+ * channel summed in 20-ms columns (numpy's summation order), bit = sum > 0.  bits must hold 1501 entries;
+ * *n_bits = 1501 for a full slice, fewer where Python's slice is clipped; SGX_E_RANGE ("ValueError") when the
+ * clipped slice is not a multiple of 20 ms.  Host code: 30 020 additions per channel. */
+int sgx_nav_bits(const double* I_P_row, int32_t ms, int32_t subFrameStart, uint8_t* bits, int32_t* n_bits);
+
 /* ---- RCCL peak gather (multi-GPU acquisition shard) ------------------
  * One process per GPU.  Rank 0 calls sgx_comm_unique_id and ships the 128 bytes to the other
  * ranks by any host channel; every rank then calls sgx_comm_create.  sgx_comm_allgather

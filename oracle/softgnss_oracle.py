@@ -387,3 +387,10 @@ def find_preambles(i_p_rows, statuses, n_channels, search_start=0):
         if first[ch] == 0:
             active = np.setdiff1d(active, ch)
     return first, active
+
+
+def nav_bits(i_p, sub_frame_start):
+    """postNavigation.py:125-138: the navBits array (0/1 ints) of one channel, same numpy calls as the reference."""
+    samples = np.asarray(i_p, dtype=np.float64)[sub_frame_start - 20: sub_frame_start + 1500 * 20].copy()
+    samples = samples.reshape(20, -1, order='F')
+    return (samples.sum(0) > 0) * 1

@@ -82,6 +82,7 @@ _PROTOS = {
     "sgx_track": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, C.c_int32, _P, _P]),
     "sgx_find_preambles": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "sgx_nav_parity_check": (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    "sgx_nav_bits": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.POINTER(C.c_int32)]),
     "sgx_comm_unique_id": (C.c_int, [_P]),
     "sgx_comm_create": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.POINTER(_P)]),
     "sgx_comm_allgather": (C.c_int, [_P, _P, _P, C.c_size_t]),
@@ -198,6 +199,18 @@ def device_count():
 
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def nav_bits(i_p_row, sub_frame_start):
+    """uint8 bits (1 = positive 20-ms sum) of I_P[start-20 : start+30000], reference postNavigation.py:125-138."""
+    a = np.ascontiguousarray(i_p_row, dtype=np.float64)
+    out = np.zeros(1501, dtype=np.uint8)
+    nb = C.c_int32(0)
+    rc = lib().sgx_nav_bits(_ptr(a), a.shape[0], int(sub_frame_start), _ptr(out), C.byref(nb))
+    if rc == SGX_E_RANGE:
+        raise ValueError(last_error())
+    check(rc)
+    return out[:nb.value]
 
 
 class Context(object):

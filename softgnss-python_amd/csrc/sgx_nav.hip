@@ -37,6 +37,16 @@ __global__ __launch_bounds__(256) void nav_corr_kernel(const double* __restrict_
     corr[(long long)ch * ms + start + t] = (short)acc;
 }
 
+// numpy's reduction order for reshape(20, -1, order='F').sum(0): the 20 contiguous values of a column go through
+// the unrolled pairwise sum (8 accumulators over two rounds, tree combine, then the last 4 in sequence)
+static inline double sum20(const double* a) {
+    double r[8];
+    for (int j = 0; j < 8; ++j) r[j] = a[j] + a[j + 8];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (int i = 16; i < 20; ++i) res += a[i];
+    return res;
+}
+
 // postNavigation.py:443-521 on +-1 values; flips d1..d24 in place like the reference
 static int parity_status(double* ndat) {
     if (ndat[1] != 1)
@@ -59,6 +69,25 @@ static int parity_status(double* ndat) {
 extern "C" int sgx_nav_parity_check(double* ndat32, int32_t* status) {
     SGX_CHECK_ARG(ndat32 && status);
     *status = parity_status(ndat32);
+    return SGX_OK;
+}
+
+// postNavigation.py:125-138: 20-ms sums from one bit before the subframe start, 1500 bits after it
+extern "C" int sgx_nav_bits(const double* I_P_row, int32_t ms, int32_t subFrameStart, uint8_t* bits,
+                            int32_t* n_bits) {
+    SGX_CHECK_ARG(I_P_row && bits && n_bits && ms >= 1 && subFrameStart >= 0);
+    const int lo = subFrameStart - 20, hi = subFrameStart + 1500 * 20;
+    const int a0 = lo < 0 ? (ms + lo > 0 ? ms + lo : 0) : (lo < ms ? lo : ms);
+    const int a1 = hi < ms ? hi : ms;
+    const int len = a1 > a0 ? a1 - a0 : 0;
+    if (len % 20 != 0) {
+        sgx_set_error("ValueError: cannot reshape array of size %d into shape (20,newaxis) "
+                      "(subframe start %d of a %d ms record, reference postNavigation.py:128-131)",
+                      len, subFrameStart, ms);
+        return SGX_E_RANGE;
+    }
+    *n_bits = len / 20;
+    for (int w = 0; w < len / 20; ++w) bits[w] = sum20(I_P_row + a0 + 20 * w) > 0 ? 1 : 0;
     return SGX_OK;
 }
 
@@ -121,9 +150,7 @@ extern "C" int sgx_find_preambles(sgx_ctx* c, const double* I_P, int32_t n_ch, i
             }
             double bits[62];
             for (int w = 0; w < 62 && w < words; ++w) {
-                double sum = 0.0;
-                for (int k = 0; k < 20; ++k) sum += ip[a0 + 20 * w + k];   // reshape(20,-1,'F').sum(0)
-                bits[w] = sum > 0 ? 1.0 : -1.0;
+                bits[w] = sum20(ip + a0 + 20 * w) > 0 ? 1.0 : -1.0;   // reshape(20,-1,'F').sum(0)
             }
             double w1[32], w2[32];
             memcpy(w1, bits, sizeof(w1));

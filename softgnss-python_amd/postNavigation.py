@@ -54,6 +54,16 @@ class NavigationResult(Result):
                 print('Could not find valid preambles in channel %2d !' % channelNr)
         return firstSubFrame, activeChnList
 
+    def navBits(self, subFrameStart, activeChnList):
+        """{channelNr: list of '0'/'1'} - the navBitsBin the reference hands to ephemeris.ephemeris() as
+        (navBitsBin[1:], navBitsBin[0]) for every active channel (reference postNavigation.py:125-138)."""
+        out = {}
+        for channelNr in activeChnList:
+            bits = _native.nav_bits(np.asarray(self._results[channelNr].I_P, dtype=np.float64),
+                                    int(subFrameStart[channelNr]))
+            out[int(channelNr)] = [str(int(b)) for b in bits]
+        return out
+
     def postNavigate(self):
         raise NotImplementedError("ephemeris decoding and the position solution stay in the reference "
                                   "(postNavigation.py:75-305): scalar code outside this engine's scope")

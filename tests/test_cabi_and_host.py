@@ -230,3 +230,22 @@ def test_navigation_result_surface():
     finally:
         sys.path.pop(0)
         sys.modules.pop("postNavigation", None)
+
+
+def test_nav_bits_matches_oracle_including_summation_order():
+    """sgx_nav_bits (host code) vs the oracle: numpy's pairwise order decides the sign of near-cancelling sums."""
+    import oracle.softgnss_oracle as orc
+    native = pkg("_native")
+    rng = np.random.default_rng(8)
+    x = rng.normal(size=33000) * 10.0 ** rng.integers(-8, 8, size=33000)
+    # columns that cancel to rounding noise: the sign then depends on the order of the additions
+    for c in range(0, 32000, 40):
+        x[c + 10:c + 20] = -x[c:c + 10]
+    for start in (20, 37, 1999, 2980):
+        assert np.array_equal(native.nav_bits(x, start), orc.nav_bits(x, start))
+    assert len(native.nav_bits(x, 1999)) == 1501
+    assert np.array_equal(native.nav_bits(x[:12000], 1980), orc.nav_bits(x[:12000], 1980))   # clipped, 20 | len
+    with pytest.raises(ValueError):
+        orc.nav_bits(x[:12000], 1999)
+    with pytest.raises(ValueError):
+        native.nav_bits(x[:12000], 1999)

@@ -466,3 +466,33 @@ def test_navigation_result_end_to_end_from_gpu_tracking():
     first2, active2 = nav.findPreambles()
     w2, a2 = orc.find_preambles(ip, ['-', 'T'], 2)
     assert np.array_equal(first2, w2) and np.array_equal(active2, a2)
+
+
+def test_nav_bits_recover_the_transmitted_subframes():
+    """32.1 s of the structured scene: track, find the subframe start, integrate the bits (sgx_nav_bits) and
+    compare with the oracle on the same I_P and with the bit table the generator transmitted."""
+    g = load_golden("nav_preambles.npz")
+    m = pkg()
+    s = _nav_settings(m)
+    s.msToProcess = 32100.0
+    ctx = m.engine.get_context(s, 0)
+    sc = _nav_scene(m, g)
+    rec = ctx.synth(sc, m.synth.record_length(s.samplesPerCode, 32100))
+    a = m.AcquisitionResult(s, device=0)
+    a._channels = np.rec.fromarrays([g["ch_PRN"], g["ch_acquiredFreq"], g["ch_codePhase"], ['T', 'T']],
+                                    names='PRN,acquiredFreq,codePhase,status')
+    t = m.TrackingResult(a, device=0)
+    t.track(m.DeviceFile(rec))
+    rec.free()
+    nav = m.NavigationResult(t, device=0)
+    first, active = nav.findPreambles()
+    assert list(first) == [1999, 1999] and list(active) == [0, 1]
+    bits = nav.navBits(first, active)
+    at = int(g["subframes_at"])
+    for ch in (0, 1):
+        ip = np.asarray(t.results[ch].I_P, dtype=np.float64)
+        want = orc.nav_bits(ip, int(first[ch]))
+        got = np.array([int(b) for b in bits[ch]])
+        assert len(got) == 1501 and np.array_equal(got, want)
+        sent = sc.nav_bits[ch][(at - 1 + np.arange(1501)) % m.synth.NAV_TABLE_BITS]
+        assert np.array_equal(got, sent) or np.array_equal(got, 1 - sent)   # Costas loop: sign ambiguity
