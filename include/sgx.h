@@ -167,6 +167,17 @@ int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset,
               const sgx_chan_init* ch, int32_t n_ch, int32_t ms,
               double* out, int32_t* ms_done);
 
+/* ---- next row: raw-data statistics of Settings.probeData (initialize.py:330-417) ------------------------------
+ * Window [offset, offset+n) of a resident record (the reference reads 10 * samplesPerCode samples,
+ * initialize.py:369-371).  f[8193] (MHz) and pxx[8193] = welch(data - mean(data), fs_mhz, hamming(16384, False),
+ * 16384, 1024, 16384) (initialize.py:389-394); hist[255] = np.histogram(data, arange(-128, 128))[0]
+ * (initialize.py:400, last bin closed); *n_segments = Welch segments averaged.  SGX_E_RANGE ("ValueError") for
+ * fewer than 16384 samples. */
+#define SGX_PROBE_BINS 8193
+#define SGX_PROBE_HIST 255
+int sgx_probe_stats(sgx_ctx* c, const sgx_if* rec, size_t offset, size_t n, double fs_mhz, double* f, double* pxx,
+                    int64_t* hist, int32_t* n_segments);
+
 /* ---- next row: bit sync + preamble search on the tracking output (postNavigation.py:443-631) ----------------
  * NavigationResult.findPreambles: I_P is [n_ch][ms] float64 (row i = i-th record of the tracking results);
  * firstSubFrame[ch] = ms index of the first verified TLM preamble, 0 = none (then the reference drops the

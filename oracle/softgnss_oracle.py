@@ -394,3 +394,35 @@ def nav_bits(i_p, sub_frame_start):
     samples = np.asarray(i_p, dtype=np.float64)[sub_frame_start - 20: sub_frame_start + 1500 * 20].copy()
     samples = samples.reshape(20, -1, order='F')
     return (samples.sum(0) > 0) * 1
+
+
+# ---- next row: probeData statistics (reference initialize.py:330-417) -------------------------------------------
+PROBE_NPERSEG = 16384
+PROBE_NOVERLAP = 1024
+
+
+def probe_stats(s, data):
+    """The numbers Settings.probeData() plots for `data` = the first 10 code periods (int8):
+    (f [MHz], Pxx) = welch(data - mean(data), fs/1e6, hamming(16384, sym=False), 16384, 1024, 16384) restated
+    step by step (scipy 1.15 legacy `_spectral_helper`: constant detrend per segment, window, rfft, density
+    scaling, one-sided doubling, mean over segments), and hist = np.histogram(data, arange(-128, 128))[0]
+    (initialize.py:389-400).  numpy's rfft and scipy's window are called, not restated."""
+    data = np.asarray(data)
+    fs = s.samplingFreq / 1000000.0
+    x = data - np.mean(data)
+    nseg_len, nov = PROBE_NPERSEG, PROBE_NOVERLAP
+    from scipy.signal.windows import hamming                         # third-party, called like the reference does
+    win = hamming(nseg_len, False)                                   # 0.54 - 0.46 cos(2 pi k / 16384)
+    step = nseg_len - nov
+    nseg = (x.shape[-1] - nov) // step
+    seg = np.stack([x[i * step:i * step + nseg_len] for i in range(nseg)])
+    seg = seg - np.mean(seg, axis=-1, keepdims=True)                # detrend='constant'
+    seg = win * seg
+    spec = np.fft.rfft(seg, n=nseg_len)
+    pxx = (np.conjugate(spec) * spec).real
+    pxx *= 1.0 / (fs * (win * win).sum())                            # scaling='density'
+    pxx[..., 1:-1] *= 2                                              # one-sided, even nfft
+    pxx = pxx.T.mean(axis=-1)                                        # average='mean' over the segments
+    f = np.fft.rfftfreq(nseg_len, 1 / fs)
+    hist = np.histogram(data, np.arange(-128, 128))[0]
+    return f, pxx, hist

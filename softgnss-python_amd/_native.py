@@ -80,6 +80,7 @@ _PROTOS = {
     "sgx_acquire": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, C.c_int32, C.c_int32, C.c_int32,
                               _P, _P, _P, _P, _P]),
     "sgx_track": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, C.c_int32, _P, _P]),
+    "sgx_probe_stats": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, C.c_double, _P, _P, _P, C.POINTER(C.c_int32)]),
     "sgx_find_preambles": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "sgx_nav_parity_check": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "sgx_nav_bits": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.POINTER(C.c_int32)]),
@@ -275,6 +276,19 @@ class Context(object):
         check(lib().sgx_acquire(self._h, rec._h, int(offset), int(n_samples), _ptr(prn), n, int(n_blocks),
                                 1 if noncoh else 0, _ptr(carr), _ptr(cph), _ptr(met), _ptr(fb), _ptr(fi)))
         return dict(carrFreq=carr, codePhase=cph, peakMetric=met, freqBin=fb, fineIdx=fi)
+
+    def probe_stats(self, rec, offset, n, fs_mhz):
+        """(f, Pxx, hist, n_segments) of the record window: Welch PSD and histogram of Settings.probeData."""
+        f = np.zeros(8193)
+        pxx = np.zeros(8193)
+        hist = np.zeros(255, dtype=np.int64)
+        nseg = C.c_int32(0)
+        rc = lib().sgx_probe_stats(self._h, rec._h, int(offset), int(n), float(fs_mhz), _ptr(f), _ptr(pxx),
+                                   _ptr(hist), C.byref(nseg))
+        if rc == SGX_E_RANGE:
+            raise ValueError(last_error())
+        check(rc)
+        return f, pxx, hist, nseg.value
 
     def find_preambles(self, i_p, search_start=0):
         """i_p: float64[n_ch, ms] -> int array firstSubFrame[n_ch] (0 = no verified preamble)."""

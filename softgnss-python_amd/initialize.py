@@ -119,9 +119,70 @@ class Settings(object):
                                                        C.byref(t2)))
         return t1.value, t2.value
 
-    def probeData(self, fileNameStr=None):
-        raise NotImplementedError("probeData is a plotting diagnostic outside the accelerated path "
-                                  "(reference initialize.py:330-417)")
+    def probeData(self, fileNameStr=None, device=None):
+        """Raw-data information of reference initialize.py:330-417 for the first 10 code periods of the record:
+        time-domain samples, Welch power spectral density (16384-point periodic Hamming window, 1024 overlap) and
+        the histogram.  The numbers come from sgx_probe_stats on the GPU; they are returned as a dict (keys
+        timeScale_ms, timeData, f_MHz, Pxx, hist, hist_edges, segments) and kept in self.probe.  The three
+        panels are drawn like the reference does when matplotlib is installed.  `fileNameStr` may also be a
+        DeviceSignal (a window of a record already resident in HBM)."""
+        from . import engine
+        from .record import DeviceSignal
+        if fileNameStr is None:
+            fileNameStr = self.fileName
+        samplesPerCode = self.samplesPerCode
+        n_want = 10 * samplesPerCode
+        ctx = engine.get_context(self, device)
+        if isinstance(fileNameStr, DeviceSignal):
+            sig = fileNameStr
+            n = min(n_want, sig.length)
+            head = sig.record.download(sig.offset + 1, max(0, min(samplesPerCode // 50, n) - 1))
+            f, pxx, hist, nseg = ctx.probe_stats(sig.record, sig.offset, n, self.samplingFreq / 1000000.0)
+        else:
+            if not isinstance(fileNameStr, str):
+                raise TypeError('File name must be a string')
+            try:
+                with open(fileNameStr, 'rb') as fid:
+                    fid.seek(self.skipNumberOfBytes, 0)
+                    data = np.fromfile(fid, self.dataType, n_want)
+            except IOError as e:
+                print('Unable to read file "%s": %s' % (fileNameStr, e))
+                return None
+            rec = ctx.upload(data)
+            try:
+                f, pxx, hist, nseg = ctx.probe_stats(rec, 0, data.size, self.samplingFreq / 1000000.0)
+            finally:
+                rec.free()
+            head = data[1:samplesPerCode // 50]
+        timeScale = np.arange(0, 0.005, 1 / self.samplingFreq)
+        self.probe = dict(timeScale_ms=1000 * timeScale[1:samplesPerCode // 50], timeData=head,
+                          f_MHz=f, Pxx=pxx, hist=hist, hist_edges=np.arange(-128, 128), segments=nseg)
+        try:
+            import matplotlib.pyplot as plt
+        except ImportError:
+            return self.probe
+        plt.figure(100)
+        plt.clf()
+        plt.subplot(2, 2, 1)
+        if head is not None:
+            plt.plot(self.probe["timeScale_ms"], head)
+        plt.grid()
+        plt.title('Time domain plot')
+        plt.xlabel('Time (ms)')
+        plt.ylabel('Amplitude')
+        plt.subplot(2, 2, 2)
+        plt.semilogy(f, pxx)
+        plt.grid()
+        plt.title('Frequency domain plot')
+        plt.xlabel('Frequency (MHz)')
+        plt.ylabel('Magnitude')
+        plt.subplot(2, 1, 2)
+        plt.bar(np.arange(-128, 127), hist, width=1.0, align='edge')
+        plt.grid(True)
+        plt.title('Histogram')
+        plt.xlabel('Bin')
+        plt.ylabel('Number in bin')
+        return self.probe
 
     def postProcessing(self, fileNameStr=None):
         """acquire -> preRun -> track on a record file, the call sequence of reference

@@ -7,7 +7,8 @@ installs the three numpy alias shims it needs (np.int / np.long / np.Inf), feeds
 from this repo's deterministic generator and stores ONLY inputs' parameters and the
 reference's outputs as small .npz fixtures next to this file.
 
-    python tests/golden/make_golden.py            # regenerates every fixture (~3 min)
+    python tests/golden/make_golden.py            # regenerates every fixture (~10 min)
+    SGX_GOLDEN_ONLY=probe python tests/golden/make_golden.py   # only probe_default.npz
 """
 import importlib
 import io
@@ -17,6 +18,7 @@ import shutil
 import subprocess
 import sys
 import tempfile
+import types
 import warnings
 
 import numpy as np
@@ -42,6 +44,11 @@ def load_reference():
     assert "xcorrLength = (len(tlmXcorrResult) + 1) / 2" in src
     open(pn, "w").write(src.replace("xcorrLength = (len(tlmXcorrResult) + 1) / 2",
                                     "xcorrLength = (len(tlmXcorrResult) + 1) // 2"))
+    # same Python-2 floor division in probeData's slice bounds (initialize.py:378-379)
+    ini = os.path.join(tmp, "initialize.py")
+    src = open(ini).read()
+    assert src.count("samplesPerCode / 50") == 2
+    open(ini, "w").write(src.replace("samplesPerCode / 50", "samplesPerCode // 50"))
     np.int = int
     np.long = int
     np.Inf = np.inf
@@ -113,6 +120,60 @@ def traced_acquire(acq, data):
     return fb, fi
 
 
+class PlotRecorder(types.ModuleType):
+    """Stand-in for matplotlib.pyplot (not installed here): records what probeData plots.  hist() bins like
+    matplotlib does, through np.histogram."""
+
+    def __init__(self):
+        super().__init__("matplotlib.pyplot")
+        self.calls = {}
+
+    def plot(self, x, y, *a, **k):
+        self.calls["plot"] = (np.asarray(x), np.asarray(y))
+
+    def semilogy(self, x, y, *a, **k):
+        self.calls["semilogy"] = (np.asarray(x), np.asarray(y))
+
+    def hist(self, x, bins, *a, **k):
+        self.calls["hist"] = np.histogram(x, bins)
+
+    def axis(self, *a, **k):
+        return [0.0, 1.0, 0.0, 1.0]
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return lambda *a, **k: None
+
+
+def golden_probe(tmp, initialize):
+    """11: probeData statistics (initialize.py:330-417): Welch PSD and histogram of the first 10 ms."""
+    import scipy.signal.windows
+    rec = PlotRecorder()
+    mpl = types.ModuleType("matplotlib")
+    mpl.pyplot = rec
+    sys.modules["matplotlib"] = mpl
+    sys.modules["matplotlib.pyplot"] = rec
+    old = types.ModuleType("scipy.signal.windows.windows")     # module path of the scipy the reference was written for
+    old.hamming = scipy.signal.windows.hamming
+    sys.modules["scipy.signal.windows.windows"] = old
+    s = initialize.Settings()
+    n = s.samplesPerCode
+    sc = synth.Scene.default()
+    data = synth.generate(sc, 10 * n + 4096)
+    path = os.path.join(tmp, "probe.bin")
+    data.tofile(path)
+    with Quiet():
+        s.probeData(path)
+    f, pxx = rec.calls["semilogy"]
+    counts, edges = rec.calls["hist"]
+    t_ms, amp = rec.calls["plot"]
+    np.savez_compressed(os.path.join(HERE, "probe_default.npz"), scene=scene_json(sc), n_samples=np.int64(10 * n),
+                        f=f, Pxx=pxx, hist=counts.astype(np.int64), hist_edges=edges.astype(np.int64),
+                        time_ms=t_ms, time_amp=amp.astype(np.int64))
+    print("probe_default.npz", f.shape, pxx.shape, counts.sum())
+
+
 def scene_json(sc):
     return json.dumps(dict(seed=sc.seed, fs=sc.fs, sats=sc.sats))
 
@@ -120,6 +181,10 @@ def scene_json(sc):
 def main():
     tmp, initialize, acquisition, tracking = load_reference()
     try:
+        if os.environ.get("SGX_GOLDEN_ONLY", "") in ("", "probe"):
+            golden_probe(tmp, initialize)
+        if os.environ.get("SGX_GOLDEN_ONLY", "") == "probe":
+            return
         s = initialize.Settings()
         n = s.samplesPerCode
         out = {}

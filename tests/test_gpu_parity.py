@@ -496,3 +496,45 @@ def test_nav_bits_recover_the_transmitted_subframes():
         assert len(got) == 1501 and np.array_equal(got, want)
         sent = sc.nav_bits[ch][(at - 1 + np.arange(1501)) % m.synth.NAV_TABLE_BITS]
         assert np.array_equal(got, sent) or np.array_equal(got, 1 - sent)   # Costas loop: sign ambiguity
+
+
+# ---- next row: probeData statistics ------------------------------------------------
+
+PSD_TOL = 1e-9     # relative, per bin (fp64 FFT with another operation order than pocketfft)
+
+
+def test_probe_statistics_golden():
+    g = load_golden("probe_default.npz")
+    m = pkg()
+    s = m.Settings()
+    data = m.synth.generate(scene_from_json(g["scene"]), int(g["n_samples"]) + 999)
+    with tempfile.NamedTemporaryFile(suffix=".bin") as fh:
+        data.tofile(fh.name)
+        out = s.probeData(fh.name, device=0)
+    assert out is s.probe and out["segments"] == 24
+    assert np.array_equal(out["hist"], g["hist"])
+    assert np.array_equal(out["f_MHz"], g["f"])
+    assert np.max(np.abs(out["Pxx"] - g["Pxx"]) / g["Pxx"]) < PSD_TOL
+    assert np.array_equal(out["timeData"], g["time_amp"]) and np.allclose(out["timeScale_ms"], g["time_ms"], rtol=0, atol=0)
+    # resident record, window at an offset, extreme sample values, another sampling rate
+    ctx = m.engine.get_context(s, 0)
+    rng = np.random.default_rng(21)
+    x = rng.integers(-128, 128, size=500000, dtype=np.int8)
+    x[1000:1200] = -128
+    x[5000:5100] = 127
+    rec = ctx.upload(x)
+    for off, n in ((0, 381920), (12345, 300001), (7, 16384), (99, 16385 + 15359)):
+        f, pxx, hist, nseg = ctx.probe_stats(rec, off, n, 16.3676)
+        s2 = orc.OracleSettings()
+        s2.samplingFreq = 16367600.0
+        fo, po, ho = orc.probe_stats(s2, x[off:off + n])
+        assert nseg == (n - 1024) // 15360
+        assert np.array_equal(hist, ho) and np.array_equal(f, fo)
+        assert np.max(np.abs(pxx - po) / po) < PSD_TOL
+    with pytest.raises(ValueError):
+        ctx.probe_stats(rec, 0, 16383, 38.192)
+    with pytest.raises(ValueError):
+        ctx.probe_stats(rec, 400000, 200000, 38.192)
+    out2 = s.probeData(m.DeviceSignal(rec, 12345, 381920), device=0)
+    assert np.array_equal(out2["timeData"], x[12346:12345 + 38192 // 50])
+    rec.free()

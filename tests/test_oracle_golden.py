@@ -160,3 +160,14 @@ def test_nav_parity_check_on_generated_words():
         bad = bits[30 * w - 2:30 * w + 30].copy()
         bad[7] *= -1
         assert orc.nav_party_chk(bad) == 0
+
+
+def test_probe_statistics_match_reference():
+    """Settings.probeData's Welch PSD and histogram (initialize.py:330-417), captured from the reference itself."""
+    g = load_golden("probe_default.npz")
+    synth = pkg("synth")
+    data = synth.generate(scene_from_json(g["scene"]), int(g["n_samples"]))
+    f, pxx, hist = orc.probe_stats(orc.OracleSettings(), data)
+    assert np.array_equal(f, g["f"]) and np.array_equal(pxx, g["Pxx"]) and np.array_equal(hist, g["hist"])
+    assert hist.sum() == data.size and len(hist) == 255
+    assert np.array_equal(data[1:38192 // 50], g["time_amp"])
