@@ -229,10 +229,11 @@ def main():
             t_ms = ctx.timing()["track_ms"]
             b_many = float(np.sum(ser[:, 0, -1] - np.array([c[2] for c in many]))) + len(many) * args.many_ms * 13 * 8.0
             out["roofline_many_channels"] = {
-                "kernel": "trk_kernel", "bound": "hbm", "channels": len(many), "ms": args.many_ms,
+                "kernel": "trk_kernel_tp", "bound": "hbm", "channels": len(many), "ms": args.many_ms,
                 "achieved": b_many / (t_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": b_many / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": t_ms,
-                "note": "same kernel, split=1: channels x ms code periods of independent work (VALU-bound fp64)"}
+                "note": "throughput-mode kernel (one lane per prompt chip, split=1): channels x ms code periods of "
+                        "independent work; fp64 VALU-bound at >= 4 instructions per sample"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, scene, n_code, args, samples_per_step, args.channels, args.ms)
         print(json.dumps(out))

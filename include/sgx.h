@@ -197,6 +197,14 @@ int sgx_nav_parity_check(double* ndat32, int32_t* status);
  * clipped slice is not a multiple of 20 ms.  Host code: 30 020 additions per channel. */
 int sgx_nav_bits(const double* I_P_row, int32_t ms, int32_t subFrameStart, uint8_t* bits, int32_t* n_bits);
 
+/* NavigationResult.calculatePseudoranges (postNavigation.py:27-72): absoluteSample is [n_rows][ms] (row i = i-th
+ * record of the tracking results), msOfTheSignal[numberOfChannels] the measurement point per channel, channelList
+ * the channels to use; pseudoranges[numberOfChannels] in metres, +inf for channels not listed (NaN everywhere if
+ * the list is empty, as in the reference).  SGX_E_RANGE ("IndexError") for a point outside the series.  Host code. */
+int sgx_pseudoranges(const double* absoluteSample, int32_t n_rows, int32_t ms, const double* msOfTheSignal,
+                     const int32_t* channelList, int32_t n_list, int32_t numberOfChannels, int64_t samplesPerCode,
+                     double startOffset, double c_mps, double* pseudoranges);
+
 /* ---- RCCL peak gather (multi-GPU acquisition shard) ------------------
  * One process per GPU.  Rank 0 calls sgx_comm_unique_id and ships the 128 bytes to the other
  * ranks by any host channel; every rank then calls sgx_comm_create.  sgx_comm_allgather

@@ -42,6 +42,8 @@ class OracleSettings(object):
         self.dllCorrelatorSpacing = 0.5
         self.pllDampingRatio = 0.7
         self.pllNoiseBandwidth = 25.0
+        self.c = 299792458.0          # initialize.py:170 (m/s)
+        self.startOffset = 68.802     # initialize.py:172 (ms)
         for k, v in kw.items():
             setattr(self, k, v)
 
@@ -426,3 +428,15 @@ def probe_stats(s, data):
     f = np.fft.rfftfreq(nseg_len, 1 / fs)
     hist = np.histogram(data, np.arange(-128, 128))[0]
     return f, pxx, hist
+
+
+def calculate_pseudoranges(s, absolute_sample_rows, ms_of_the_signal, channel_list):
+    """postNavigation.py:27-72: relative pseudoranges in metres; absolute_sample_rows[i] = absoluteSample series of
+    the i-th tracking record."""
+    travel = np.inf * np.ones(s.numberOfChannels)
+    n = s.samplesPerCode
+    for ch in channel_list:
+        travel[ch] = absolute_sample_rows[ch][int(ms_of_the_signal[ch])] / n
+    minimum = np.floor(travel.min())
+    travel = travel - minimum + s.startOffset
+    return travel * s.c / 1000

@@ -83,6 +83,8 @@ _PROTOS = {
     "sgx_probe_stats": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, C.c_double, _P, _P, _P, C.POINTER(C.c_int32)]),
     "sgx_find_preambles": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "sgx_nav_parity_check": (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    "sgx_pseudoranges": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int64, C.c_double,
+                                   C.c_double, _P]),
     "sgx_nav_bits": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.POINTER(C.c_int32)]),
     "sgx_comm_unique_id": (C.c_int, [_P]),
     "sgx_comm_create": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.POINTER(_P)]),

@@ -161,6 +161,7 @@ extern "C" int sgx_ctx_destroy(sgx_ctx* c) {
     hipStreamSynchronize(c->stream);
     sgx_fft_plan_destroy(&c->plan_code);
     sgx_fft_plan_destroy(&c->plan_fine);
+    sgx_fft_plan_destroy(&c->plan_probe);
     hipFree(c->d_codes);
     hipFree(c->d_fwd);
     hipFree(c->d_codefd);

@@ -59,6 +59,7 @@ struct sgx_ctx {
     // acquisition scratch (lazily sized)
     FftPlan plan_code;           // length samplesPerCode
     FftPlan plan_fine;           // length 8 * 2^ceil(log2(10 N))
+    FftPlan plan_probe;          // length 16384 (Welch segments of sgx_probe_stats)
     cplx* d_fwd = nullptr;       // [n_blocks][n_bins][N] mixed-signal spectra
     cplx* d_codefd = nullptr;    // [32][N] code spectra
     cplx* d_work[2] = {nullptr, nullptr};   // ping-pong [rows][N]

@@ -91,6 +91,37 @@ extern "C" int sgx_nav_bits(const double* I_P_row, int32_t ms, int32_t subFrameS
     return SGX_OK;
 }
 
+// postNavigation.py:27-72: relative pseudoranges (metres) at one measurement point per channel
+extern "C" int sgx_pseudoranges(const double* absoluteSample, int32_t n_rows, int32_t ms, const double* msOfTheSignal,
+                                const int32_t* channelList, int32_t n_list, int32_t numberOfChannels,
+                                int64_t samplesPerCode, double startOffset, double c_mps, double* pseudoranges) {
+    SGX_CHECK_ARG(absoluteSample && msOfTheSignal && pseudoranges && (channelList || n_list == 0));
+    SGX_CHECK_ARG(n_rows >= 0 && ms >= 1 && n_list >= 0 && numberOfChannels >= 1 && samplesPerCode >= 1);
+    for (int i = 0; i < numberOfChannels; ++i) pseudoranges[i] = INFINITY;   // travelTime = Inf * ones(...)
+    for (int k = 0; k < n_list; ++k) {
+        const int ch = channelList[k];
+        long long idx = (long long)msOfTheSignal[ch >= 0 && ch < numberOfChannels ? ch : 0];   // np.int(): truncation
+        if (ch < 0 || ch >= numberOfChannels || ch >= n_rows) {
+            sgx_set_error("IndexError: channel %d outside the %d tracked / %d configured channels", ch, n_rows,
+                          numberOfChannels);
+            return SGX_E_RANGE;
+        }
+        if (idx < 0) idx += ms;                                               // Python's negative index
+        if (idx < 0 || idx >= ms) {
+            sgx_set_error("IndexError: measurement point %lld outside the %d ms of channel %d",
+                          (long long)msOfTheSignal[ch], ms, ch);
+            return SGX_E_RANGE;
+        }
+        pseudoranges[ch] = absoluteSample[(size_t)ch * (size_t)ms + (size_t)idx] / (double)samplesPerCode;
+    }
+    double mn = INFINITY;
+    for (int i = 0; i < numberOfChannels; ++i) mn = pseudoranges[i] < mn ? pseudoranges[i] : mn;
+    const double minimum = floor(mn);
+    for (int i = 0; i < numberOfChannels; ++i)
+        pseudoranges[i] = ((pseudoranges[i] - minimum) + startOffset) * c_mps / 1000;   // left to right, as written
+    return SGX_OK;
+}
+
 extern "C" int sgx_find_preambles(sgx_ctx* c, const double* I_P, int32_t n_ch, int32_t ms, int32_t search_start,
                                   int32_t* firstSubFrame) {
     SGX_CHECK_ARG(c && I_P && firstSubFrame && n_ch >= 1 && ms >= 1 && search_start >= 0 && search_start < ms);

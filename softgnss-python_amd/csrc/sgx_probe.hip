@@ -85,13 +85,7 @@ extern "C" int sgx_probe_stats(sgx_ctx* c, const sgx_if* rec, size_t offset, siz
     }
     const double scale = 1.0 / (fs_mhz * w2);
 
-    static FftPlan plan;                  // 16384 = 16 * 16 * 16 * 4; twiddles live on the device of first use
-    static int plan_device = -1;
-    if (plan_device != c->device) {
-        plan = FftPlan();
-        plan_device = c->device;
-    }
-    int rc = sgx_fft_plan_create(&plan, PROBE_NSEG);
+    int rc = sgx_fft_plan_create(&c->plan_probe, PROBE_NSEG);   // 16384 = 16 * 16 * 16 * 4, kept with the context
     if (rc != SGX_OK) return rc;
 
     const size_t row_bytes = sizeof(cplx) * (size_t)PROBE_NSEG;
@@ -126,7 +120,7 @@ extern "C" int sgx_probe_stats(sgx_ctx* c, const sgx_if* rec, size_t offset, siz
 
     probe_segment_kernel<<<n_seg, 256, 0, st>>>(x, d_a, d_win, mean, step);
     cplx* res = nullptr;
-    rc = sgx_fft_forward(&plan, d_a, d_b, n_seg, st, &res, PROBE_NSEG);
+    rc = sgx_fft_forward(&c->plan_probe, d_a, d_b, n_seg, st, &res, PROBE_NSEG);
     if (rc != SGX_OK) {
         hipFree(d_all);
         return rc;

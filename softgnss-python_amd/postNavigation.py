@@ -1,9 +1,9 @@
 """NavigationResult with the reference's interface, limited to the stage next to the accelerated path:
 bit synchronisation and preamble search on the tracking output (reference postNavigation.py:443-631).
 
-findPreambles() and navPartyChk() are answered by libsgx.so (sgx_find_preambles, sgx_nav_parity_check).
-Ephemeris decoding, pseudoranges and the position solution (postNavigate, calculatePseudoranges, plot) stay
-in the reference: they are scalar, millisecond-rate code outside this engine's scope.
+findPreambles(), navPartyChk(), the bit integration and calculatePseudoranges() are answered by libsgx.so
+(sgx_find_preambles, sgx_nav_parity_check, sgx_nav_bits, sgx_pseudoranges).  Ephemeris decoding and the position
+solution (postNavigate, plot) stay in the reference: they are scalar, millisecond-rate code outside this engine's scope.
 """
 from __future__ import print_function
 
@@ -69,7 +69,25 @@ class NavigationResult(Result):
                                   "(postNavigation.py:75-305): scalar code outside this engine's scope")
 
     def calculatePseudoranges(self, msOfTheSignal, channelList):
-        raise NotImplementedError("outside this engine's scope (reference postNavigation.py:27-72)")
+        """Relative pseudoranges (metres, +inf for channels not in channelList) at millisecond
+        msOfTheSignal[channel] of the tracking results (reference postNavigation.py:27-72)."""
+        trackResults = self._results
+        settings = self._settings
+        abs_s = np.ascontiguousarray(np.stack([np.asarray(r.absoluteSample, dtype=np.float64) for r in trackResults]))
+        when = np.ascontiguousarray(msOfTheSignal, dtype=np.float64)
+        chans = np.ascontiguousarray(channelList, dtype=np.int32)
+        if when.shape[0] < settings.numberOfChannels:
+            raise IndexError("msOfTheSignal needs one entry per configured channel")
+        out = np.empty(settings.numberOfChannels)
+        rc = _native.lib().sgx_pseudoranges(abs_s.ctypes.data_as(C.c_void_p), abs_s.shape[0], abs_s.shape[1],
+                                            when.ctypes.data_as(C.c_void_p), chans.ctypes.data_as(C.c_void_p),
+                                            chans.shape[0], int(settings.numberOfChannels),
+                                            int(settings.samplesPerCode), float(settings.startOffset),
+                                            float(settings.c), out.ctypes.data_as(C.c_void_p))
+        if rc == _native.SGX_E_RANGE:
+            raise IndexError(_native.last_error())
+        _native.check(rc)
+        return out
 
     def plot(self):
         raise NotImplementedError("plotting is outside the accelerated path (reference postNavigation.py:307-439)")

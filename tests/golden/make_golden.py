@@ -174,6 +174,46 @@ def golden_probe(tmp, initialize):
     print("probe_default.npz", f.shape, pxx.shape, counts.sum())
 
 
+def golden_nav(tmp, initialize, acquisition, tracking):
+    """10: bit sync / preamble search (postNavigation.findPreambles) and calculatePseudoranges on structured
+    navigation data."""
+    with Quiet():
+        import postNavigation
+    s3 = initialize.Settings()
+    s3.samplingFreq = 16367600.0
+    s3.IF = 4130400.0
+    s3.msToProcess = 10000.0
+    s3.numberOfChannels = 2
+    s3.acqSatelliteList = range(1, 13)
+    n3 = s3.samplesPerCode
+    sc3 = synth.Scene.make(0x4E415601, s3.samplingFreq, s3.IF, [4, 10], [1500, -2600], [3000, 11111],
+                           [8, 7]).with_subframes(100)
+    rec3 = synth.generate(sc3, synth.record_length(n3, 10000))
+    acq3 = acquisition.AcquisitionResult(s3)
+    with Quiet():
+        acq3.acquire(rec3[:11 * n3])
+        acq3.preRun()
+    trk3 = tracking.TrackingResult(acq3)
+    fid3 = as_file(tmp, "rec3.bin", rec3)
+    with Quiet():
+        trk3.track(fid3)
+        nav = postNavigation.NavigationResult(trk3)
+        first, active = nav.findPreambles()
+    ip = np.stack([np.asarray(trk3.results[i].I_P, dtype=np.float64) for i in range(len(trk3.results))])
+    # calculatePseudoranges (postNavigation.py:27-72) at four measurement points, both channels / one channel
+    meas = np.stack([np.asarray(first) + 500 * k for k in range(4)]).astype(np.float64)
+    pr_all = np.stack([nav.calculatePseudoranges(meas[k], np.asarray(active)) for k in range(4)])
+    pr_one = nav.calculatePseudoranges(meas[1], np.array([1]))
+    abs_s = np.stack([np.asarray(trk3.results[i].absoluteSample, dtype=np.float64) for i in range(len(trk3.results))])
+    np.savez_compressed(os.path.join(HERE, "nav_preambles.npz"), scene=scene_json(sc3), subframes_at=np.int64(100),
+                        absoluteSample=abs_s, pr_ms=meas, pr_all=pr_all, pr_one=pr_one,
+                        n_samples=np.int64(len(rec3)), ms=np.int64(10000), I_P=ip,
+                        ch_PRN=acq3.channels.PRN, ch_acquiredFreq=acq3.channels.acquiredFreq,
+                        ch_codePhase=acq3.channels.codePhase,
+                        firstSubFrame=np.asarray(first), activeChnList=np.asarray(active))
+    print("nav_preambles.npz", first, active)
+
+
 def scene_json(sc):
     return json.dumps(dict(seed=sc.seed, fs=sc.fs, sats=sc.sats))
 
@@ -184,6 +224,9 @@ def main():
         if os.environ.get("SGX_GOLDEN_ONLY", "") in ("", "probe"):
             golden_probe(tmp, initialize)
         if os.environ.get("SGX_GOLDEN_ONLY", "") == "probe":
+            return
+        if os.environ.get("SGX_GOLDEN_ONLY", "") == "nav":
+            golden_nav(tmp, initialize, acquisition, tracking)
             return
         s = initialize.Settings()
         n = s.samplesPerCode
@@ -308,37 +351,8 @@ def main():
                             series=series2, PRN=np.array([int(x.PRN) for x in rb]))
         print("rate2.npz", n2, np.flatnonzero(det2) + 1, series2.shape)
 
-        # ---- 10: bit sync / preamble search (postNavigation.findPreambles) on structured navigation data ----
         if os.environ.get("SGX_GOLDEN_NAV", "1") == "1":
-            with Quiet():
-                import postNavigation
-            s3 = initialize.Settings()
-            s3.samplingFreq = 16367600.0
-            s3.IF = 4130400.0
-            s3.msToProcess = 10000.0
-            s3.numberOfChannels = 2
-            s3.acqSatelliteList = range(1, 13)
-            n3 = s3.samplesPerCode
-            sc3 = synth.Scene.make(0x4E415601, s3.samplingFreq, s3.IF, [4, 10], [1500, -2600], [3000, 11111],
-                                   [8, 7]).with_subframes(100)
-            rec3 = synth.generate(sc3, synth.record_length(n3, 10000))
-            acq3 = acquisition.AcquisitionResult(s3)
-            with Quiet():
-                acq3.acquire(rec3[:11 * n3])
-                acq3.preRun()
-            trk3 = tracking.TrackingResult(acq3)
-            fid3 = as_file(tmp, "rec3.bin", rec3)
-            with Quiet():
-                trk3.track(fid3)
-                nav = postNavigation.NavigationResult(trk3)
-                first, active = nav.findPreambles()
-            ip = np.stack([np.asarray(trk3.results[i].I_P, dtype=np.float64) for i in range(len(trk3.results))])
-            np.savez_compressed(os.path.join(HERE, "nav_preambles.npz"), scene=scene_json(sc3), subframes_at=np.int64(100),
-                                n_samples=np.int64(len(rec3)), ms=np.int64(10000), I_P=ip,
-                                ch_PRN=acq3.channels.PRN, ch_acquiredFreq=acq3.channels.acquiredFreq,
-                                ch_codePhase=acq3.channels.codePhase,
-                                firstSubFrame=np.asarray(first), activeChnList=np.asarray(active))
-            print("nav_preambles.npz", first, active)
+            golden_nav(tmp, initialize, acquisition, tracking)
 
         trk2 = tracking.TrackingResult(acq_t)
         short = as_file(tmp, "short.bin", rec[:100 * n])

@@ -249,3 +249,37 @@ def test_nav_bits_matches_oracle_including_summation_order():
         orc.nav_bits(x[:12000], 1999)
     with pytest.raises(ValueError):
         native.nav_bits(x[:12000], 1999)
+
+
+def test_pseudoranges_match_reference():
+    """sgx_pseudoranges (host code) and the oracle vs NavigationResult.calculatePseudoranges of the reference
+    (fixture made from the reference tracker's absoluteSample series)."""
+    import oracle.softgnss_oracle as orc
+    g = load_golden("nav_preambles.npz")
+    m = pkg()
+    s = m.Settings()
+    s.samplingFreq, s.IF, s.numberOfChannels = 16367600.0, 4130400.0, 2
+    so = orc.OracleSettings(samplingFreq=16367600.0, IF=4130400.0, numberOfChannels=2)
+
+    class Trk(object):
+        pass
+
+    t = Trk()
+    t.settings, t.channels = s, None
+    t.results = np.recarray((2,), dtype=[('status', 'S1'), ('absoluteSample', 'O'), ('PRN', 'i8')])
+    for i in range(2):
+        t.results[i].status, t.results[i].absoluteSample, t.results[i].PRN = b'T', g["absoluteSample"][i], (4, 10)[i]
+    nav = m.NavigationResult(t)
+    for k in range(4):
+        want = g["pr_all"][k]
+        assert np.array_equal(orc.calculate_pseudoranges(so, g["absoluteSample"], g["pr_ms"][k], g["activeChnList"]), want)
+        assert np.array_equal(nav.calculatePseudoranges(g["pr_ms"][k], g["activeChnList"]), want)
+    one = nav.calculatePseudoranges(g["pr_ms"][1], np.array([1]))
+    assert np.array_equal(one, g["pr_one"]) and np.isinf(one[0])
+    assert np.all(np.isnan(nav.calculatePseudoranges(g["pr_ms"][0], np.array([], dtype=int))))
+    with pytest.raises(IndexError):
+        nav.calculatePseudoranges(np.array([10000.0, 5.0]), [0])
+    # negative measurement points index from the end, like numpy does
+    neg = np.array([-1.0, -3.0])
+    assert np.array_equal(nav.calculatePseudoranges(neg, [0, 1]),
+                          orc.calculate_pseudoranges(so, g["absoluteSample"], neg, [0, 1]))
