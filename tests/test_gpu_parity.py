@@ -538,3 +538,92 @@ def test_probe_statistics_golden():
     out2 = s.probeData(m.DeviceSignal(rec, 12345, 381920), device=0)
     assert np.array_equal(out2["timeData"], x[12346:12345 + 38192 // 50])
     rec.free()
+
+
+# ---- settings off the defaults, random scenes -------------------------------------------------------------------
+
+def _oracle_vs_gpu(m, s, os_, rec_host, ms, split_env=None):
+    n = s.samplesPerCode
+    a = m.AcquisitionResult(s, device=0)
+    a.acquire(rec_host[:11 * n])
+    ref = orc.acquire(os_, rec_host[:11 * n])
+    assert np.array_equal(a.codePhase, ref["codePhase"])
+    assert np.array_equal(a.carrFreq, ref["carrFreq"])
+    assert np.allclose(a.peakMetric, ref["peakMetric"], rtol=1e-9, atol=0)
+    if not np.any(a.carrFreq):
+        return a, None
+    a.preRun()
+    chans_ref = orc.pre_run(os_, ref)
+    assert np.array_equal(a.channels.PRN, chans_ref["PRN"])
+    t = m.TrackingResult(a, device=0)
+    ctx = m.engine.get_context(s, 0)
+    rec = ctx.upload(rec_host)
+    old = {k: os.environ.get(k) for k in (split_env or {})}
+    os.environ.update(split_env or {})
+    try:
+        t.track(m.DeviceFile(rec))
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        rec.free()
+    want = orc.stack_series(orc.track(os_, chans_ref, rec_host))
+    assert np.array_equal(t.series[:, 0], want[:, 0])
+    assert _trk_err(t.series, want) < TRK_TOL
+    return a, t
+
+
+@pytest.mark.parametrize("spacing,dll_bw,pll_bw,band,split", [(0.25, 1.0, 15.0, 10.0, None), (0.4, 4.0, 40.0, 6.0, "1"),
+                                                              (0.1, 2.0, 25.0, 14.0, "3")])
+def test_non_default_loop_and_search_settings(spacing, dll_bw, pll_bw, band, split):
+    """Correlator spacing, loop bandwidths, damping, search band and threshold off the defaults: the three code
+    ramps then switch chips at different samples (exact per-sample path of the map)."""
+    m = pkg()
+    kw = dict(dllCorrelatorSpacing=spacing, dllNoiseBandwidth=dll_bw, pllNoiseBandwidth=pll_bw, acqSearchBand=band,
+              acqThreshold=2.2, dllDampingRatio=0.8, pllDampingRatio=0.6, numberOfChannels=3, msToProcess=60.0,
+              acqSatelliteList=range(1, 9))    # the reference searches PRN 1..len(list) (acquisition.py:103)
+    s = m.Settings()
+    os_ = orc.OracleSettings()
+    for k, v in kw.items():
+        setattr(s, k, v)
+        setattr(os_, k, v)
+    sc = m.synth.Scene.make(0x5E771 + int(spacing * 100), s.samplingFreq, s.IF, [3, 7, 8], [1200, -2100, 2600],
+                            [100, 20000, 31000], [9, 8, 8])
+    rec = m.synth.generate(sc, m.synth.record_length(s.samplesPerCode, 60))
+    a, t = _oracle_vs_gpu(m, s, os_, rec, 60, {"SGX_TRK_SPLIT": split} if split else None)
+    assert t is not None and set(a.channels.PRN[:3]) == {3, 7, 8}
+    # the throughput-mode kernel (more than 128 channels) with the same settings: replicas of the three channels
+    ctx = m.engine.get_context(s, 0)
+    dev = ctx.upload(rec)
+    chans = [(int(c.PRN), float(c.acquiredFreq), float(c.codePhase)) for c in a.channels]
+    many, done = ctx.track(dev, [chans[i % 3] for i in range(132)], 60)
+    dev.free()
+    assert np.all(done == 60)
+    for i in range(132):
+        assert np.array_equal(many[i, 0], t.series[i % 3, 0])
+        assert np.array_equal(many[i], many[i % 3])
+    assert _trk_err(many[:3], t.series) < 1e-9
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16])
+def test_random_scenes_against_oracle(seed):
+    """Random Doppler / code phase / amplitude (down to signals near the detection threshold), random PRN subsets;
+    one scene without any satellite."""
+    m = pkg()
+    rng = np.random.default_rng(seed)
+    s = m.Settings()
+    os_ = orc.OracleSettings()
+    prns = sorted(rng.choice(np.arange(1, 7), size=3, replace=False).tolist())
+    present = prns[:2] if seed != 13 else []
+    for o in (s, os_):
+        o.acqSatelliteList = range(1, 7)      # PRN 1..6 are searched (acquisition.py:103 loops over range(len(list)))
+        o.numberOfChannels = 2
+        o.msToProcess = 40.0
+    n = s.samplesPerCode
+    sc = m.synth.Scene.make(0xF00D0000 + seed, s.samplingFreq, s.IF, present,
+                            [float(rng.integers(-6500, 6500)) for _ in present],
+                            [int(rng.integers(0, n)) for _ in present],
+                            [int(rng.integers(2, 10)) for _ in present])
+    rec = m.synth.generate(sc, m.synth.record_length(n, 40))
+    a, t = _oracle_vs_gpu(m, s, os_, rec, 40)
+    if seed == 13:
+        assert t is None and not np.any(a.carrFreq)
