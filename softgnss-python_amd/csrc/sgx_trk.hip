@@ -184,30 +184,45 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
     int* d_done = (int*)(aux + sz_ch);
     unsigned long long* d_xch = (unsigned long long*)(aux + sz_ch + sz_done);
     int* d_err = (int*)(aux + sz_ch + sz_done + sz_xch);
-    SGX_HIP(hipMemcpyAsync(d_ch, hc.data(), sizeof(TrkChan) * (size_t)n_ch, hipMemcpyHostToDevice, st));
-    SGX_HIP(hipMemsetAsync(aux + sz_ch, 0, sz_done + sz_xch + 256, st));   // done, every polled word, err
-    if (!direct) trk_fill_kernel<<<(unsigned)((elems + 255) / 256), 256, 0, st>>>(d_out, ms, (long long)elems);
     const char* pe = getenv("SGX_TRK_PROFILE");
     const bool want_prof = pe && pe[0] == '1';
     long long* d_prof = want_prof ? (long long*)(aux + sz_ch + sz_done + sz_xch + 256) : nullptr;
-    const int n_blocks = ((n_ch + 7) / 8) * 8 * K.split;
     // SGX_TRK_SPEC=1 selects the experimental speculative pipeline (sgx_trk_spec.hip; needs exactly one unit
     // per member).  It reproduces the cooperative kernel's results but measured slower.
     const char* sp = getenv("SGX_TRK_SPEC");
-    const bool use_spec = (K.split > 1 && K.split == K.n_units) && (sp && sp[0] == '1');
-    if (want_prof) SGX_HIP(hipMemsetAsync(d_prof, 0, sizeof(long long) * 64 * (size_t)n_ch, st));
-    hipEventRecord(c->ev[3], st);
-    if (use_spec)
-        sgx_trk_spec_launch(n_blocks, st, r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err);
-    else if (K.split == 1 && n_ch > 128)
-        sgx_trk_tp_launch(n_blocks, st, r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err);
-    else
-        trk_kernel<<<n_blocks, TRK_THREADS, 0, st>>>(r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch,
-                                                        d_err);
-    hipEventRecord(c->ev[4], st);
-    hipError_t e = hipGetLastError();
+    bool use_spec = false;
+    hipError_t e = hipSuccess;
     int h_err = 0;
-    if (e == hipSuccess) e = hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, st);
+    // The cooperating workgroups of a channel wait for each other, so all of them must be resident at once.  If
+    // something else occupies the CUs a member times out (bounded spins) and flags the channel: the launch is
+    // then repeated once with one workgroup per channel, which needs no co-residency.
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        SGX_HIP(hipMemcpyAsync(d_ch, hc.data(), sizeof(TrkChan) * (size_t)n_ch, hipMemcpyHostToDevice, st));
+        SGX_HIP(hipMemsetAsync(aux + sz_ch, 0, sz_done + sz_xch + 256, st));   // done, every polled word, err
+        if (!direct) trk_fill_kernel<<<(unsigned)((elems + 255) / 256), 256, 0, st>>>(d_out, ms, (long long)elems);
+        const int n_blocks = ((n_ch + 7) / 8) * 8 * K.split;
+        use_spec = (K.split > 1 && K.split == K.n_units) && (sp && sp[0] == '1');
+        if (want_prof) SGX_HIP(hipMemsetAsync(d_prof, 0, sizeof(long long) * 64 * (size_t)n_ch, st));
+        hipEventRecord(c->ev[3], st);
+        if (use_spec)
+            sgx_trk_spec_launch(n_blocks, st, r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err);
+        else if (K.split == 1 && n_ch > 128)
+            sgx_trk_tp_launch(n_blocks, st, r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err);
+        else
+            trk_kernel<<<n_blocks, TRK_THREADS, 0, st>>>(r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch,
+                                                            d_err);
+        hipEventRecord(c->ev[4], st);
+        e = hipGetLastError();
+        h_err = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        const char* th = getenv("SGX_TRK_TEST_TIMEOUT");   // test hook: treat the first attempt as timed out
+        if (e == hipSuccess && th && th[0] == '1' && attempt == 0 && K.split > 1) h_err = 1;
+        if (e != hipSuccess || h_err == 0 || K.split == 1) break;
+        fprintf(stderr, "[sgx] tracking: channel %d timed out waiting for a cooperating workgroup (split %d, are the "
+                        "CUs shared?); repeating the launch with one workgroup per channel\n", h_err - 1, K.split);
+        K.split = 1;
+    }
     if (e == hipSuccess && !direct) e = hipMemcpyAsync(out, d_out, elems * sizeof(double), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(ms_done, d_done, sizeof(int) * (size_t)n_ch, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -252,8 +267,7 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
         }
     }
     if (h_err != 0) {
-        sgx_set_error("tracking kernel: channel %d timed out waiting for a cooperating workgroup (split %d); "
-                      "set SGX_TRK_SPLIT=1", h_err - 1, K.split);
+        sgx_set_error("tracking kernel: channel %d reported a timeout with split %d", h_err - 1, K.split);
         return SGX_E_HIP;
     }
     hipEventElapsedTime(&c->timing.track_ms, c->ev[3], c->ev[4]);

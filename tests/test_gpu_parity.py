@@ -294,6 +294,19 @@ def test_split_variants_agree_on_the_full_run(full_run):
                 os.environ[k] = v
 
 
+def test_cooperative_timeout_falls_back_to_one_workgroup_per_channel(full_run, capfd):
+    """A member that times out flags the channel; the host repeats the launch with split = 1 (same results)."""
+    m, s, ctx, sc, rec, a, chans, series, done = full_run
+    os.environ["SGX_TRK_TEST_TIMEOUT"] = "1"
+    try:
+        s2, d2 = ctx.track(rec, chans, 500)
+    finally:
+        os.environ.pop("SGX_TRK_TEST_TIMEOUT", None)
+    assert "repeating the launch with one workgroup per channel" in capfd.readouterr().err
+    assert np.all(d2 == 500) and np.array_equal(s2[:, 0], series[:, 0, :500])
+    assert _trk_err(s2, series[:, :, :500]) < 1e-9
+
+
 def test_many_channels_throughput_mode(full_run):
     """256 channels (32 replicas of the 8 inits) on one GPU: one CU per channel, replicas bit-identical."""
     m, s, ctx, sc, rec, a, chans, series, done = full_run
