@@ -196,6 +196,7 @@ def main():
 
     if rank == 0:
         traffic = pmc_traffic(args.channels, args.ms)
+        read_gbs, copy_gbs = ctx.stream_rates(1 << 30, 5)
         out = {
             "metric": "IF Msamples/s through acquisition + tracking (x real-time = value / 38.192)",
             "value": value, "unit": "Msamples/s", "x_realtime": value / REALTIME_MSPS,
@@ -216,6 +217,8 @@ def main():
                          "traffic_source": (traffic[1] + " (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes of this "
                                             "command; FETCH_SIZE x2, gfx950 correction)") if traffic else None,
                          "algorithmic_bytes_per_launch": b_trk,
+                         "measured_stream_read_gbs": read_gbs, "measured_stream_copy_gbs": copy_gbs,
+                         "frac_of_measured_read": achieved / read_gbs,
                          "note": "37 000 dependent steps per channel; 8 channels x 10 cooperating CUs = 80 of 256 "
                                  "CUs busy: latency-bound, not bandwidth-bound (DESIGN.md section 5)"},
         }
@@ -232,6 +235,7 @@ def main():
                 "kernel": "trk_kernel_tp", "bound": "hbm", "channels": len(many), "ms": args.many_ms,
                 "achieved": b_many / (t_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": b_many / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": t_ms,
+                "frac_of_measured_read": b_many / (t_ms * 1e-3) / 1e9 / read_gbs,
                 "note": "throughput-mode kernel (one lane per prompt chip, split=1): channels x ms code periods of "
                         "independent work; fp64 VALU-bound at >= 4 instructions per sample"}
         if world == 1 and not args.no_cpu_baseline:

@@ -167,6 +167,10 @@ int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset,
               const sgx_chan_init* ch, int32_t n_ch, int32_t ms,
               double* out, int32_t* ms_done);
 
+/* Measured HBM rates of this device for the roofline report (no reference counterpart): a read-only stream and a
+ * copy (read + write bytes counted) over `bytes` of device memory, `reps` timed launches each, GB/s. */
+int sgx_stream_rates(sgx_ctx* c, size_t bytes, int reps, double* read_gbs, double* copy_gbs);
+
 /* ---- next row: raw-data statistics of Settings.probeData (initialize.py:330-417) ------------------------------
  * Window [offset, offset+n) of a resident record (the reference reads 10 * samplesPerCode samples,
  * initialize.py:369-371).  f[8193] (MHz) and pxx[8193] = welch(data - mean(data), fs_mhz, hamming(16384, False),

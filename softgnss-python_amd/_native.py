@@ -80,6 +80,7 @@ _PROTOS = {
     "sgx_acquire": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, C.c_int32, C.c_int32, C.c_int32,
                               _P, _P, _P, _P, _P]),
     "sgx_track": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, C.c_int32, _P, _P]),
+    "sgx_stream_rates": (C.c_int, [_P, C.c_size_t, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "sgx_probe_stats": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, C.c_double, _P, _P, _P, C.POINTER(C.c_int32)]),
     "sgx_find_preambles": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "sgx_nav_parity_check": (C.c_int, [_P, C.POINTER(C.c_int32)]),
@@ -244,6 +245,12 @@ class Context(object):
         check(lib().sgx_get_timing(self._h, C.byref(t)))
         return dict(acquire_ms=t.acquire_ms, acq_coarse_ms=t.acq_coarse_ms, acq_fine_ms=t.acq_fine_ms,
                     track_ms=t.track_ms, synth_ms=t.synth_ms)
+
+    def stream_rates(self, nbytes=1 << 30, reps=5):
+        """(read GB/s, copy GB/s) measured on this device: the practical HBM roof next to the 8 TB/s datasheet peak."""
+        r, w = C.c_double(0), C.c_double(0)
+        check(lib().sgx_stream_rates(self._h, int(nbytes), int(reps), C.byref(r), C.byref(w)))
+        return r.value, w.value
 
     # ---- records ----
     def upload(self, samples):

@@ -111,3 +111,60 @@ extern "C" int sgx_if_synth(sgx_ctx* c, const sgx_scene* scene, uint64_t offset,
     *out = r;
     return SGX_OK;
 }
+
+// ---- measured HBM rates for the roofline report ("also report vs. a measured stream peak") --
+__global__ __launch_bounds__(256) void stream_read_kernel(const uint4* __restrict__ src, size_t n16,
+                                                          unsigned* __restrict__ sink) {
+    unsigned acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+        const uint4 v = src[i];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x9E3779B9u) *sink = acc;   // keeps the loads alive; practically never true
+}
+
+__global__ __launch_bounds__(256) void stream_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst,
+                                                          size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+extern "C" int sgx_stream_rates(sgx_ctx* c, size_t bytes, int reps, double* read_gbs, double* copy_gbs) {
+    SGX_CHECK_ARG(c && read_gbs && copy_gbs && bytes >= (1u << 20) && reps >= 1);
+    SGX_HIP(hipSetDevice(c->device));
+    const size_t n16 = bytes / 16;
+    uint4 *a = nullptr, *b = nullptr;
+    SGX_HIP(hipMalloc((void**)&a, n16 * 16));
+    if (hipMalloc((void**)&b, n16 * 16) != hipSuccess) {
+        hipFree(a);
+        sgx_set_error("hipMalloc of %zu bytes failed in sgx_stream_rates", n16 * 16);
+        return SGX_E_NOMEM;
+    }
+    hipStream_t st = c->stream;
+    hipMemsetAsync(a, 0x5A, n16 * 16, st);
+    hipMemsetAsync(b, 0, n16 * 16, st);
+    const int blocks = 256 * 16;
+    float ms_r = 0.f, ms_c = 0.f;
+    stream_read_kernel<<<blocks, 256, 0, st>>>(a, n16, (unsigned*)b);
+    hipEventRecord(c->ev[0], st);
+    for (int i = 0; i < reps; ++i) stream_read_kernel<<<blocks, 256, 0, st>>>(a, n16, (unsigned*)b);
+    hipEventRecord(c->ev[1], st);
+    stream_copy_kernel<<<blocks, 256, 0, st>>>(a, b, n16);
+    hipEventRecord(c->ev[2], st);
+    for (int i = 0; i < reps; ++i) stream_copy_kernel<<<blocks, 256, 0, st>>>(a, b, n16);
+    hipEventRecord(c->ev[3], st);
+    hipError_t e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) {
+        hipEventElapsedTime(&ms_r, c->ev[0], c->ev[1]);
+        hipEventElapsedTime(&ms_c, c->ev[2], c->ev[3]);
+    }
+    hipFree(a);
+    hipFree(b);
+    if (e != hipSuccess) {
+        sgx_set_error("stream rate kernels failed: %s", hipGetErrorString(e));
+        return SGX_E_HIP;
+    }
+    *read_gbs = (double)(n16 * 16) * reps / (ms_r * 1e-3) / 1e9;
+    *copy_gbs = 2.0 * (double)(n16 * 16) * reps / (ms_c * 1e-3) / 1e9;   // bytes read + bytes written
+    return SGX_OK;
+}
