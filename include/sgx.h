@@ -201,6 +201,15 @@ int sgx_nav_parity_check(double* ndat32, int32_t* status);
  * clipped slice is not a multiple of 20 ms.  Host code: 30 020 additions per channel. */
 int sgx_nav_bits(const double* I_P_row, int32_t ms, int32_t subFrameStart, uint8_t* bits, int32_t* n_bits);
 
+/* ephemeris.ephemeris (ephemeris.py:60-195): bits = n_bits >= 1500 values 0/1 starting at the first bit of a
+ * subframe, d30star = last bit of the word before; eph[27] in the reference's field order (weekNumber, accuracy,
+ * health, T_GD, IODC, t_oc, a_f2, a_f1, a_f0, IODE_sf2, C_rs, deltan, M_0, C_uc, e, C_us, sqrtA, t_oe, C_ic,
+ * omega_0, C_is, i_0, C_rc, omega, omegaDot, IODE_sf3, iDot), *tow in seconds.  Like the reference, parity is not
+ * checked here.  SGX_E_ARG ("TypeError") for fewer than 1500 bits, SGX_E_RANGE ("UnboundLocalError") when
+ * subframe 1, 2 or 3 is not among the five.  Host code. */
+#define SGX_EPH_FIELDS 27
+int sgx_ephemeris(const uint8_t* bits, int32_t n_bits, uint8_t d30star, double* eph, int64_t* tow);
+
 /* NavigationResult.calculatePseudoranges (postNavigation.py:27-72): absoluteSample is [n_rows][ms] (row i = i-th
  * record of the tracking results), msOfTheSignal[numberOfChannels] the measurement point per channel, channelList
  * the channels to use; pseudoranges[numberOfChannels] in metres, +inf for channels not listed (NaN everywhere if

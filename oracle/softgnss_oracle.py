@@ -440,3 +440,55 @@ def calculate_pseudoranges(s, absolute_sample_rows, ms_of_the_signal, channel_li
     minimum = np.floor(travel.min())
     travel = travel - minimum + s.startOffset
     return travel * s.c / 1000
+
+
+def _u(sub, *slices):
+    return int(''.join(''.join(sub[a:b]) for a, b in slices), 2)
+
+
+def _s(sub, *slices):
+    txt = ''.join(''.join(sub[a:b]) for a, b in slices)
+    v = int(txt, 2)
+    return v - 2 ** len(txt) if txt[0] == '1' else v            # ephemeris.py:7-25
+
+
+def ephemeris(bits, d30star):
+    """ephemeris.py:60-195: (eph 27-tuple, TOW) from 1500 bits ('0'/'1' characters) and the bit before them."""
+    if len(bits) < 1500:
+        raise TypeError('The parameter BITS must contain 1500 bits!')
+    gps_pi = 3.1415926535898
+    f = {}
+    sub = None
+    for i in range(5):
+        sub = list(bits[300 * i:300 * (i + 1)])
+        for j in range(10):
+            if d30star == '1':                                      # checkPhase, ephemeris.py:30-57
+                for k in range(30 * j, 30 * j + 24):
+                    sub[k] = '0' if sub[k] == '1' else '1'
+            d30star = sub[30 * (j + 1) - 1]
+        sid = _u(sub, (49, 52))
+        if sid == 1:
+            f.update(weekNumber=_u(sub, (60, 70)) + 1024, accuracy=_u(sub, (72, 76)), health=_u(sub, (76, 82)),
+                     T_GD=_s(sub, (195, 204)) * 2 ** (-31), IODC=_u(sub, (82, 84), (196, 204)),
+                     t_oc=_u(sub, (218, 234)) * 2 ** 4, a_f2=_s(sub, (240, 248)) * 2 ** (-55),
+                     a_f1=_s(sub, (248, 264)) * 2 ** (-43), a_f0=_s(sub, (270, 292)) * 2 ** (-31))
+        elif sid == 2:
+            f.update(IODE_sf2=_u(sub, (60, 68)), C_rs=_s(sub, (68, 84)) * 2 ** (-5),
+                     deltan=_s(sub, (90, 106)) * 2 ** (-43) * gps_pi,
+                     M_0=_s(sub, (106, 114), (120, 144)) * 2 ** (-31) * gps_pi, C_uc=_s(sub, (150, 166)) * 2 ** (-29),
+                     e=_u(sub, (166, 174), (180, 204)) * 2 ** (-33), C_us=_s(sub, (210, 226)) * 2 ** (-29),
+                     sqrtA=_u(sub, (226, 234), (240, 264)) * 2 ** (-19), t_oe=_u(sub, (270, 286)) * 2 ** 4)
+        elif sid == 3:
+            f.update(C_ic=_s(sub, (60, 76)) * 2 ** (-29), omega_0=_s(sub, (76, 84), (90, 114)) * 2 ** (-31) * gps_pi,
+                     C_is=_s(sub, (120, 136)) * 2 ** (-29), i_0=_s(sub, (136, 144), (150, 174)) * 2 ** (-31) * gps_pi,
+                     C_rc=_s(sub, (180, 196)) * 2 ** (-5), omega=_s(sub, (196, 204), (210, 234)) * 2 ** (-31) * gps_pi,
+                     omegaDot=_s(sub, (240, 264)) * 2 ** (-43) * gps_pi, IODE_sf3=_u(sub, (270, 278)),
+                     iDot=_s(sub, (278, 292)) * 2 ** (-43) * gps_pi)
+    tow = _u(sub, (30, 47)) * 6 - 30
+    names = ('weekNumber', 'accuracy', 'health', 'T_GD', 'IODC', 't_oc', 'a_f2', 'a_f1', 'a_f0', 'IODE_sf2', 'C_rs',
+             'deltan', 'M_0', 'C_uc', 'e', 'C_us', 'sqrtA', 't_oe', 'C_ic', 'omega_0', 'C_is', 'i_0', 'C_rc', 'omega',
+             'omegaDot', 'IODE_sf3', 'iDot')
+    missing = [k for k in names if k not in f]
+    if missing:
+        raise UnboundLocalError("local variable '%s' referenced before assignment" % missing[0])
+    return tuple(f[k] for k in names), tow

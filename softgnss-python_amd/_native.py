@@ -84,6 +84,7 @@ _PROTOS = {
     "sgx_probe_stats": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, C.c_double, _P, _P, _P, C.POINTER(C.c_int32)]),
     "sgx_find_preambles": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "sgx_nav_parity_check": (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    "sgx_ephemeris": (C.c_int, [_P, C.c_int32, C.c_uint8, _P, C.POINTER(C.c_int64)]),
     "sgx_pseudoranges": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int64, C.c_double,
                                    C.c_double, _P]),
     "sgx_nav_bits": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.POINTER(C.c_int32)]),

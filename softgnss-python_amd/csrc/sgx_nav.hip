@@ -122,6 +122,94 @@ extern "C" int sgx_pseudoranges(const double* absoluteSample, int32_t n_rows, in
     return SGX_OK;
 }
 
+// ---- ephemeris.py:60-195: clock and orbit parameters + TOW from five consecutive subframes -------------------------
+namespace {
+struct BitView {
+    const uint8_t* b;   // 300 polarity-corrected bits of one subframe
+    // unsigned value of bits [a0, a1) followed by bits [b0, b1) (Python slices; the second may be empty)
+    unsigned long long u(int a0, int a1, int b0 = 0, int b1 = 0) const {
+        unsigned long long v = 0;
+        for (int i = a0; i < a1; ++i) v = (v << 1) | b[i];
+        for (int i = b0; i < b1; ++i) v = (v << 1) | b[i];
+        return v;
+    }
+    // twosComp2dec of the same bits (ephemeris.py:7-25)
+    long long s(int a0, int a1, int b0 = 0, int b1 = 0) const {
+        const int len = (a1 - a0) + (b1 - b0);
+        long long v = (long long)u(a0, a1, b0, b1);
+        if (b[a0]) v -= 1ll << len;
+        return v;
+    }
+};
+}   // namespace
+
+extern "C" int sgx_ephemeris(const uint8_t* bits, int32_t n_bits, uint8_t d30star, double* eph, int64_t* tow) {
+    SGX_CHECK_ARG(bits && eph && tow);
+    if (n_bits < 1500) {
+        sgx_set_error("TypeError: The parameter BITS must contain 1500 bits!");
+        return SGX_E_ARG;
+    }
+    const double gpsPi = 3.1415926535898;                      // ephemeris.py:94
+    const double p2m5 = ldexp(1.0, -5), p2m19 = ldexp(1.0, -19), p2m29 = ldexp(1.0, -29), p2m31 = ldexp(1.0, -31),
+                 p2m33 = ldexp(1.0, -33), p2m43 = ldexp(1.0, -43), p2m55 = ldexp(1.0, -55);
+    bool have[4] = {false, false, false, false};
+    uint8_t sf[300];
+    uint8_t d30 = d30star ? 1 : 0;
+    for (int i = 0; i < 5; ++i) {
+        for (int j = 0; j < 10; ++j) {                         // checkPhase (ephemeris.py:30-57): D30* = 1 inverts d1..d24
+            for (int k = 0; k < 30; ++k) {
+                const uint8_t v = bits[300 * i + 30 * j + k] ? 1 : 0;
+                sf[30 * j + k] = (k < 24 && d30) ? (uint8_t)(1 - v) : v;
+            }
+            d30 = sf[30 * j + 29];
+        }
+        const BitView w{sf};
+        const int id = (int)w.u(49, 52);
+        if (id == 1) {
+            have[1] = true;
+            eph[0] = (double)(w.u(60, 70) + 1024);             // weekNumber
+            eph[1] = (double)w.u(72, 76);                      // accuracy
+            eph[2] = (double)w.u(76, 82);                      // health
+            eph[3] = (double)w.s(195, 204) * p2m31;            // T_GD (9 bits as the reference slices them)
+            eph[4] = (double)w.u(82, 84, 196, 204);            // IODC
+            eph[5] = (double)(w.u(218, 234) * 16);             // t_oc
+            eph[6] = (double)w.s(240, 248) * p2m55;            // a_f2
+            eph[7] = (double)w.s(248, 264) * p2m43;            // a_f1
+            eph[8] = (double)w.s(270, 292) * p2m31;            // a_f0
+        } else if (id == 2) {
+            have[2] = true;
+            eph[9] = (double)w.u(60, 68);                      // IODE_sf2
+            eph[10] = (double)w.s(68, 84) * p2m5;              // C_rs
+            eph[11] = (double)w.s(90, 106) * p2m43 * gpsPi;    // deltan
+            eph[12] = (double)w.s(106, 114, 120, 144) * p2m31 * gpsPi;   // M_0
+            eph[13] = (double)w.s(150, 166) * p2m29;           // C_uc
+            eph[14] = (double)w.u(166, 174, 180, 204) * p2m33; // e
+            eph[15] = (double)w.s(210, 226) * p2m29;           // C_us
+            eph[16] = (double)w.u(226, 234, 240, 264) * p2m19; // sqrtA
+            eph[17] = (double)(w.u(270, 286) * 16);            // t_oe
+        } else if (id == 3) {
+            have[3] = true;
+            eph[18] = (double)w.s(60, 76) * p2m29;             // C_ic
+            eph[19] = (double)w.s(76, 84, 90, 114) * p2m31 * gpsPi;      // omega_0
+            eph[20] = (double)w.s(120, 136) * p2m29;           // C_is
+            eph[21] = (double)w.s(136, 144, 150, 174) * p2m31 * gpsPi;   // i_0
+            eph[22] = (double)w.s(180, 196) * p2m5;            // C_rc
+            eph[23] = (double)w.s(196, 204, 210, 234) * p2m31 * gpsPi;   // omega
+            eph[24] = (double)w.s(240, 264) * p2m43 * gpsPi;   // omegaDot
+            eph[25] = (double)w.u(270, 278);                   // IODE_sf3
+            eph[26] = (double)w.s(278, 292) * p2m43 * gpsPi;   // iDot
+        }
+        if (i == 4) *tow = (int64_t)w.u(30, 47) * 6 - 30;      // TOW of the first subframe of the block
+    }
+    if (!have[1] || !have[2] || !have[3]) {
+        // the reference then reads a local variable that was never assigned (ephemeris.py:190-193)
+        sgx_set_error("UnboundLocalError: subframe %d is not among the five decoded subframes",
+                      !have[1] ? 1 : (!have[2] ? 2 : 3));
+        return SGX_E_RANGE;
+    }
+    return SGX_OK;
+}
+
 extern "C" int sgx_find_preambles(sgx_ctx* c, const double* I_P, int32_t n_ch, int32_t ms, int32_t search_start,
                                   int32_t* firstSubFrame) {
     SGX_CHECK_ARG(c && I_P && firstSubFrame && n_ch >= 1 && ms >= 1 && search_start >= 0 && search_start < ms);

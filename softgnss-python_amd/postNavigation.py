@@ -2,8 +2,9 @@
 bit synchronisation and preamble search on the tracking output (reference postNavigation.py:443-631).
 
 findPreambles(), navPartyChk(), the bit integration and calculatePseudoranges() are answered by libsgx.so
-(sgx_find_preambles, sgx_nav_parity_check, sgx_nav_bits, sgx_pseudoranges).  Ephemeris decoding and the position
-solution (postNavigate, plot) stay in the reference: they are scalar, millisecond-rate code outside this engine's scope.
+(sgx_find_preambles, sgx_nav_parity_check, sgx_nav_bits, sgx_pseudoranges); decodeEphemerides() runs the first half
+of postNavigate (preambles -> bits -> sgx_ephemeris).  Satellite positions and the least-squares position
+solution (the rest of postNavigate, plot) stay in the reference: they are scalar, millisecond-rate code outside this engine's scope.
 """
 from __future__ import print_function
 
@@ -64,9 +65,29 @@ class NavigationResult(Result):
             out[int(channelNr)] = [str(int(b)) for b in bits]
         return out
 
+    def decodeEphemerides(self):
+        """The first half of the reference's postNavigate (postNavigation.py:113-147): find the subframe starts,
+        integrate the navigation bits and decode clock / orbit parameters and the time of week per channel.
+        Returns (eph, TOW, subFrameStart, activeChnList); eph is the reference's recarray of 32 records with 27
+        object fields, filled at index PRN-1.  Needs the 1500 bits after the first preamble, i.e. about 32 s."""
+        from . import ephemeris as eph_mod
+        subFrameStart, activeChnList = self.findPreambles()
+        eph = np.recarray((32,), formats=['O'] * 27, names=','.join(eph_mod.FIELDS))
+        TOW = None
+        bits = self.navBits(subFrameStart, activeChnList)
+        for channelNr in activeChnList:
+            navBitsBin = bits[int(channelNr)]
+            prn = int(self._results[channelNr].PRN)
+            eph[prn - 1], TOW = eph_mod.ephemeris(navBitsBin[1:], navBitsBin[0])
+            if eph[prn - 1].IODC is None or eph[prn - 1].IODE_sf2 is None or eph[prn - 1].IODE_sf3 is None:
+                activeChnList = np.setdiff1d(activeChnList, channelNr)
+        self._eph = eph
+        return eph, TOW, subFrameStart, activeChnList
+
     def postNavigate(self):
-        raise NotImplementedError("ephemeris decoding and the position solution stay in the reference "
-                                  "(postNavigation.py:75-305): scalar code outside this engine's scope")
+        raise NotImplementedError("satellite positions and the least-squares fix stay in the reference "
+                                  "(postNavigation.py:150-305, geoFunctions); decodeEphemerides() covers "
+                                  "postNavigation.py:113-147")
 
     def calculatePseudoranges(self, msOfTheSignal, channelList):
         """Relative pseudoranges (metres, +inf for channels not in channelList) at millisecond

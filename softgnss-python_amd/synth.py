@@ -104,6 +104,35 @@ def subframe_bits(seed, first_boundary=100, n_bits=NAV_TABLE_BITS):
     return np.array(out[skip:skip + n_bits], dtype=np.uint8)
 
 
+def nav_message_bits(seed, first_boundary=100, n_bits=NAV_TABLE_BITS, tow0=1000, first_id=1):
+    """Like subframe_bits, with a decodable frame structure: word 1 = TLM (preamble + 16 message bits), word 2 =
+    HOW (17-bit TOW count of the NEXT subframe, 2 flag bits, 3-bit subframe ID cycling 1..5, 2 filler bits), words
+    3-10 random data - so subframes 1, 2 and 3 parse into (random but well-defined) clock and orbit fields.  The
+    subframe that starts at table position first_boundary has ID first_id and announces TOW count tow0 + 1."""
+    import random
+    rng = random.Random(int(seed) ^ 0x6E6176)
+    out = []
+    d29s = d30s = 0
+    n_sub = (n_bits + 300) // 300 + 2
+    # the stream is cut so that table bit first_boundary starts a subframe; k counts subframes from that one
+    k0 = -((first_boundary + 299) // 300)              # index of the first generated subframe relative to it
+    for k in range(k0, k0 + n_sub):
+        sid = (first_id - 1 + k) % 5 + 1
+        tow = (tow0 + 1 + k) & 0x1FFFF
+        for wno in range(10):
+            d = [rng.randint(0, 1) for _ in range(24)]
+            if wno == 0:
+                d[:8] = [1, 0, 0, 0, 1, 0, 1, 1]
+            elif wno == 1:
+                d[:17] = [(tow >> (16 - b)) & 1 for b in range(17)]
+                d[19:22] = [(sid >> 2) & 1, (sid >> 1) & 1, sid & 1]
+            w = gps_parity(d, d29s, d30s)
+            d29s, d30s = w[28], w[29]
+            out.extend(w)
+    skip = (-k0) * 300 - first_boundary                 # generated bits before table bit 0
+    return np.array(out[skip:skip + n_bits], dtype=np.uint8)
+
+
 class Scene(object):
     """Integer description of a synthetic record. All fields are plain Python ints."""
 
@@ -122,6 +151,12 @@ class Scene(object):
     def with_subframes(self, first_boundary=100):
         """Same scene with structured navigation data (subframes + parity) instead of hash bits."""
         tab = np.stack([subframe_bits(self.seed * 131 + s["prn"], first_boundary) for s in self.sats])
+        return Scene(self.seed, self.sats, self.fs, self.cos_lut, tab)
+
+    def with_nav_message(self, first_boundary=100, tow0=1000, first_id=1):
+        """Same scene with decodable navigation frames (TLM/HOW with subframe IDs and TOW counts, valid parity)."""
+        tab = np.stack([nav_message_bits(self.seed * 137 + s["prn"], first_boundary, NAV_TABLE_BITS, tow0, first_id)
+                        for s in self.sats])
         return Scene(self.seed, self.sats, self.fs, self.cos_lut, tab)
 
     @staticmethod

@@ -146,6 +146,29 @@ class PlotRecorder(types.ModuleType):
         return lambda *a, **k: None
 
 
+EPH_CASES = [  # seed, first_boundary, first_id, tow0, invert the whole stream
+    (101, 100, 1, 1000, 0), (102, 0, 3, 52000, 0), (103, 299, 5, 99999, 1), (104, 37, 2, 7, 0), (105, 100, 4, 131070, 1)]
+
+
+def golden_eph(tmp):
+    """12: ephemeris.ephemeris (ephemeris.py:60-195) on 1500 bits of the generator's decodable navigation frames."""
+    with Quiet():
+        import ephemeris
+    out = []
+    for seed, fb, fid, tow0, inv in EPH_CASES:
+        tab = synth.nav_message_bits(seed, fb, 2048, tow0, fid)
+        if inv:
+            tab = 1 - tab
+        start = fb if fb > 0 else 300
+        bits = [str(int(b)) for b in tab[start:start + 1500]]
+        eph, tow = ephemeris.ephemeris(bits, str(int(tab[start - 1])))
+        out.append(list(eph) + [tow])
+        assert all(isinstance(eph[i], int) for i in (0, 1, 2, 4, 5, 9, 17, 25)) and isinstance(tow, int)
+    np.savez_compressed(os.path.join(HERE, "eph_cases.npz"), cases=np.array(EPH_CASES, dtype=np.int64),
+                        eph_tow=np.array(out, dtype=np.float64), int_fields=np.array([0, 1, 2, 4, 5, 9, 17, 25]))
+    print("eph_cases.npz", np.array(out)[:, [0, 4, 27]])
+
+
 def golden_probe(tmp, initialize):
     """11: probeData statistics (initialize.py:330-417): Welch PSD and histogram of the first 10 ms."""
     import scipy.signal.windows
@@ -223,7 +246,9 @@ def main():
     try:
         if os.environ.get("SGX_GOLDEN_ONLY", "") in ("", "probe"):
             golden_probe(tmp, initialize)
-        if os.environ.get("SGX_GOLDEN_ONLY", "") == "probe":
+        if os.environ.get("SGX_GOLDEN_ONLY", "") in ("", "eph"):
+            golden_eph(tmp)
+        if os.environ.get("SGX_GOLDEN_ONLY", "") in ("probe", "eph"):
             return
         if os.environ.get("SGX_GOLDEN_ONLY", "") == "nav":
             golden_nav(tmp, initialize, acquisition, tracking)

@@ -227,9 +227,12 @@ def test_navigation_result_surface():
     try:
         m = importlib.import_module("postNavigation")
         assert m.NavigationResult is nav.NavigationResult
+        e = importlib.import_module("ephemeris")
+        assert e.ephemeris is pkg("ephemeris").ephemeris
     finally:
         sys.path.pop(0)
         sys.modules.pop("postNavigation", None)
+        sys.modules.pop("ephemeris", None)
 
 
 def test_nav_bits_matches_oracle_including_summation_order():
@@ -283,3 +286,37 @@ def test_pseudoranges_match_reference():
     neg = np.array([-1.0, -3.0])
     assert np.array_equal(nav.calculatePseudoranges(neg, [0, 1]),
                           orc.calculate_pseudoranges(so, g["absoluteSample"], neg, [0, 1]))
+
+
+def _eph_case(synth, case):
+    seed, fb, fid, tow0, inv = [int(v) for v in case]
+    tab = synth.nav_message_bits(seed, fb, 2048, tow0, fid)
+    if inv:
+        tab = 1 - tab
+    start = fb if fb > 0 else 300
+    return [str(int(b)) for b in tab[start:start + 1500]], str(int(tab[start - 1])), tab, start
+
+
+def test_ephemeris_decode_matches_reference():
+    """sgx_ephemeris (host code) and the oracle vs the reference's ephemeris.ephemeris on the generator's frames."""
+    import oracle.softgnss_oracle as orc
+    g = load_golden("eph_cases.npz")
+    synth = pkg("synth")
+    eph_mod = pkg("ephemeris")
+    for case, want in zip(g["cases"], g["eph_tow"]):
+        bits, d30, tab, start = _eph_case(synth, case)
+        for fn in (orc.ephemeris, eph_mod.ephemeris):
+            eph, tow = fn(list(bits), d30)
+            assert np.array_equal(np.array(list(eph) + [tow], dtype=np.float64), want), fn
+            assert all(isinstance(eph[i], int) for i in g["int_fields"]) and isinstance(tow, int)
+    bits, d30, tab, start = _eph_case(synth, g["cases"][0])
+    with pytest.raises(TypeError):
+        eph_mod.ephemeris(bits[:1499], d30)
+    with pytest.raises(TypeError):
+        orc.ephemeris(bits[:1499], d30)
+    # five subframes that repeat IDs 4 and 5 only: the reference trips over an unassigned local
+    four = [str(int(b)) for b in np.concatenate([tab[start + 900:start + 1500]] * 3)[:1500]]
+    with pytest.raises(UnboundLocalError):
+        orc.ephemeris(list(four), str(int(tab[start + 899])))
+    with pytest.raises(UnboundLocalError):
+        eph_mod.ephemeris(four, str(int(tab[start + 899])))

@@ -640,3 +640,33 @@ def test_random_scenes_against_oracle(seed):
     a, t = _oracle_vs_gpu(m, s, os_, rec, 40)
     if seed == 13:
         assert t is None and not np.any(a.carrFreq)
+
+
+def test_decode_ephemerides_end_to_end():
+    """32.1 s of a scene with decodable navigation frames: track -> findPreambles -> bits -> sgx_ephemeris; the
+    decoded parameters and TOW must be the ones the generator transmitted (decoded from its bit table directly by
+    the oracle, which is pinned on the reference's ephemeris())."""
+    g = load_golden("nav_preambles.npz")
+    m = pkg()
+    s = _nav_settings(m)
+    s.msToProcess = 32100.0
+    ctx = m.engine.get_context(s, 0)
+    sc = scene_from_json(g["scene"]).with_nav_message(first_boundary=100, tow0=4321, first_id=3)
+    rec = ctx.synth(sc, m.synth.record_length(s.samplesPerCode, 32100))
+    a = m.AcquisitionResult(s, device=0)
+    a._channels = np.rec.fromarrays([g["ch_PRN"], g["ch_acquiredFreq"], g["ch_codePhase"], ['T', 'T']],
+                                    names='PRN,acquiredFreq,codePhase,status')
+    t = m.TrackingResult(a, device=0)
+    t.track(m.DeviceFile(rec))
+    rec.free()
+    nav = m.NavigationResult(t, device=0)
+    eph, tow, first, active = nav.decodeEphemerides()
+    assert list(first) == [1999, 1999] and list(active) == [0, 1]
+    assert tow == (4321 + 1 + 4) * 6 - 30
+    for ch, prn in enumerate(g["ch_PRN"]):
+        tab = sc.nav_bits[ch]
+        want, tow_w = orc.ephemeris([str(int(b)) for b in tab[100:1600]], str(int(tab[99])))
+        got = tuple(eph[int(prn) - 1])
+        assert got == want and tow_w == tow
+        assert isinstance(got[0], int) and isinstance(got[3], float)
+    assert eph[0].IODC is None      # PRN 1 was not tracked
