@@ -218,6 +218,25 @@ int sgx_pseudoranges(const double* absoluteSample, int32_t n_rows, int32_t ms, c
                      const int32_t* channelList, int32_t n_list, int32_t numberOfChannels, int64_t samplesPerCode,
                      double startOffset, double c_mps, double* pseudoranges);
 
+/* ---- next row: satellite positions and the least-squares fix (geoFunctions/__init__.py); scalar host code -------
+ * eph is [32][SGX_EPH_FIELDS] in sgx_ephemeris order, row PRN-1.  Angles in degrees where the reference's are. */
+int sgx_check_t(double time, double* corrTime);                                  /* geoFunctions/__init__.py:745-771 */
+int sgx_e_r_corr(double traveltime, const double* X_sat, double* X_sat_rot);     /* :491-523, 3-vectors */
+int sgx_togeod(double a, double finv, double X, double Y, double Z, double* dphi, double* dlambda, double* h); /* :892-996 */
+int sgx_topocent(const double* X, const double* dx, double* Az, double* El, double* D);                      /* :1003-1064 */
+int sgx_tropo(double sinel, double hsta, double p, double tkel, double hum, double hp, double htkel, double hhum,
+              double* ddr);                                                                                 /* :1071-1186 */
+/* satpos (:779-885): satPositions [3][n] (row-major, one column per entry of prnList), satClkCorr [n] seconds */
+int sgx_satpos(double transmitTime, const int32_t* prnList, int32_t n, const double* eph, double* satPositions,
+               double* satClkCorr);
+/* leastSquarePos (:636-739): satpos [3][n], obs [n] metres; pos[4] = X Y Z dt, el / az [n], dop[5] = G P H V T.
+ * *rank_deficient = 1 where the reference gives up (matrix_rank(A) != 4) and returns a zero position. */
+int sgx_least_square_pos(const double* satpos, const double* obs, int32_t n, double c_mps, int32_t useTropCorr,
+                         double* pos, double* el, double* az, double* dop, int32_t* rank_deficient);
+int sgx_cart2geo(double X, double Y, double Z, int32_t i, double* phi, double* lambda_, double* h);   /* :7-77 */
+int sgx_find_utm_zone(double latitude, double longitude, int32_t* utmZone);                          /* :529-571 */
+int sgx_cart2utm(double X, double Y, double Z, int32_t zone, double* E, double* N, double* U);      /* :176-372 */
+
 /* ---- RCCL peak gather (multi-GPU acquisition shard) ------------------
  * One process per GPU.  Rank 0 calls sgx_comm_unique_id and ships the 128 bytes to the other
  * ranks by any host channel; every rank then calls sgx_comm_create.  sgx_comm_allgather

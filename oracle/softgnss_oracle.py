@@ -492,3 +492,287 @@ def ephemeris(bits, d30star):
     if missing:
         raise UnboundLocalError("local variable '%s' referenced before assignment" % missing[0])
     return tuple(f[k] for k in names), tow
+
+
+# ---- next row: satellite positions and least-squares fix (reference geoFunctions/__init__.py) -------------------
+EPH_NAMES = ('weekNumber', 'accuracy', 'health', 'T_GD', 'IODC', 't_oc', 'a_f2', 'a_f1', 'a_f0', 'IODE_sf2', 'C_rs',
+             'deltan', 'M_0', 'C_uc', 'e', 'C_us', 'sqrtA', 't_oe', 'C_ic', 'omega_0', 'C_is', 'i_0', 'C_rc', 'omega',
+             'omegaDot', 'IODE_sf3', 'iDot')
+
+
+def check_t(t):
+    """geoFunctions/__init__.py:745-771: fold a time difference into +-half a week."""
+    half = 302400.0
+    if t > half:
+        return t - 2 * half
+    if t < -half:
+        return t + 2 * half
+    return t
+
+
+def e_r_corr(traveltime, x_sat):
+    """geoFunctions/__init__.py:491-523."""
+    w = 7.292115147e-05 * traveltime
+    r3 = np.array([[np.cos(w), np.sin(w), 0.0], [-np.sin(w), np.cos(w), 0.0], [0.0, 0.0, 1.0]])
+    return r3.dot(x_sat)
+
+
+def togeod(a, finv, X, Y, Z):
+    """geoFunctions/__init__.py:892-996: (latitude deg, longitude deg, height)."""
+    rtd = 180 / np.pi
+    esq = 0.0 if finv < 1e-20 else (2 - 1 / finv) / finv
+    oneesq = 1 - esq
+    P = np.sqrt(X ** 2 + Y ** 2)
+    dlambda = np.arctan2(Y, X) * rtd if P > 1e-20 else 0.0
+    if dlambda < 0:
+        dlambda = dlambda + 360
+    r = np.sqrt(P ** 2 + Z ** 2)
+    sinphi = Z / r if r > 1e-20 else 0.0
+    dphi = np.arcsin(sinphi)
+    if r < 1e-20:
+        return dphi, dlambda, 0.0
+    h = r - a * (1 - sinphi * sinphi / finv)
+    for _ in range(10):
+        sinphi = np.sin(dphi)
+        cosphi = np.cos(dphi)
+        n_phi = a / np.sqrt(1 - esq * sinphi * sinphi)
+        dP = P - (n_phi + h) * cosphi
+        dZ = Z - (n_phi * oneesq + h) * sinphi
+        h = h + sinphi * dZ + cosphi * dP
+        dphi = dphi + (cosphi * dZ - sinphi * dP) / (n_phi + h)
+        if (dP * dP + dZ * dZ) < 1e-10:
+            break
+    return dphi * rtd, dlambda, h
+
+
+def topocent(X, dx):
+    """geoFunctions/__init__.py:1003-1064: (Az deg, El deg, distance)."""
+    dtr = np.pi / 180
+    phi, lam, _ = togeod(6378137, 298.257223563, X[0], X[1], X[2])
+    cl, sl = np.cos(lam * dtr), np.sin(lam * dtr)
+    cb, sb = np.cos(phi * dtr), np.sin(phi * dtr)
+    F = np.array([[-sl, -sb * cl, cb * cl], [cl, -sb * sl, cb * sl], [0.0, cb, sb]])
+    E, N, U = F.T.dot(dx)
+    hor = np.sqrt(E ** 2 + N ** 2)
+    if hor < 1e-20:
+        az, el = 0.0, 90.0
+    else:
+        az = np.arctan2(E, N) / dtr
+        el = np.arctan2(U, hor) / dtr
+    if az < 0:
+        az = az + 360
+    return az, el, np.sqrt(dx[0] ** 2 + dx[1] ** 2 + dx[2] ** 2)
+
+
+def tropo(sinel, hsta, p, tkel, hum, hp, htkel, hhum):
+    """geoFunctions/__init__.py:1071-1186 (Goad & Goodman): tropospheric range correction, metres."""
+    a_e, b0, tlapse = 6378.137, 7.839257e-05, -6.5
+    tkhum = tkel + tlapse * (hhum - htkel)
+    atkel = 7.5 * (tkhum - 273.15) / (237.3 + tkhum - 273.15)
+    e0 = 0.0611 * hum * 10 ** atkel
+    tksea = tkel - tlapse * htkel
+    em = -978.77 / (2870400.0 * tlapse * 1e-05)
+    e0sea = e0 * (tksea / (tksea + tlapse * hhum)) ** (4 * em)
+    psea = p * (tksea / (tksea + tlapse * hp)) ** em
+    if sinel < 0:
+        sinel = 0
+    total = 0.0
+    refsea = 7.7624e-05 / tksea
+    htop = 1.1385e-05 / refsea
+    refsea = refsea * psea
+    ref = refsea * ((htop - hsta) / htop) ** 4
+    for second in (False, True):
+        rtop = (a_e + htop) ** 2 - (a_e + hsta) ** 2 * (1 - sinel ** 2)
+        if rtop < 0:
+            rtop = 0
+        rtop = np.sqrt(rtop) - (a_e + hsta) * sinel
+        a = -sinel / (htop - hsta)
+        b = -b0 * (1 - sinel ** 2) / (htop - hsta)
+        rn = np.array([rtop ** (i + 2) for i in range(8)])
+        alpha = np.array([2 * a, 2 * a ** 2 + 4 * b / 3, a * (a ** 2 + 3 * b),
+                          a ** 4 / 5 + 2.4 * a ** 2 * b + 1.2 * b ** 2, 2 * a * b * (a ** 2 + 3 * b) / 3,
+                          b ** 2 * (6 * a ** 2 + 4 * b) * 0.1428571, 0, 0])
+        if b ** 2 > 1e-35:
+            alpha[6] = a * b ** 3 / 2
+            alpha[7] = b ** 4 / 9
+        total += (rtop + alpha.dot(rn)) * ref * 1000
+        if second:
+            break
+        refsea = (0.3719 / tksea - 1.292e-05) / tksea
+        htop = 1.1385e-05 * (1255.0 / tksea + 0.05) / refsea
+        ref = refsea * e0sea * ((htop - hsta) / htop) ** 4
+    return total
+
+
+def satpos(transmit_time, prn_list, eph_table):
+    """geoFunctions/__init__.py:779-885.  eph_table: float [32][27] (EPH_NAMES order) -> (positions [3, n], clock s)."""
+    gps_pi = 3.14159265359
+    omegae_dot, GM, F = 7.2921151467e-05, 3.986005e+14, -4.442807633e-10
+    n = len(prn_list)
+    clk = np.zeros(n)
+    pos = np.zeros((3, n))
+    for k in range(n):
+        q = dict(zip(EPH_NAMES, [float(v) for v in eph_table[int(prn_list[k]) - 1]]))
+        dt = check_t(transmit_time - q['t_oc'])
+        clk[k] = (q['a_f2'] * dt + q['a_f1']) * dt + q['a_f0'] - q['T_GD']
+        time = transmit_time - clk[k]
+        a = q['sqrtA'] * q['sqrtA']
+        tk = check_t(time - q['t_oe'])
+        n0 = np.sqrt(GM / a ** 3)
+        M = q['M_0'] + (n0 + q['deltan']) * tk
+        M = np.remainder(M + 2 * gps_pi, 2 * gps_pi)
+        E = M
+        for _ in range(10):
+            E_old = E
+            E = M + q['e'] * np.sin(E)
+            if abs(np.remainder(E - E_old, 2 * gps_pi)) < 1e-12:
+                break
+        E = np.remainder(E + 2 * gps_pi, 2 * gps_pi)
+        dtr = F * q['e'] * q['sqrtA'] * np.sin(E)
+        nu = np.arctan2(np.sqrt(1 - q['e'] ** 2) * np.sin(E), np.cos(E) - q['e'])
+        phi = np.remainder(nu + q['omega'], 2 * gps_pi)
+        u = phi + q['C_uc'] * np.cos(2 * phi) + q['C_us'] * np.sin(2 * phi)
+        r = a * (1 - q['e'] * np.cos(E)) + q['C_rc'] * np.cos(2 * phi) + q['C_rs'] * np.sin(2 * phi)
+        i = q['i_0'] + q['iDot'] * tk + q['C_ic'] * np.cos(2 * phi) + q['C_is'] * np.sin(2 * phi)
+        Om = q['omega_0'] + (q['omegaDot'] - omegae_dot) * tk - omegae_dot * q['t_oe']
+        Om = np.remainder(Om + 2 * gps_pi, 2 * gps_pi)
+        pos[0, k] = np.cos(u) * r * np.cos(Om) - np.sin(u) * r * np.cos(i) * np.sin(Om)
+        pos[1, k] = np.cos(u) * r * np.sin(Om) + np.sin(u) * r * np.cos(i) * np.cos(Om)
+        pos[2, k] = np.sin(u) * r * np.sin(i)
+        clk[k] = (q['a_f2'] * dt + q['a_f1']) * dt + q['a_f0'] - q['T_GD'] + dtr
+    return pos, clk
+
+
+def least_square_pos(sat, obs, c, use_trop):
+    """geoFunctions/__init__.py:636-739 -> (pos, el, az, dop); pos is zeros((4, 1)) for rank-deficient geometry."""
+    dtr = np.pi / 180
+    pos = np.zeros(4)
+    n = sat.shape[1]
+    A = np.zeros((n, 4))
+    omc = np.zeros(n)
+    az, el, dop = np.zeros(n), np.zeros(n), np.zeros(5)
+    for it in range(7):
+        for i in range(n):
+            if it == 0:
+                rot = sat[:, i].copy()
+                trop = 2
+            else:
+                rho2 = (sat[0, i] - pos[0]) ** 2 + (sat[1, i] - pos[1]) ** 2 + (sat[2, i] - pos[2]) ** 2
+                rot = e_r_corr(np.sqrt(rho2) / c, sat[:, i])
+                az[i], el[i], _ = topocent(pos[0:3], rot - pos[0:3])
+                trop = tropo(np.sin(el[i] * dtr), 0.0, 1013.0, 293.0, 50.0, 0.0, 0.0, 0.0) if use_trop else 0
+            omc[i] = obs[i] - np.linalg.norm(rot - pos[0:3]) - pos[3] - trop
+            A[i, :] = np.array([-(rot[0] - pos[0]) / obs[i], -(rot[1] - pos[1]) / obs[i], -(rot[2] - pos[2]) / obs[i], 1])
+        if np.linalg.matrix_rank(A) != 4:
+            return np.zeros((4, 1)), el, az, dop
+        pos = pos + np.linalg.lstsq(A, omc, rcond=None)[0].flatten()
+    Q = np.linalg.inv(A.T.dot(A))
+    dop[:] = [np.sqrt(np.trace(Q)), np.sqrt(Q[0, 0] + Q[1, 1] + Q[2, 2]), np.sqrt(Q[0, 0] + Q[1, 1]), np.sqrt(Q[2, 2]),
+              np.sqrt(Q[3, 3])]
+    return pos, el, az, dop
+
+
+def cart2geo(X, Y, Z, i):
+    """geoFunctions/__init__.py:7-77 -> (phi deg, lambda deg, h)."""
+    a = [6378388.0, 6378160.0, 6378135.0, 6378137.0, 6378137.0][i]
+    f = [1 / 297, 1 / 298.247, 1 / 298.26, 1 / 298.257222101, 1 / 298.257223563][i]
+    lam = np.arctan2(Y, X)
+    ex2 = (2 - f) * f / ((1 - f) ** 2)
+    c = a * np.sqrt(1 + ex2)
+    phi = np.arctan(Z / (np.sqrt(X ** 2 + Y ** 2) * (1 - (2 - f)) * f))
+    h, oldh, it = 0.1, 0, 0
+    while abs(h - oldh) > 1e-12:
+        oldh = h
+        N = c / np.sqrt(1 + ex2 * np.cos(phi) ** 2)
+        phi = np.arctan(Z / (np.sqrt(X ** 2 + Y ** 2) * (1 - (2 - f) * f * N / (N + h))))
+        h = np.sqrt(X ** 2 + Y ** 2) / np.cos(phi) - N
+        it += 1
+        if it > 100:
+            break
+    return phi * (180 / np.pi), lam * (180 / np.pi), h
+
+
+def find_utm_zone(latitude, longitude):
+    """geoFunctions/__init__.py:529-571."""
+    if longitude > 180 or longitude < -180:
+        raise IOError('Longitude value exceeds limits (-180:180).')
+    if latitude > 84 or latitude < -80:
+        raise IOError('Latitude value exceeds limits (-80:84).')
+    zone = np.fix((180 + longitude) / 6) + 1
+    if latitude > 72:
+        for lo, hi, z in ((0, 9, 31), (9, 21, 33), (21, 33, 35), (33, 42, 37)):
+            if lo <= longitude < hi:
+                zone = z
+    elif 56 <= latitude < 64 and 3 <= longitude < 12:
+        zone = 32
+    return zone
+
+
+def _clsin(ar, degree, argument):
+    cos_arg = 2 * np.cos(argument)
+    hr1 = hr = 0
+    for t in range(degree, 0, -1):
+        hr2, hr1 = hr1, hr
+        hr = ar[t - 1] + cos_arg * hr1 - hr2
+    return hr * np.sin(argument)
+
+
+def _clksin(ar, degree, arg_real, arg_imag):
+    sr, cr = np.sin(arg_real), np.cos(arg_real)
+    shi, chi = np.sinh(arg_imag), np.cosh(arg_imag)
+    r = 2 * cr * chi
+    i = -2 * sr * shi
+    hr1 = hr = hi1 = hi = 0
+    for t in range(degree, 0, -1):
+        hr2, hr1, hi2, hi1 = hr1, hr, hi1, hi
+        z = ar[t - 1] + r * hr1 - i * hi - hr2
+        hi = i * hr1 + r * hi1 - hi2
+        hr = z
+    r = sr * chi
+    i = cr * shi
+    return r * hr - i * hi, r * hi + i * hr
+
+
+def cart2utm(X, Y, Z, zone):
+    """geoFunctions/__init__.py:176-372 -> (E, N, U) on the International 1924 ellipsoid (ED50 shift applied)."""
+    a, f = 6378388.0, 1.0 / 297.0
+    ex2 = (2 - f) * f / (1 - f) ** 2
+    c = a * np.sqrt(1 + ex2)
+    vec = np.array([X, Y, Z - 4.5])
+    alpha = 7.56e-07
+    R = np.array([[1, -alpha, 0], [alpha, 1, 0], [0, 0, 1]])
+    v = 0.9999988 * R.dot(vec) + np.array([89.5, 93.8, 127.6])
+    L = np.arctan2(v[1], v[0])
+    N1 = 6395000.0
+    B = np.arctan2(v[2] / ((1 - f) ** 2 * N1), np.linalg.norm(v[0:2]) / N1)
+    U, oldU, it = 0.1, 0, 0
+    while abs(U - oldU) > 0.0001:
+        oldU = U
+        N1 = c / np.sqrt(1 + ex2 * (np.cos(B)) ** 2)
+        B = np.arctan2(v[2] / ((1 - f) ** 2 * N1 + U), np.linalg.norm(v[0:2]) / (N1 + U))
+        U = np.linalg.norm(v[0:2]) / np.cos(B) - N1
+        it += 1
+        if it > 100:
+            break
+    m0 = 0.0004
+    n = f / (2 - f)
+    m = n ** 2 * (1.0 / 4.0 + n ** 2 / 64)
+    Q_n = a + (a * (-n - m0 + m * (1 - m0))) / (1 + n)
+    L0 = ((zone - 30) * 6 - 3) * np.pi / 180
+    bg = np.array([-0.00337077907, 4.73444769e-06, -8.2991457e-09, 1.5878533e-11])
+    gtu = np.array([0.000841275991, 7.67306686e-07, 1.2129123e-09, 2.48508228e-12])
+    neg = B < 0
+    Bg = np.abs(B)
+    Bg = Bg + _clsin(bg, 4, 2 * Bg)
+    Lg = L - L0
+    cos_bn = np.cos(Bg)
+    Np = np.arctan2(np.sin(Bg), np.cos(Lg) * cos_bn) * 2
+    Ep = np.arctanh(np.sin(Lg) * cos_bn) * 2
+    dN, dE = _clksin(gtu, 4, Np, Ep)
+    Np = Np / 2 + dN
+    Ep = Ep / 2 + dE
+    N = Q_n * Np
+    E = Q_n * Ep + 500000.0
+    if neg:
+        N = -N + 20000000
+    return E, N, U

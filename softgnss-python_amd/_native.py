@@ -84,6 +84,16 @@ _PROTOS = {
     "sgx_probe_stats": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, C.c_double, _P, _P, _P, C.POINTER(C.c_int32)]),
     "sgx_find_preambles": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "sgx_nav_parity_check": (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    "sgx_check_t": (C.c_int, [C.c_double, _P]),
+    "sgx_e_r_corr": (C.c_int, [C.c_double, _P, _P]),
+    "sgx_togeod": (C.c_int, [C.c_double] * 5 + [_P, _P, _P]),
+    "sgx_topocent": (C.c_int, [_P] * 5),
+    "sgx_tropo": (C.c_int, [C.c_double] * 8 + [_P]),
+    "sgx_satpos": (C.c_int, [C.c_double, _P, C.c_int32, _P, _P, _P]),
+    "sgx_least_square_pos": (C.c_int, [_P, _P, C.c_int32, C.c_double, C.c_int32, _P, _P, _P, _P, _P]),
+    "sgx_cart2geo": (C.c_int, [C.c_double] * 3 + [C.c_int32, _P, _P, _P]),
+    "sgx_find_utm_zone": (C.c_int, [C.c_double, C.c_double, _P]),
+    "sgx_cart2utm": (C.c_int, [C.c_double] * 3 + [C.c_int32, _P, _P, _P]),
     "sgx_ephemeris": (C.c_int, [_P, C.c_int32, C.c_uint8, _P, C.POINTER(C.c_int64)]),
     "sgx_pseudoranges": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int64, C.c_double,
                                    C.c_double, _P]),

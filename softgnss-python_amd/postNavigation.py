@@ -1,10 +1,11 @@
-"""NavigationResult with the reference's interface, limited to the stage next to the accelerated path:
-bit synchronisation and preamble search on the tracking output (reference postNavigation.py:443-631).
+"""NavigationResult with the reference's interface (reference postNavigation.py): what happens to the tracking
+output after the accelerated path.
 
 findPreambles(), navPartyChk(), the bit integration and calculatePseudoranges() are answered by libsgx.so
-(sgx_find_preambles, sgx_nav_parity_check, sgx_nav_bits, sgx_pseudoranges); decodeEphemerides() runs the first half
-of postNavigate (preambles -> bits -> sgx_ephemeris).  Satellite positions and the least-squares position
-solution (the rest of postNavigate, plot) stay in the reference: they are scalar, millisecond-rate code outside this engine's scope.
+(sgx_find_preambles - the one device kernel of this stage -, sgx_nav_parity_check, sgx_nav_bits, sgx_pseudoranges);
+decodeEphemerides() runs the first half of postNavigate (preambles -> bits -> sgx_ephemeris); postNavigate() the
+whole chain down to the position fix (geoFunctions.py -> sgx_satpos, sgx_least_square_pos, ...).  Everything after
+the preamble correlation is scalar, millisecond-rate host code.  Only plot() is left to the reference.
 """
 from __future__ import print_function
 
@@ -85,9 +86,80 @@ class NavigationResult(Result):
         return eph, TOW, subFrameStart, activeChnList
 
     def postNavigate(self):
-        raise NotImplementedError("satellite positions and the least-squares fix stay in the reference "
-                                  "(postNavigation.py:150-305, geoFunctions); decodeEphemerides() covers "
-                                  "postNavigation.py:113-147")
+        """Navigation solutions of reference postNavigation.py:75-305: subframe starts, ephemerides, then every
+        navSolPeriod ms pseudoranges -> satellite positions -> least-squares position -> geodetic / UTM.
+        Results in self.solutions (the reference's nested recarray, 64 measurement columns) and self.ephemeris.
+        The arithmetic runs in libsgx.so (sgx_find_preambles, sgx_nav_bits, sgx_ephemeris, sgx_pseudoranges,
+        sgx_satpos, sgx_least_square_pos, sgx_cart2geo, sgx_find_utm_zone, sgx_cart2utm)."""
+        from .geoFunctions import satpos, leastSquarePos, cart2geo, findUtmZone, cart2utm
+        trackResults = self._results
+        settings = self._settings
+        status = trackResults.status
+        n_tracked = int(np.sum(status != (b'-' if status.dtype.kind == 'S' else '-')))
+        if settings.msToProcess < 36000 or n_tracked < 4:
+            print('Record is to short or too few satellites tracked. Exiting!')
+            self._solutions = None
+            self._eph = None
+            return
+        eph, TOW, subFrameStart, activeChnList = self.decodeEphemerides()
+        if activeChnList.size == 0 or activeChnList.size < 4:
+            print('Too few satellites with ephemeris data for position calculations. Exiting!')
+            self._solutions = None
+            self._eph = None
+            return
+        nch = settings.numberOfChannels
+        satElev = np.inf * np.ones(nch)
+        readyChnList = activeChnList.copy()
+        transmitTime = TOW
+        channel = np.rec.array([(np.zeros((nch, 64)), np.nan * np.ones((nch, 64)), np.nan * np.ones((nch, 64)),
+                                 np.nan * np.ones((nch, 64)), np.nan * np.ones((nch, 64)))],
+                               formats=['O'] * 5, names='PRN,el,az,rawP,correctedP')
+        nan64 = lambda: np.nan * np.ones(64)   # noqa: E731
+        navSolutions = np.rec.array([(channel, np.zeros((5, 64)), nan64(), nan64(), nan64(), nan64(), nan64(), nan64(),
+                                      nan64(), 0, nan64(), nan64(), nan64())], formats=['O'] * 13,
+                                    names='channel,DOP,X,Y,Z,dt,latitude,longitude,height,utmZone,E,N,U')
+        sol = navSolutions[0]
+        for currMeasNr in range(int(np.fix(settings.msToProcess - subFrameStart.max()) / settings.navSolPeriod)):
+            activeChnList = np.intersect1d((satElev >= settings.elevationMask).nonzero()[0], readyChnList)
+            channel[0].PRN[activeChnList, currMeasNr] = trackResults[activeChnList].PRN
+            channel[0].rawP[:, currMeasNr] = self.calculatePseudoranges(
+                subFrameStart + settings.navSolPeriod * currMeasNr, activeChnList)
+            satPositions, satClkCorr = satpos(transmitTime, trackResults[activeChnList].PRN, eph, settings)
+            if activeChnList.size > 3:
+                (xyzdt, channel[0].el[activeChnList, currMeasNr], channel[0].az[activeChnList, currMeasNr],
+                 sol.DOP[:, currMeasNr]) = leastSquarePos(
+                    satPositions, channel[0].rawP[activeChnList, currMeasNr] + satClkCorr * settings.c, settings)
+                xyzdt = np.asarray(xyzdt).reshape(-1)
+                sol.X[currMeasNr], sol.Y[currMeasNr], sol.Z[currMeasNr], sol.dt[currMeasNr] = xyzdt[:4]
+                satElev = channel[0].el[:, currMeasNr]
+                channel[0].correctedP[activeChnList, currMeasNr] = \
+                    channel[0].rawP[activeChnList, currMeasNr] + satClkCorr * settings.c + sol.dt[currMeasNr]
+                (sol.latitude[currMeasNr], sol.longitude[currMeasNr], sol.height[currMeasNr]) = cart2geo(
+                    sol.X[currMeasNr], sol.Y[currMeasNr], sol.Z[currMeasNr], 4)
+                sol.utmZone = findUtmZone(sol.latitude[currMeasNr], sol.longitude[currMeasNr])
+                (sol.E[currMeasNr], sol.N[currMeasNr], sol.U[currMeasNr]) = cart2utm(xyzdt[0], xyzdt[1], xyzdt[2],
+                                                                                     sol.utmZone)
+            else:
+                print('   Measurement No. %d' % currMeasNr + ': Not enough information for position solution.')
+                for name in ('X', 'Y', 'Z', 'dt', 'latitude', 'longitude', 'height', 'E', 'N', 'U'):
+                    sol[name][currMeasNr] = np.nan
+                sol.DOP[:, currMeasNr] = np.zeros(5)
+                channel[0].az[activeChnList, currMeasNr] = np.nan * np.ones(activeChnList.shape)
+                channel[0].el[activeChnList, currMeasNr] = np.nan * np.ones(activeChnList.shape)
+            transmitTime += settings.navSolPeriod / 1000
+        self._solutions = navSolutions
+        self._eph = eph
+        return
+
+    @property
+    def solutions(self):
+        assert isinstance(self._solutions, np.recarray)
+        return self._solutions
+
+    @property
+    def ephemeris(self):
+        assert isinstance(self._solutions, np.recarray)
+        return self._eph
 
     def calculatePseudoranges(self, msOfTheSignal, channelList):
         """Relative pseudoranges (metres, +inf for channels not in channelList) at millisecond

@@ -104,16 +104,76 @@ def subframe_bits(seed, first_boundary=100, n_bits=NAV_TABLE_BITS):
     return np.array(out[skip:skip + n_bits], dtype=np.uint8)
 
 
-def nav_message_bits(seed, first_boundary=100, n_bits=NAV_TABLE_BITS, tow0=1000, first_id=1):
+GPS_PI = 3.1415926535898            # the value the navigation message is scaled with (IS-GPS-200)
+
+# (name, scale exponent, times pi, signed, bit slices in the 300-bit subframe) per subframe, laid out where the
+# reference's decoder reads them (reference ephemeris.py:106-175, which departs from IS-GPS-200 for IODC / T_GD)
+EPH_LAYOUT = {
+    1: [("weekNumber", 0, 0, 0, [(60, 70)]), ("accuracy", 0, 0, 0, [(72, 76)]), ("health", 0, 0, 0, [(76, 82)]),
+        ("T_GD", -31, 0, 1, [(195, 204)]), ("t_oc", 4, 0, 0, [(218, 234)]), ("a_f2", -55, 0, 1, [(240, 248)]),
+        ("a_f1", -43, 0, 1, [(248, 264)]), ("a_f0", -31, 0, 1, [(270, 292)])],
+    2: [("IODE_sf2", 0, 0, 0, [(60, 68)]), ("C_rs", -5, 0, 1, [(68, 84)]), ("deltan", -43, 1, 1, [(90, 106)]),
+        ("M_0", -31, 1, 1, [(106, 114), (120, 144)]), ("C_uc", -29, 0, 1, [(150, 166)]),
+        ("e", -33, 0, 0, [(166, 174), (180, 204)]), ("C_us", -29, 0, 1, [(210, 226)]),
+        ("sqrtA", -19, 0, 0, [(226, 234), (240, 264)]), ("t_oe", 4, 0, 0, [(270, 286)])],
+    3: [("C_ic", -29, 0, 1, [(60, 76)]), ("omega_0", -31, 1, 1, [(76, 84), (90, 114)]), ("C_is", -29, 0, 1, [(120, 136)]),
+        ("i_0", -31, 1, 1, [(136, 144), (150, 174)]), ("C_rc", -5, 0, 1, [(180, 196)]),
+        ("omega", -31, 1, 1, [(196, 204), (210, 234)]), ("omegaDot", -43, 1, 1, [(240, 264)]),
+        ("IODE_sf3", 0, 0, 0, [(270, 278)]), ("iDot", -43, 1, 1, [(278, 292)])],
+}
+
+
+def make_ephemeris(seed, toe=100800, week=1900):
+    """Plausible GPS orbit / clock parameters (dict, reference field names) from a seed: near-circular 26 560 km
+    orbit at 55 degrees inclination, random node / perigee / anomaly."""
+    import random
+    rng = random.Random(int(seed) ^ 0x657068)
+    pi = GPS_PI
+    return dict(weekNumber=week, accuracy=1, health=0, T_GD=rng.uniform(-1.2e-8, 1.2e-8), t_oc=toe,
+                a_f2=0.0, a_f1=rng.uniform(-1e-11, 1e-11), a_f0=rng.uniform(-4e-4, 4e-4),
+                IODE_sf2=rng.randrange(256), C_rs=rng.uniform(-120, 120), deltan=rng.uniform(4.0e-9, 5.2e-9),
+                M_0=rng.uniform(-pi, pi), C_uc=rng.uniform(-6e-6, 6e-6), e=rng.uniform(0.002, 0.02),
+                C_us=rng.uniform(-6e-6, 9e-6), sqrtA=5153.65 + rng.uniform(-0.15, 0.15), t_oe=toe,
+                C_ic=rng.uniform(-2e-7, 2e-7), omega_0=rng.uniform(-pi, pi), C_is=rng.uniform(-2e-7, 2e-7),
+                i_0=rng.uniform(0.94, 0.985), C_rc=rng.uniform(180, 330), omega=rng.uniform(-pi, pi),
+                omegaDot=rng.uniform(-8.6e-9, -7.6e-9), IODE_sf3=0, iDot=rng.uniform(-6e-10, 6e-10))
+
+
+def encode_ephemeris(eph):
+    """{1: uint8[300], 2: ..., 3: ...} with the parameter bits set (everything else 0, parity not filled in) so that
+    the reference's decoder returns them, quantised to the message LSBs.  weekNumber is sent modulo 1024."""
+    out = {}
+    for sid, fields in EPH_LAYOUT.items():
+        sub = np.zeros(300, dtype=np.uint8)
+        for name, exp, times_pi, signed, slices in fields:
+            v = eph["IODE_sf2"] if name == "IODE_sf3" else eph[name]
+            if name == "weekNumber":
+                v = v - 1024
+            width = sum(b - a for a, b in slices)
+            q = int(round(v / (GPS_PI if times_pi else 1.0) / 2.0 ** exp))
+            lo, hi = (-(1 << (width - 1)), (1 << (width - 1)) - 1) if signed else (0, (1 << width) - 1)
+            if not lo <= q <= hi:
+                raise ValueError("%s = %r does not fit its %d-bit field" % (name, v, width))
+            q &= (1 << width) - 1
+            pos = [p for a, b in slices for p in range(a, b)]
+            for k, p in enumerate(pos):
+                sub[p] = (q >> (width - 1 - k)) & 1
+        out[sid] = sub
+    return out
+
+
+def nav_message_bits(seed, first_boundary=100, n_bits=NAV_TABLE_BITS, tow0=1000, first_id=1, eph=None):
     """Like subframe_bits, with a decodable frame structure: word 1 = TLM (preamble + 16 message bits), word 2 =
     HOW (17-bit TOW count of the NEXT subframe, 2 flag bits, 3-bit subframe ID cycling 1..5, 2 filler bits), words
-    3-10 random data - so subframes 1, 2 and 3 parse into (random but well-defined) clock and orbit fields.  The
-    subframe that starts at table position first_boundary has ID first_id and announces TOW count tow0 + 1."""
+    3-10 random data - so subframes 1, 2 and 3 parse into (random but well-defined) clock and orbit fields - or,
+    with `eph` (dict of the reference's field names), the encoded parameters in subframes 1-3.  The subframe that
+    starts at table position first_boundary has ID first_id and announces TOW count tow0 + 1."""
     import random
     rng = random.Random(int(seed) ^ 0x6E6176)
     out = []
     d29s = d30s = 0
     n_sub = (n_bits + 300) // 300 + 2
+    fixed = encode_ephemeris(eph) if eph is not None else {}
     # the stream is cut so that table bit first_boundary starts a subframe; k counts subframes from that one
     k0 = -((first_boundary + 299) // 300)              # index of the first generated subframe relative to it
     for k in range(k0, k0 + n_sub):
@@ -126,6 +186,8 @@ def nav_message_bits(seed, first_boundary=100, n_bits=NAV_TABLE_BITS, tow0=1000,
             elif wno == 1:
                 d[:17] = [(tow >> (16 - b)) & 1 for b in range(17)]
                 d[19:22] = [(sid >> 2) & 1, (sid >> 1) & 1, sid & 1]
+            elif sid in fixed:
+                d = [int(b) for b in fixed[sid][30 * wno:30 * wno + 24]]
             w = gps_parity(d, d29s, d30s)
             d29s, d30s = w[28], w[29]
             out.extend(w)
@@ -153,9 +215,11 @@ class Scene(object):
         tab = np.stack([subframe_bits(self.seed * 131 + s["prn"], first_boundary) for s in self.sats])
         return Scene(self.seed, self.sats, self.fs, self.cos_lut, tab)
 
-    def with_nav_message(self, first_boundary=100, tow0=1000, first_id=1):
-        """Same scene with decodable navigation frames (TLM/HOW with subframe IDs and TOW counts, valid parity)."""
-        tab = np.stack([nav_message_bits(self.seed * 137 + s["prn"], first_boundary, NAV_TABLE_BITS, tow0, first_id)
+    def with_nav_message(self, first_boundary=100, tow0=1000, first_id=1, ephs=None):
+        """Same scene with decodable navigation frames (TLM/HOW with subframe IDs and TOW counts, valid parity);
+        ephs: optional {prn: parameter dict} to transmit in subframes 1-3."""
+        tab = np.stack([nav_message_bits(self.seed * 137 + s["prn"], first_boundary, NAV_TABLE_BITS, tow0, first_id,
+                                         None if ephs is None else ephs.get(s["prn"]))
                         for s in self.sats])
         return Scene(self.seed, self.sats, self.fs, self.cos_lut, tab)
 

@@ -169,6 +169,96 @@ def golden_eph(tmp):
     print("eph_cases.npz", np.array(out)[:, [0, 4, 27]])
 
 
+def geodetic_to_ecef(lat_deg, lon_deg, h):
+    a, f = 6378137.0, 1 / 298.257223563
+    e2 = f * (2 - f)
+    la, lo = np.radians(lat_deg), np.radians(lon_deg)
+    n = a / np.sqrt(1 - e2 * np.sin(la) ** 2)
+    return np.array([(n + h) * np.cos(la) * np.cos(lo), (n + h) * np.cos(la) * np.sin(lo), (n * (1 - e2) + h) * np.sin(la)])
+
+
+GEO_SITES = [(40.0, -105.2, 1650.0), (-33.9, 151.2, 30.0), (78.2, 15.6, 10.0), (60.4, 5.3, 50.0), (1.3, 103.8, 15.0),
+             (-54.8, -68.3, 20.0)]
+
+
+def golden_geo(tmp, initialize):
+    """13: satpos / leastSquarePos / cart2geo / findUtmZone / cart2utm and their helpers (geoFunctions/__init__.py)
+    on transmitted-and-decoded ephemerides of synthetic constellations."""
+    with Quiet():
+        import ephemeris
+        import geoFunctions as gf
+    s = initialize.Settings()
+    out = {}
+    cases = []
+    for ci, (lat, lon, hgt) in enumerate(GEO_SITES):
+        rx = geodetic_to_ecef(lat, lon, hgt)
+        tow = 100800 + 6 * ci
+        eph = np.recarray((32,), formats=['O'] * 27, names=','.join(
+            'weekNumber,accuracy,health,T_GD,IODC,t_oc,a_f2,a_f1,a_f0,IODE_sf2,C_rs,deltan,M_0,C_uc,e,C_us,sqrtA,t_oe,'
+            'C_ic,omega_0,C_is,i_0,C_rc,omega,omegaDot,IODE_sf3,iDot'.split(',')))
+        tab = np.zeros((32, 27))
+        for prn in range(1, 33):
+            e = synth.make_ephemeris(1000 * ci + prn, toe=100800)
+            bits = synth.nav_message_bits(77 + prn, 0, 2048, 16800, 1, e)
+            eph[prn - 1], _ = ephemeris.ephemeris([str(int(b)) for b in bits[300:1800]], str(int(bits[299])))
+            tab[prn - 1] = [float(v) for v in eph[prn - 1]]
+        prn_all = np.arange(1, 33)
+        pos_all, clk_all = gf.satpos(float(tow), prn_all, eph, s)
+        vis = []
+        for k in range(32):
+            az, el, d = gf.topocent(rx, pos_all[:, k] - rx)
+            if el > 12.0:
+                vis.append(k)
+        vis = np.array(vis[:9])
+        rng = np.random.default_rng(50 + ci)
+        rho = np.linalg.norm(pos_all[:, vis] - rx[:, None], axis=0)
+        obs = rho + 2345.6 * (ci + 1) - clk_all[vis] * s.c + rng.normal(0, 3.0, size=vis.size)
+        s.useTropCorr = (ci != 4)
+        sp = pos_all[:, vis]
+        pos, el, az, dop = gf.leastSquarePos(sp, obs + clk_all[vis] * s.c, s)
+        lat_o, lon_o, h_o = gf.cart2geo(pos[0], pos[1], pos[2], 4)
+        zone = gf.findUtmZone(lat_o, lon_o)
+        E, N, U = gf.cart2utm(pos[0], pos[1], pos[2], zone)
+        cases.append(dict(eph=tab, tow=float(tow), prn=prn_all, sat_all=pos_all, clk_all=clk_all, vis=vis, obs=obs,
+                          trop=int(s.useTropCorr), pos=np.asarray(pos, dtype=np.float64).reshape(-1), el=el, az=az,
+                          dop=dop, geo=np.array([lat_o, lon_o, h_o]), zone=float(zone), utm=np.array([E, N, U]),
+                          rx=rx))
+        print("geo case", ci, "visible", vis.size, "fix error %.1f m" % np.linalg.norm(pos[:3] - rx), "zone", zone)
+    for k in cases[0]:
+        out[k] = np.stack([np.asarray(c[k], dtype=np.float64) if k != "vis" else
+                           np.pad(c[k], (0, 9 - c[k].size), constant_values=-1) for c in cases]) \
+            if k not in ("obs", "el", "az") else np.stack([np.pad(np.asarray(c[k], dtype=np.float64),
+                                                                  (0, 9 - len(c[k])), constant_values=np.nan)
+                                                           for c in cases])
+    # helper vectors
+    s.useTropCorr = True
+    sinels = np.array([-0.2, 0.0, 0.05, 0.3, 0.7, 1.0])
+    out["tropo_sinel"] = sinels
+    out["tropo"] = np.array([gf.tropo(v, 0.0, 1013.0, 293.0, 50.0, 0.0, 0.0, 0.0) for v in sinels])
+    out["tropo_alt"] = np.array([gf.tropo(v, 1.2, 900.0, 280.0, 70.0, 1.0, 1.1, 1.3) for v in sinels])
+    times = np.array([0.0, 302400.0, 302400.5, -302400.5, 604799.0, -604000.0])
+    out["check_t_in"] = times
+    out["check_t"] = np.array([gf.check_t(v) for v in times])
+    xs = cases[0]["sat_all"][:, :6]
+    out["erc"] = np.stack([gf.e_r_corr(0.066 + 0.004 * k, xs[:, k]) for k in range(6)])
+    pts = np.array([geodetic_to_ecef(*g) for g in GEO_SITES] + [[0.0, 0.0, 6356752.0], [6378137.0, 0.0, 0.0]])
+    out["pts"] = pts
+    out["togeod"] = np.array([gf.togeod(6378137, 298.257223563, *p) for p in pts])
+    out["topocent"] = np.array([gf.topocent(pts[k], xs[:, k % 6] - pts[k]) for k in range(len(pts))])
+    out["cart2geo"] = np.array([[gf.cart2geo(p[0], p[1], p[2], i) for i in range(5)] for p in pts[:6]])
+    zone_in = np.array([[10.0, 20.0], [75.0, 5.0], [75.0, 15.0], [75.0, 25.0], [75.0, 35.0], [75.0, 50.0], [60.0, 5.0],
+                        [60.0, 2.0], [-79.0, -179.9], [0.0, 180.0], [84.0, -180.0]])
+    out["zone_in"] = zone_in
+    out["zone_out"] = np.array([gf.findUtmZone(a, b) for a, b in zone_in])
+    # rank-deficient geometry: the reference gives up and returns zeros
+    same = np.tile(cases[0]["sat_all"][:, :1], (1, 5))
+    p0, el0, az0, dop0 = gf.leastSquarePos(same, np.full(5, 2.2e7), s)
+    out["deficient_shape"] = np.array(np.asarray(p0).shape)
+    out["deficient_sum"] = np.float64(np.abs(np.asarray(p0)).sum() + np.abs(dop0).sum())
+    np.savez_compressed(os.path.join(HERE, "geo_cases.npz"), **out)
+    print("geo_cases.npz", {k: v.shape for k, v in out.items() if k in ("eph", "pos", "obs", "togeod")})
+
+
 def golden_probe(tmp, initialize):
     """11: probeData statistics (initialize.py:330-417): Welch PSD and histogram of the first 10 ms."""
     import scipy.signal.windows
@@ -248,7 +338,9 @@ def main():
             golden_probe(tmp, initialize)
         if os.environ.get("SGX_GOLDEN_ONLY", "") in ("", "eph"):
             golden_eph(tmp)
-        if os.environ.get("SGX_GOLDEN_ONLY", "") in ("probe", "eph"):
+        if os.environ.get("SGX_GOLDEN_ONLY", "") in ("", "geo"):
+            golden_geo(tmp, initialize)
+        if os.environ.get("SGX_GOLDEN_ONLY", "") in ("probe", "eph", "geo"):
             return
         if os.environ.get("SGX_GOLDEN_ONLY", "") == "nav":
             golden_nav(tmp, initialize, acquisition, tracking)

@@ -670,3 +670,85 @@ def test_decode_ephemerides_end_to_end():
         assert got == want and tow_w == tow
         assert isinstance(got[0], int) and isinstance(got[3], float)
     assert eph[0].IODC is None      # PRN 1 was not tracked
+
+
+def test_position_fix_from_if_samples():
+    """The whole receiver on a physically consistent scene (tests/nav_scene.py): 37 s of IF samples generated in HBM
+    -> acquisition -> tracking -> preambles -> ephemerides -> pseudoranges -> least squares.  The fix must land
+    on the receiver position the scene was built for, and the decoded ephemerides must be the transmitted ones."""
+    import nav_scene
+    m = pkg()
+    sc, truth = nav_scene.build()
+    s = m.Settings()
+    nsat = len(truth["prns"])
+    s.samplingFreq, s.IF, s.msToProcess, s.numberOfChannels = 16368000.0, 4130400.0, 37000.0, nsat
+    ctx = m.engine.get_context(s, 0)
+    n = s.samplesPerCode
+    rec = ctx.synth(sc, m.synth.record_length(n, 37000))
+    a = m.AcquisitionResult(s, device=0)
+    a.acquire(m.DeviceSignal(rec, 0, 11 * n))
+    a.preRun()
+    assert sorted(int(p) for p in a.channels.PRN) == sorted(truth["prns"]) and truth["gdop"] < 4.0
+    t = m.TrackingResult(a, device=0)
+    t.track(m.DeviceFile(rec))
+    rec.free()
+    nav = m.NavigationResult(t, device=0)
+    nav.postNavigate()
+    sol = nav.solutions[0]
+    n_meas = int((37000 - 5200) / 500)
+    xyz = np.stack([sol.X, sol.Y, sol.Z])[:, :n_meas]
+    assert np.all(np.isfinite(xyz)) and np.all(np.isnan(sol.X[n_meas:]))
+    # truth.  The scene keeps every Doppler constant, so the modelled range is off by up to a*t^2/2 (tens of metres
+    # after half a minute), and the reference's pseudoranges are whole samples (18 m here): the first fixes are
+    # the sharp ones
+    err = np.linalg.norm(xyz - truth["rx"][:, None], axis=0)
+    assert err[:6].max() < 60.0 and np.median(err) < 100.0 and err.max() < 250.0, err
+    assert abs(np.median(sol.latitude[:n_meas]) - truth["site"][0]) < 1e-3
+    assert abs(np.median(sol.longitude[:n_meas]) - truth["site"][1]) < 1e-3
+    assert sol.utmZone == 13 and np.all(sol.DOP[0, :n_meas] > 1.0) and np.all(sol.DOP[0, :n_meas] < 5.0)
+    # parity: the oracle's restatement of the same chain on the same tracking output, several epochs
+    so = orc.OracleSettings(samplingFreq=s.samplingFreq, IF=s.IF, numberOfChannels=nsat, msToProcess=37000.0)
+    rows = [np.asarray(r.absoluteSample, dtype=np.float64) for r in t.results]
+    ip = np.stack([np.asarray(r.I_P, dtype=np.float64) for r in t.results])
+    first, active = orc.find_preambles(ip, ['T'] * nsat, nsat)
+    assert np.array_equal(first, nav.findPreambles()[0]) and np.all(np.abs(first - 5210) <= 12)
+    table = np.zeros((32, 27))
+    tow = None
+    for c_ in active:
+        bits = [str(int(b)) for b in orc.nav_bits(ip[c_], int(first[c_]))]
+        dec, tow = orc.ephemeris(bits[1:], bits[0])
+        table[int(t.results[c_].PRN) - 1] = [float(v) for v in dec]
+    assert tow == truth["tow"]
+    prn_act = [int(t.results[c_].PRN) for c_ in active]
+    for k in (0, 1, 17, 40, n_meas - 1):
+        raw = orc.calculate_pseudoranges(so, rows, first + 500.0 * k, active)
+        sat, clk = orc.satpos(tow + 0.5 * k, prn_act, table)
+        p, el, az, dop = orc.least_square_pos(sat, raw[active] + clk * so.c, so.c, True)
+        assert np.max(np.abs(p[:3] - xyz[:, k])) < 1e-5 and abs(p[3] - sol.dt[k]) < 1e-5
+        assert np.max(np.abs(dop - sol.DOP[:, k])) < 1e-9
+        ch = sol.channel[0]
+        assert np.max(np.abs(ch.rawP[:, k] - raw)) == 0.0
+        assert np.max(np.abs(ch.el[active, k] - el)) < 1e-9 and np.max(np.abs(ch.az[active, k] - az)) < 1e-9
+        lat, lon, h = orc.cart2geo(p[0], p[1], p[2], 4)
+        assert abs(lat - sol.latitude[k]) < 1e-10 and abs(lon - sol.longitude[k]) < 1e-10 and abs(h - sol.height[k]) < 1e-5
+        E, N, U = orc.cart2utm(p[0], p[1], p[2], orc.find_utm_zone(lat, lon))
+        assert abs(E - sol.E[k]) < 1e-5 and abs(N - sol.N[k]) < 1e-5 and abs(U - sol.U[k]) < 1e-5
+    # the tracker against the generator: every code period starts within a sample of where the scene's code NCO
+    # puts it (true arrival of the subframe + whole code periods at the satellite's code rate)
+    for c_ in active:
+        prn = int(t.results[c_].PRN)
+        sat_ = [q for q in sc.sats if q["prn"] == prn][0]
+        arrival = truth["arrival_samples"][truth["prns"].index(prn)]
+        per = 1023.0 * 2 ** 32 / sat_["code_fcw"]                        # samples per code period
+        kk = np.arange(0, 37000 - int(first[c_]))
+        # absoluteSample is the file position AFTER the block (tracking.py:255): the next period's first sample,
+        # i.e. the true boundary rounded up to a whole sample, plus the DLL's jitter
+        d = rows[c_][int(first[c_]):] - (arrival + (kk + 1) * per)
+        assert -0.35 < d.min() and d.max() < 1.35, (prn, d.min(), d.max())
+    for prn in truth["prns"]:
+        got = np.array([float(v) for v in nav.ephemeris[prn - 1]])
+        assert np.array_equal(got, truth["eph_table"][prn - 1])
+    ch = sol.channel[0]
+    assert np.all(np.sort(ch.PRN[:, 0]) == np.sort(truth["prns"]))
+    assert np.all(ch.el[:, 1] > 10.0)
+    print("position error over %d fixes: median %.1f m, max %.1f m" % (n_meas, np.median(err), err.max()))
