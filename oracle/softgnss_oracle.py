@@ -776,3 +776,51 @@ def cart2utm(X, Y, Z, zone):
     if neg:
         N = -N + 20000000
     return E, N, U
+
+
+def post_navigate(s, prn_rows, status_rows, abs_rows, ip_rows, nav_sol_period=500.0, elevation_mask=10.0,
+                  use_trop=True):
+    """postNavigation.py:75-305 on tracking output given as rows (PRN, status, absoluteSample series, I_P series):
+    -> dict with the reference's navSolutions fields (64 measurement columns) or None where the reference gives up."""
+    nch = s.numberOfChannels
+    if s.msToProcess < 36000 or sum(1 for x in status_rows if x != '-') < 4:
+        return None
+    first, active = find_preambles(np.stack(ip_rows), list(status_rows), nch)
+    table = np.zeros((32, len(EPH_NAMES)))
+    tow = None
+    for ch in active:
+        bits = [str(int(b)) for b in nav_bits(ip_rows[ch], int(first[ch]))]
+        dec, tow = ephemeris(bits[1:], bits[0])
+        table[int(prn_rows[ch]) - 1] = [float(v) for v in dec]
+    if active.size < 4:
+        return None
+    out = dict(PRN=np.zeros((nch, 64)), DOP=np.zeros((5, 64)), utmZone=0, firstSubFrame=first, eph=table, TOW=tow)
+    for k in ('el', 'az', 'rawP', 'correctedP'):
+        out[k] = np.nan * np.ones((nch, 64))
+    for k in ('X', 'Y', 'Z', 'dt', 'latitude', 'longitude', 'height', 'E', 'N', 'U'):
+        out[k] = np.nan * np.ones(64)
+    sat_elev = np.inf * np.ones(nch)
+    ready = active.copy()
+    t_tx = tow
+    prn_arr = np.asarray(prn_rows)
+    for m in range(int(np.fix(s.msToProcess - first.max()) / nav_sol_period)):
+        act = np.intersect1d((sat_elev >= elevation_mask).nonzero()[0], ready)
+        out['PRN'][act, m] = prn_arr[act]
+        out['rawP'][:, m] = calculate_pseudoranges(s, abs_rows, first + nav_sol_period * m, act)
+        sat, clk = satpos(t_tx, prn_arr[act], table)
+        if act.size > 3:
+            p, out['el'][act, m], out['az'][act, m], out['DOP'][:, m] = least_square_pos(
+                sat, out['rawP'][act, m] + clk * s.c, s.c, use_trop)
+            p = np.asarray(p).reshape(-1)
+            out['X'][m], out['Y'][m], out['Z'][m], out['dt'][m] = p
+            sat_elev = out['el'][:, m]
+            out['correctedP'][act, m] = out['rawP'][act, m] + clk * s.c + out['dt'][m]
+            out['latitude'][m], out['longitude'][m], out['height'][m] = cart2geo(p[0], p[1], p[2], 4)
+            out['utmZone'] = find_utm_zone(out['latitude'][m], out['longitude'][m])
+            out['E'][m], out['N'][m], out['U'][m] = cart2utm(p[0], p[1], p[2], out['utmZone'])
+        else:
+            out['DOP'][:, m] = 0.0
+            out['az'][act, m] = np.nan
+            out['el'][act, m] = np.nan
+        t_tx += nav_sol_period / 1000
+    return out

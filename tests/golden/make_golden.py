@@ -259,6 +259,56 @@ def golden_geo(tmp, initialize):
     print("geo_cases.npz", {k: v.shape for k, v in out.items() if k in ("eph", "pos", "obs", "togeod")})
 
 
+def golden_fix(tmp, initialize, acquisition, tracking):
+    """14: the reference's whole chain - acquire, preRun, track (37 s, six channels), postNavigate - on the
+    physically consistent scene of tests/nav_scene.py.  Stored: what postNavigate produced, and the tracking output
+    it consumed in compact form (sign of I_P, block lengths), from which the tests rebuild the recarray."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import nav_scene
+    with Quiet():
+        import postNavigation
+    sc, truth = nav_scene.build()
+    s = initialize.Settings()
+    s.samplingFreq, s.IF, s.msToProcess, s.numberOfChannels = 16368000.0, 4130400.0, 37000.0, len(truth["prns"])
+    n = s.samplesPerCode
+    rec = synth.generate(sc, synth.record_length(n, 37000))
+    print("record", rec.size)
+    acq = acquisition.AcquisitionResult(s)
+    with Quiet():
+        acq.acquire(rec[:11 * n])
+        acq.preRun()
+    trk = tracking.TrackingResult(acq)
+    fid = as_file(tmp, "rec_fix.bin", rec)
+    del rec
+    with Quiet():
+        trk.track(fid)
+        nav = postNavigation.NavigationResult(trk)
+        nav.postNavigate()
+    r = trk.results
+    sol = nav.solutions[0]
+    ch = sol.channel[0]
+    eph = nav.ephemeris
+    abs_s = np.stack([np.asarray(x.absoluteSample, dtype=np.int64) for x in r])
+    blk = np.diff(np.concatenate([np.zeros((len(r), 1), dtype=np.int64), abs_s], axis=1), axis=1)
+    ip = np.stack([np.asarray(x.I_P, dtype=np.float64) for x in r])
+    first, active = nav.findPreambles()
+    eph_tab = np.zeros((32, 27))
+    for i in range(32):
+        if eph[i].IODC is not None:
+            eph_tab[i] = [float(v) for v in eph[i]]
+    np.savez_compressed(
+        os.path.join(HERE, "fix_scene.npz"), PRN=np.array([int(x.PRN) for x in r]),
+        ch_acquiredFreq=acq.channels.acquiredFreq, ch_codePhase=acq.channels.codePhase,
+        first_block=blk[:, 0], blk_offset=(blk[:, 1:] - n).astype(np.int8), ip_sign=np.packbits(ip > 0, axis=1),
+        ip_rms=np.sqrt(np.mean(ip ** 2, axis=1)), firstSubFrame=np.asarray(first), activeChnList=np.asarray(active),
+        eph=eph_tab, X=sol.X, Y=sol.Y, Z=sol.Z, dt=sol.dt, latitude=sol.latitude, longitude=sol.longitude,
+        height=sol.height, E=sol.E, N=sol.N, U=sol.U, DOP=sol.DOP, utmZone=np.float64(sol.utmZone),
+        rawP=ch.rawP.astype(np.float64), correctedP=ch.correctedP.astype(np.float64), el=ch.el.astype(np.float64),
+        az=ch.az.astype(np.float64), chPRN=ch.PRN.astype(np.float64), rx=truth["rx"])
+    err = np.linalg.norm(np.stack([sol.X, sol.Y, sol.Z])[:, :63] - truth["rx"][:, None], axis=0)
+    print("fix_scene.npz", first, active, "reference fix error median %.1f m max %.1f m" % (np.median(err), err.max()))
+
+
 def golden_probe(tmp, initialize):
     """11: probeData statistics (initialize.py:330-417): Welch PSD and histogram of the first 10 ms."""
     import scipy.signal.windows
@@ -341,6 +391,9 @@ def main():
         if os.environ.get("SGX_GOLDEN_ONLY", "") in ("", "geo"):
             golden_geo(tmp, initialize)
         if os.environ.get("SGX_GOLDEN_ONLY", "") in ("probe", "eph", "geo"):
+            return
+        if os.environ.get("SGX_GOLDEN_ONLY", "") == "fix":
+            golden_fix(tmp, initialize, acquisition, tracking)
             return
         if os.environ.get("SGX_GOLDEN_ONLY", "") == "nav":
             golden_nav(tmp, initialize, acquisition, tracking)
@@ -470,6 +523,9 @@ def main():
 
         if os.environ.get("SGX_GOLDEN_NAV", "1") == "1":
             golden_nav(tmp, initialize, acquisition, tracking)
+
+        if os.environ.get("SGX_GOLDEN_FIX", "1") == "1":
+            golden_fix(tmp, initialize, acquisition, tracking)
 
         trk2 = tracking.TrackingResult(acq_t)
         short = as_file(tmp, "short.bin", rec[:100 * n])

@@ -229,10 +229,15 @@ def test_navigation_result_surface():
         assert m.NavigationResult is nav.NavigationResult
         e = importlib.import_module("ephemeris")
         assert e.ephemeris is pkg("ephemeris").ephemeris
+        gfm = importlib.import_module("geoFunctions")
+        for name in ("satpos", "leastSquarePos", "cart2geo", "findUtmZone", "cart2utm", "topocent", "togeod", "tropo",
+                     "e_r_corr", "check_t"):
+            assert getattr(gfm, name) is getattr(pkg("geoFunctions"), name)
     finally:
         sys.path.pop(0)
         sys.modules.pop("postNavigation", None)
         sys.modules.pop("ephemeris", None)
+        sys.modules.pop("geoFunctions", None)
 
 
 def test_nav_bits_matches_oracle_including_summation_order():
