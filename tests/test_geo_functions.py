@@ -85,3 +85,43 @@ def test_geo_helpers_match_reference(name, impl):
     same = np.tile(g["sat_all"][0][:, :1], (1, 5))
     p0, el0, az0, dop0 = impl.least_square_pos(same, np.full(5, 2.2e7), _S.c, 1)
     assert np.asarray(p0).shape == tuple(g["deficient_shape"]) and np.abs(np.asarray(p0)).sum() + np.abs(dop0).sum() == 0.0
+
+
+def rebuild_tracking(g, n_code=16368, ms=37000):
+    """(PRN list, status list, absoluteSample rows, I_P rows) of the reference tracker's output, from the compact
+    form stored in fix_scene.npz (block lengths, sign and RMS of I_P)."""
+    blk = np.concatenate([g["first_block"][:, None], g["blk_offset"].astype(np.int64) + n_code], axis=1)
+    abs_rows = np.cumsum(blk, axis=1).astype(np.float64)
+    sign = np.unpackbits(g["ip_sign"], axis=1)[:, :ms].astype(np.float64) * 2 - 1
+    ip_rows = sign * g["ip_rms"][:, None]
+    return [int(p) for p in g["PRN"]], ['T'] * len(g["PRN"]), list(abs_rows), list(ip_rows)
+
+
+def compare_solutions(got, g, tol_m=1e-6):
+    n_meas = int(np.sum(np.isfinite(g["X"])))
+    assert n_meas == 63
+    for k in ("X", "Y", "Z", "dt", "height", "E", "N", "U"):
+        assert np.max(np.abs(np.asarray(got[k], dtype=np.float64)[:n_meas] - g[k][:n_meas])) < tol_m, k
+        assert np.all(np.isnan(np.asarray(got[k], dtype=np.float64)[n_meas:]))
+    for k in ("latitude", "longitude"):
+        assert np.max(np.abs(np.asarray(got[k], dtype=np.float64)[:n_meas] - g[k][:n_meas])) < 1e-10, k
+    assert np.max(np.abs(np.asarray(got["DOP"], dtype=np.float64) - g["DOP"])) < 1e-9
+    for k, name in (("rawP", "rawP"), ("correctedP", "correctedP"), ("el", "el"), ("az", "az")):
+        a, b = np.asarray(got[k], dtype=np.float64), g[name]
+        assert np.array_equal(np.isnan(a), np.isnan(b)), k
+        assert np.nanmax(np.abs(a - b)) < (1e-9 if k in ("el", "az") else tol_m), k
+    assert float(got["utmZone"]) == float(g["utmZone"])
+
+
+def test_oracle_post_navigate_matches_reference():
+    """The whole navigation chain of the oracle on the reference tracker's output vs the reference's postNavigate."""
+    g = load_golden("fix_scene.npz")
+    prn, status, abs_rows, ip_rows = rebuild_tracking(g)
+    so = orc.OracleSettings(samplingFreq=16368000.0, IF=4130400.0, numberOfChannels=len(prn), msToProcess=37000.0)
+    out = orc.post_navigate(so, prn, status, abs_rows, ip_rows)
+    assert np.array_equal(out["firstSubFrame"], g["firstSubFrame"])
+    assert np.array_equal(out["eph"], g["eph"])
+    assert np.array_equal(out["PRN"], g["chPRN"])
+    compare_solutions(out, g)
+    err = np.linalg.norm(np.stack([g["X"], g["Y"], g["Z"]])[:, :63] - g["rx"][:, None], axis=0)
+    assert np.median(err) < 30.0 and err.max() < 80.0          # the reference finds the simulated receiver

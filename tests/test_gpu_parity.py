@@ -752,3 +752,56 @@ def test_position_fix_from_if_samples():
     assert np.all(np.sort(ch.PRN[:, 0]) == np.sort(truth["prns"]))
     assert np.all(ch.el[:, 1] > 10.0)
     print("position error over %d fixes: median %.1f m, max %.1f m" % (n_meas, np.median(err), err.max()))
+    # and the reference itself, run on the host-generated twin of this record (fixture fix_scene.npz: its own
+    # acquisition, tracking and postNavigate): same channels, same block boundaries, same fixes
+    from test_geo_functions import compare_solutions, rebuild_tracking
+    g = load_golden("fix_scene.npz")
+    assert [int(p) for p in t.results.PRN] == [int(p) for p in g["PRN"]]
+    assert np.array_equal(a.channels.acquiredFreq[:nsat], g["ch_acquiredFreq"][:nsat])
+    assert np.array_equal(a.channels.codePhase[:nsat], g["ch_codePhase"][:nsat])
+    _, _, abs_ref, _ = rebuild_tracking(g)
+    assert np.array_equal(np.stack(rows), np.stack(abs_ref))
+    assert np.array_equal(np.packbits(ip > 0, axis=1), g["ip_sign"])
+    assert np.max(np.abs(np.sqrt(np.mean(ip ** 2, axis=1)) / g["ip_rms"] - 1)) < 1e-9
+    assert np.array_equal(np.asarray(first), g["firstSubFrame"])
+    got = {k: sol[k] for k in ("X", "Y", "Z", "dt", "latitude", "longitude", "height", "E", "N", "U", "DOP", "utmZone")}
+    got.update({k: sol.channel[0][k] for k in ("rawP", "correctedP", "el", "az")})
+    compare_solutions(got, g, tol_m=1e-5)
+    assert np.array_equal(sol.channel[0].PRN.astype(np.float64), g["chPRN"])
+
+
+def test_post_navigate_on_reference_tracking_output():
+    """NavigationResult.postNavigate on the tracking output of the reference's own tracker (rebuilt from the compact
+    fixture) against the reference's postNavigate."""
+    from test_geo_functions import compare_solutions, rebuild_tracking
+    g = load_golden("fix_scene.npz")
+    m = pkg()
+    prn, status, abs_rows, ip_rows = rebuild_tracking(g)
+    s = m.Settings()
+    s.samplingFreq, s.IF, s.msToProcess, s.numberOfChannels = 16368000.0, 4130400.0, 37000.0, len(prn)
+
+    class Trk(object):
+        pass
+
+    t = Trk()
+    t.settings, t.channels = s, None
+    t.results = np.recarray((len(prn),), dtype=[('status', 'S1'), ('absoluteSample', 'O'), ('I_P', 'O'), ('PRN', 'i8')])
+    for i in range(len(prn)):
+        t.results[i].status, t.results[i].PRN = b'T', prn[i]
+        t.results[i].absoluteSample, t.results[i].I_P = abs_rows[i], ip_rows[i]
+    nav = m.NavigationResult(t, device=0)
+    nav.postNavigate()
+    sol = nav.solutions[0]
+    got = {k: sol[k] for k in ("X", "Y", "Z", "dt", "latitude", "longitude", "height", "E", "N", "U", "DOP", "utmZone")}
+    got.update({k: sol.channel[0][k] for k in ("rawP", "correctedP", "el", "az")})
+    compare_solutions(got, g, tol_m=1e-5)
+    tab = np.zeros((32, 27))
+    for i in range(32):
+        if nav.ephemeris[i].IODC is not None:
+            tab[i] = [float(v) for v in nav.ephemeris[i]]
+    assert np.array_equal(tab, g["eph"])
+    # too short a record / too few channels: the reference prints a message and leaves the results unset
+    s.msToProcess = 35000.0
+    nav2 = m.NavigationResult(t, device=0)
+    nav2.postNavigate()
+    assert nav2._solutions is None and nav2._eph is None
