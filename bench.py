@@ -39,8 +39,8 @@ def parse():
     ap.add_argument("--many-channels", type=int, default=2048,
                     help="extra leg at N=1: channels of the many-channel (bandwidth-regime) tracking run, 0 = skip")
     ap.add_argument("--many-ms", type=int, default=500)
-    ap.add_argument("--cpu-trk-ms", type=int, default=2500, help="ms of 1-channel oracle tracking timed")
-    ap.add_argument("--cpu-acq-prns", type=int, default=2, help="PRNs of oracle acquisition timed")
+    ap.add_argument("--cpu-trk-ms", type=int, default=8000, help="ms of 1-channel oracle tracking timed")
+    ap.add_argument("--cpu-acq-prns", type=int, default=8, help="PRNs of oracle acquisition timed")
     return ap.parse_args()
 
 
