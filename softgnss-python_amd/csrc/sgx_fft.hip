@@ -57,6 +57,53 @@ __device__ __forceinline__ cplx twiddle(const PassArgs& a, long long t) {
     return cmul(h, l);
 }
 
+// Odd radix: out[k] = v0 + sum_q (a_q c_qk + (b_q.im, -b_q.re) s_qk), out[R-k] with -s, a_q = v[q] + v[R-q],
+// b_q = v[q] - v[R-q].  Outputs are handed to `emit` as they are produced (stored, or squared and max-reduced), so
+// only a, b and four accumulators are live.  Only the roots m = 1..H are touched (cos is even, sin odd in
+// m -> R-m, the sign is a free operand modifier): 4H uniform dwords stay in SGPRs.  With all R-1 roots the
+// radix-31 kernel spilled its scalar registers into VGPR lanes and spent two thirds of its instructions on
+// v_readlane.
+template <int R, class Emit>
+__device__ __forceinline__ void dft_odd_emit(const cplx (&v)[R], const cplx* __restrict__ wr, Emit&& emit) {
+    static_assert(R % 2 == 1, "odd radix expected");
+    constexpr int H = (R - 1) / 2;
+    cplx a[H], b[H];
+#pragma unroll
+    for (int q = 1; q <= H; ++q) {
+        a[q - 1] = cadd(v[q], v[R - q]);
+        b[q - 1] = csub(v[q], v[R - q]);
+    }
+    const cplx v0 = v[0];
+    cplx s0 = v0;
+#pragma unroll
+    for (int q = 0; q < H; ++q) s0 = cadd(s0, a[q]);
+    double wc[H], ws[H];   // cos(2 pi m / R), -sin(2 pi m / R), m = 1..H
+#pragma unroll
+    for (int m = 1; m <= H; ++m) {
+        wc[m - 1] = wr[m].x;
+        ws[m - 1] = wr[m].y;
+    }
+    emit(0, s0);
+#pragma unroll
+    for (int k = 1; k <= H; ++k) {
+        double pr = v0.x, pi = v0.y, qr = 0.0, qi = 0.0;
+#pragma unroll
+        for (int q = 1; q <= H; ++q) {
+            const int m0 = (q * k) % R;
+            const bool lowhalf = m0 <= H;
+            const int m = lowhalf ? m0 : R - m0;
+            const double c = wc[m - 1];
+            const double sy = lowhalf ? ws[m - 1] : -ws[m - 1];   // imaginary part of the root m0
+            pr = __builtin_fma(a[q - 1].x, c, pr);
+            pi = __builtin_fma(a[q - 1].y, c, pi);
+            qr = __builtin_fma(b[q - 1].y, -sy, qr);
+            qi = __builtin_fma(b[q - 1].x, sy, qi);
+        }
+        emit(k, make_double2(pr + qr, pi + qi));
+        emit(R - k, make_double2(pr - qr, pi - qi));
+    }
+}
+
 template <int R>
 __device__ __forceinline__ void dft_small(cplx (&v)[R], const cplx* __restrict__ wr) {
     if constexpr (R == 2) {
@@ -108,34 +155,7 @@ __device__ __forceinline__ void dft_small(cplx (&v)[R], const cplx* __restrict__
             v[k2 + 12] = b3;
         }
     } else {
-        // odd radix: out[k] = v0 + sum_q (a_q c_qk + (b_q.im, -b_q.re) s_qk), out[R-k] with -s
-        static_assert(R % 2 == 1, "odd radix expected");
-        constexpr int H = (R - 1) / 2;
-        cplx a[H], b[H];
-#pragma unroll
-        for (int q = 1; q <= H; ++q) {
-            a[q - 1] = cadd(v[q], v[R - q]);
-            b[q - 1] = csub(v[q], v[R - q]);
-        }
-        const cplx v0 = v[0];
-        cplx s0 = v0;
-#pragma unroll
-        for (int q = 0; q < H; ++q) s0 = cadd(s0, a[q]);
-        v[0] = s0;
-#pragma unroll
-        for (int k = 1; k <= H; ++k) {
-            double pr = v0.x, pi = v0.y, qr = 0.0, qi = 0.0;
-#pragma unroll
-            for (int q = 1; q <= H; ++q) {
-                const cplx w = wr[(q * k) % R];   // (cos, -sin)
-                pr = __builtin_fma(a[q - 1].x, w.x, pr);
-                pi = __builtin_fma(a[q - 1].y, w.x, pi);
-                qr = __builtin_fma(b[q - 1].y, -w.y, qr);
-                qi = __builtin_fma(b[q - 1].x, w.y, qi);
-            }
-            v[k] = make_double2(pr + qr, pi + qi);
-            v[R - k] = make_double2(pr - qr, pi - qi);
-        }
+        dft_odd_emit<R>(v, wr, [&](int q, cplx V) { v[q] = V; });
     }
 }
 
@@ -188,22 +208,28 @@ __global__ __launch_bounds__(TPB) void fft_pass_kernel(PassArgs a) {
             v[q] = cmul(v[q], twiddle(a, t));
         }
     }
-    dft_small<R>(v, a.wr);
     const long long j0 = (j / a.ns) * a.ns * R + k;
+    constexpr bool kEmit = (R % 2 == 1) && (R >= 11);   // large odd radix: consume outputs as they are produced
     if (MODE == 2) {
         // acquisition.py:124-126 abs(ifft(.))**2 for this thread's outputs, then (max, FIRST index)
         double best = -1.0;
         int arg = 0;
+        auto take = [&](int q, cplx V) {
+            const double re = V.x * a.inv_n, im = V.y * a.inv_n;
+            const double pw = re * re + im * im;
+            const int idx = (int)(j0 + q * a.ns);
+            if (pw > best || (pw == best && idx < arg)) {
+                best = pw;
+                arg = idx;
+            }
+        };
         if (live) {
+            if constexpr (kEmit) {
+                dft_odd_emit<R>(v, a.wr, take);
+            } else {
+                dft_small<R>(v, a.wr);
 #pragma unroll
-            for (int q = 0; q < R; ++q) {
-                const double re = v[q].x * a.inv_n, im = v[q].y * a.inv_n;
-                const double pw = re * re + im * im;
-                const int idx = (int)(j0 + q * a.ns);
-                if (pw > best || (pw == best && idx < arg)) {
-                    best = pw;
-                    arg = idx;
-                }
+                for (int q = 0; q < R; ++q) take(q, v[q]);
             }
         }
         __shared__ double s_v[TPB];
@@ -228,8 +254,13 @@ __global__ __launch_bounds__(TPB) void fft_pass_kernel(PassArgs a) {
         }
         return;
     }
+    if constexpr (kEmit) {
+        dft_odd_emit<R>(v, a.wr, [&](int q, cplx V) { out[j0 + q * a.ns] = V; });
+    } else {
+        dft_small<R>(v, a.wr);
 #pragma unroll
-    for (int q = 0; q < R; ++q) out[j0 + q * a.ns] = v[q];
+        for (int q = 0; q < R; ++q) out[j0 + q * a.ns] = v[q];
+    }
 }
 
 // ---- plan -----------------------------------------------------------------------------------
