@@ -185,23 +185,36 @@ class Settings(object):
         return self.probe
 
     def postProcessing(self, fileNameStr=None):
-        """acquire -> preRun -> track on a record file, the call sequence of reference
-        initialize.py:454-515 without plots and without the navigation solution.
-        Returns (acqResults, trackResults)."""
-        from . import acquisition, tracking
-        name = self.fileName if fileNameStr is None else fileNameStr
+        """acquire -> preRun -> track -> postNavigate on a record file: the call sequence of reference
+        initialize.py:420-515 without the plots and without the .npy cache of the tracking results.
+        Returns (acqResults, trackResults, navResults); navResults.solutions is unset when the record is too short
+        or too few satellites carry ephemerides, as in the reference."""
+        from . import acquisition, postNavigation, tracking
+        print('Starting processing...')
+        name = self.fileName if not fileNameStr else fileNameStr
         if not isinstance(name, str):
             raise TypeError('File name must be a string')
         with open(name, 'rb') as fid:
             fid.seek(self.skipNumberOfBytes, 0)
             data = np.fromfile(fid, self.dataType, 11 * self.samplesPerCode)
+            print('   Acquiring satellites...')
             acqResults = acquisition.AcquisitionResult(self)
             acqResults.acquire(data)
             if not np.any(acqResults.carrFreq):
-                raise RuntimeError('No GNSS signals detected, signal processing finished.')
+                print('No GNSS signals detected, signal processing finished.')
+                return acqResults, None, None
             acqResults.preRun()
+            acqResults.showChannelStatus()
             trackResults = tracking.TrackingResult(acqResults)
             start = datetime.datetime.now()
+            print('   Tracking started at %s' % start.strftime('%X'))
             trackResults.track(fid)
             self.lastTrackingSeconds = (datetime.datetime.now() - start).total_seconds()
-        return acqResults, trackResults
+            print('   Tracking is over (elapsed time %s s)' % self.lastTrackingSeconds)
+        if trackResults._results is None:
+            return acqResults, trackResults, None
+        print('   Calculating navigation solutions...')
+        navResults = postNavigation.NavigationResult(trackResults)
+        navResults.postNavigate()
+        print('   Processing is complete for this data block')
+        return acqResults, trackResults, navResults

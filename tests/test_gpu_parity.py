@@ -805,3 +805,33 @@ def test_post_navigate_on_reference_tracking_output():
     nav2 = m.NavigationResult(t, device=0)
     nav2.postNavigate()
     assert nav2._solutions is None and nav2._eph is None
+
+
+def test_post_processing_from_a_record_file(tmp_path):
+    """Settings.postProcessing(fileName) - the reference's top-level call (initialize.py:420-515) - on a 606 MB record
+    file: streamed into HBM, acquired, tracked and navigated; same fixes as the reference's own run (fix_scene.npz)."""
+    import nav_scene
+    from test_geo_functions import compare_solutions
+    g = load_golden("fix_scene.npz")
+    m = pkg()
+    sc, truth = nav_scene.build()
+    s = m.Settings()
+    s.samplingFreq, s.IF, s.msToProcess, s.numberOfChannels = 16368000.0, 4130400.0, 37000.0, len(truth["prns"])
+    ctx = m.engine.get_context(s, 0)
+    rec = ctx.synth(sc, m.synth.record_length(s.samplesPerCode, 37000))
+    path = str(tmp_path / "record.bin")
+    rec.download().tofile(path)
+    rec.free()
+    acq, trk, nav = s.postProcessing(path)
+    sol = nav.solutions[0]
+    got = {k: sol[k] for k in ("X", "Y", "Z", "dt", "latitude", "longitude", "height", "E", "N", "U", "DOP", "utmZone")}
+    got.update({k: sol.channel[0][k] for k in ("rawP", "correctedP", "el", "az")})
+    compare_solutions(got, g, tol_m=1e-5)
+    assert [int(p) for p in trk.results.PRN] == [int(p) for p in g["PRN"]]
+    # nothing to acquire: the reference prints a message and stops
+    quiet = str(tmp_path / "noise.bin")
+    m.synth.generate(m.synth.Scene.make(5, s.samplingFreq, s.IF, [], [], [], []), 12 * s.samplesPerCode).tofile(quiet)
+    s2 = m.Settings()
+    s2.samplingFreq, s2.IF = s.samplingFreq, s.IF
+    a2, t2, n2 = s2.postProcessing(quiet)
+    assert t2 is None and n2 is None and not np.any(a2.carrFreq)
