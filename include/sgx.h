@@ -132,6 +132,13 @@ int sgx_if_upload(sgx_ctx* c, const int8_t* host, size_t n, sgx_if** out);
  * pinned staging buffers, the next pread overlapping the previous chunk's H2D copy.  A file shorter than
  * requested yields a shorter record (tracking then reports the reference's short-read exit). */
 int sgx_if_upload_file(sgx_ctx* c, const char* path, uint64_t file_offset, size_t n, sgx_if** out);
+/* The same record, but the call returns at once: a background thread streams the file into HBM in file order and
+ * sgx_acquire / sgx_track / sgx_if_download / sgx_probe_stats wait for exactly the samples they need - sgx_track's
+ * cooperative kernel follows a device-side watermark block by block, so tracking overlaps the transfer.
+ * sgx_if_wait blocks until the first n samples (0 = all) are resident and reports a read error if there was one;
+ * sgx_if_free joins the thread. */
+int sgx_if_open_file(sgx_ctx* c, const char* path, uint64_t file_offset, size_t n, sgx_if** out);
+int sgx_if_wait(sgx_ctx* c, sgx_if* r, size_t n);
 /* Generate samples [offset, offset+n) of a synthetic scene directly in HBM. */
 int sgx_if_synth(sgx_ctx* c, const sgx_scene* scene, uint64_t offset, size_t n, sgx_if** out);
 int sgx_if_download(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n, int8_t* host);

@@ -73,6 +73,8 @@ _PROTOS = {
     "sgx_host_free": (C.c_int, [_P]),
     "sgx_if_upload": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(_P)]),
     "sgx_if_upload_file": (C.c_int, [_P, C.c_char_p, C.c_uint64, C.c_size_t, C.POINTER(_P)]),
+    "sgx_if_open_file": (C.c_int, [_P, C.c_char_p, C.c_uint64, C.c_size_t, C.POINTER(_P)]),
+    "sgx_if_wait": (C.c_int, [_P, _P, C.c_size_t]),
     "sgx_if_synth": (C.c_int, [_P, C.POINTER(Scene), C.c_uint64, C.c_size_t, C.POINTER(_P)]),
     "sgx_if_download": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P]),
     "sgx_if_length": (C.c_int, [_P, C.POINTER(C.c_size_t)]),
@@ -278,6 +280,15 @@ class Context(object):
         check(lib().sgx_if_length(h, C.byref(ln)))
         return Record(self, h, int(ln.value))
 
+    def open_file(self, path, file_offset, n):
+        """Like upload_file, but returns at once: the record fills in the background (file order) while
+        acquisition and tracking already run on it.  Record.wait() blocks until everything is resident."""
+        h = _P()
+        check(lib().sgx_if_open_file(self._h, os.fsencode(path), int(file_offset), int(n), C.byref(h)))
+        ln = C.c_size_t(0)
+        check(lib().sgx_if_length(h, C.byref(ln)))
+        return Record(self, h, int(ln.value))
+
     def synth(self, scene, n, offset=0):
         h = _P()
         sc = scene_struct(scene)
@@ -344,6 +355,10 @@ class Record(object):
 
     def __len__(self):
         return self.n
+
+    def wait(self, n=0):
+        """Block until the first n samples (0 = all) of a record opened with Context.open_file are resident."""
+        check(lib().sgx_if_wait(self.ctx._h, self._h, int(n)))
 
     def download(self, offset=0, n=None):
         n = self.n - offset if n is None else n

@@ -303,6 +303,10 @@ extern "C" int sgx_acquire(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n_
                       n_samples, offset, (long long)n_blocks * N);
         return SGX_E_RANGE;
     }
+    {
+        const int rq = sgx_if_require(r, offset + n_samples);   // a record that is still streaming in
+        if (rq != SGX_OK) return rq;
+    }
     SGX_HIP(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const int8_t* x = r->d + offset;

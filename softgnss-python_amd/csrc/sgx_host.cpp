@@ -10,6 +10,9 @@
 #include <stdarg.h>
 #include <stdlib.h>
 
+#include <chrono>
+#include <string>
+
 #include "sgx_internal.h"
 
 static thread_local char g_err[512] = "";
@@ -162,6 +165,8 @@ extern "C" int sgx_ctx_destroy(sgx_ctx* c) {
     sgx_fft_plan_destroy(&c->plan_code);
     sgx_fft_plan_destroy(&c->plan_fine);
     sgx_fft_plan_destroy(&c->plan_probe);
+    for (int i = 0; i < 2; ++i)
+        if (c->stage[i]) hipHostFree(c->stage[i]);
     hipFree(c->d_codes);
     hipFree(c->d_fwd);
     hipFree(c->d_codefd);
@@ -328,9 +333,140 @@ extern "C" int sgx_if_upload_file(sgx_ctx* c, const char* path, uint64_t file_of
     return SGX_OK;
 }
 
+// ---- background streaming: the record fills in file order while acquisition and tracking already run ----------
+__global__ void if_mark_kernel(unsigned long long* mark, unsigned long long value) {
+    __hip_atomic_store(mark, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+#define SGX_STAGE_BYTES (32u << 20)   // a multiple of every cache-line size: a line is never half written
+
+static void if_loader_main(sgx_if* r, int fd, uint64_t file_offset, std::string path, sgx_ctx* owner) {
+    const size_t chunk = SGX_STAGE_BYTES;
+    // staging buffers: the context's (owner != null: reserved for this loader by sgx_if_open_file) or private ones
+    void* stage[2] = {owner ? owner->stage[0] : nullptr, owner ? owner->stage[1] : nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    size_t end_of[2] = {0, 0};
+    hipError_t e = hipSetDevice(r->device);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        if (!owner) e = hipHostMalloc(&stage[i], chunk, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+    }
+    size_t off = 0;
+    int k = 0;
+    bool io_fail = false;
+    while (e == hipSuccess && off < r->n) {
+        const size_t len = (r->n - off < chunk) ? (r->n - off) : chunk;
+        e = hipEventSynchronize(done[k]);   // the copy that last used this staging buffer has finished
+        if (e != hipSuccess) break;
+        if (end_of[k] > r->host_mark.load()) r->host_mark.store(end_of[k]);
+        size_t got = 0;
+        while (got < len) {
+            const ssize_t m = pread(fd, (char*)stage[k] + got, len - got, (off_t)(file_offset + off + got));
+            if (m <= 0) {
+                io_fail = true;
+                break;
+            }
+            got += (size_t)m;
+        }
+        if (io_fail) break;
+        e = hipMemcpyAsync(r->d + off, stage[k], len, hipMemcpyHostToDevice, r->copy_stream);
+        off += len;
+        if (e == hipSuccess) {
+            if_mark_kernel<<<1, 1, 0, r->copy_stream>>>(r->d_mark, (unsigned long long)off);
+            e = hipEventRecord(done[k], r->copy_stream);
+        }
+        end_of[k] = off;
+        k ^= 1;
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(r->copy_stream);
+    if (e != hipSuccess || io_fail) {
+        snprintf(r->load_err, sizeof(r->load_err), io_fail ? "read error on %s at byte %llu: %s" : "streaming %s failed at byte %llu: %s",
+                 path.c_str(), (unsigned long long)(file_offset + off), io_fail ? strerror(errno) : hipGetErrorString(e));
+        r->load_rc.store(io_fail ? SGX_E_ARG : SGX_E_HIP);
+    } else {
+        r->host_mark.store(r->n);
+    }
+    // whatever happened, nobody may wait for the watermark any longer
+    if_mark_kernel<<<1, 1, 0, r->copy_stream>>>(r->d_mark, 0x7FFFFFFFFFFFFFFFull);
+    hipStreamSynchronize(r->copy_stream);
+    for (int i = 0; i < 2; ++i) {
+        if (done[i]) hipEventDestroy(done[i]);
+        if (!owner && stage[i]) hipHostFree(stage[i]);
+    }
+    if (owner) owner->stage_busy.store(false);
+    close(fd);
+    r->load_done.store(true);
+}
+
+int sgx_if_require(const sgx_if* r, size_t end) {
+    if (!r->loader) return SGX_OK;
+    if (end > r->n) end = r->n;
+    while (!r->load_done.load() && r->host_mark.load() < end) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    const int rc = r->load_rc.load();
+    if (rc != SGX_OK) sgx_set_error("%s", r->load_err);
+    return rc;
+}
+
+extern "C" int sgx_if_open_file(sgx_ctx* c, const char* path, uint64_t file_offset, size_t n, sgx_if** out) {
+    SGX_CHECK_ARG(c && path && out);
+    SGX_HIP(hipSetDevice(c->device));
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) {
+        sgx_set_error("cannot open %s: %s", path, strerror(errno));
+        return SGX_E_ARG;
+    }
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) {
+        close(fd);
+        sgx_set_error("fstat(%s) failed: %s", path, strerror(errno));
+        return SGX_E_ARG;
+    }
+    size_t avail = ((uint64_t)sb.st_size > file_offset) ? (size_t)((uint64_t)sb.st_size - file_offset) : 0;
+    if (avail > n) avail = n;
+    sgx_if* r = nullptr;
+    int rc = if_alloc(c, avail, &r);
+    if (rc != SGX_OK) {
+        close(fd);
+        return rc;
+    }
+    hipError_t e = hipStreamSynchronize(c->stream);   // the zero pad is in place
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void**)&r->d_mark, 256);
+    if (e == hipSuccess) e = hipMemset(r->d_mark, 0, 256);
+    if (e != hipSuccess) {
+        close(fd);
+        sgx_if_free(c, r);
+        sgx_set_error("cannot set up the streaming record: %s", hipGetErrorString(e));
+        return SGX_E_HIP;
+    }
+    // reserve the context's pinned staging buffers for this loader if nobody else is streaming
+    sgx_ctx* owner = nullptr;
+    bool expected = false;
+    if (c->stage_busy.compare_exchange_strong(expected, true)) {
+        for (int i = 0; i < 2; ++i)
+            if (!c->stage[i] && hipHostMalloc(&c->stage[i], SGX_STAGE_BYTES, hipHostMallocDefault) != hipSuccess) c->stage[i] = nullptr;
+        if (c->stage[0] && c->stage[1])
+            owner = c;
+        else
+            c->stage_busy.store(false);
+    }
+    r->loader = new std::thread(if_loader_main, r, fd, file_offset, std::string(path), owner);
+    *out = r;
+    return SGX_OK;
+}
+
+extern "C" int sgx_if_wait(sgx_ctx* c, sgx_if* r, size_t n) {
+    SGX_CHECK_ARG(c && r);
+    return sgx_if_require(r, n == 0 ? r->n : n);
+}
+
 extern "C" int sgx_if_download(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n, int8_t* host) {
     SGX_CHECK_ARG(c && r && host);
     SGX_CHECK_ARG(offset <= r->n && n <= r->n - offset);
+    {
+        const int rq = sgx_if_require(r, offset + n);
+        if (rq != SGX_OK) return rq;
+    }
     SGX_HIP(hipSetDevice(c->device));
     SGX_HIP(hipMemcpyAsync(host, r->d + offset, n, hipMemcpyDeviceToHost, c->stream));
     SGX_HIP(hipStreamSynchronize(c->stream));
@@ -345,10 +481,17 @@ extern "C" int sgx_if_length(const sgx_if* r, size_t* n) {
 
 extern "C" int sgx_if_free(sgx_ctx* c, sgx_if* r) {
     if (!r) return SGX_OK;
+    if (r->loader) {
+        r->loader->join();
+        delete r->loader;
+        r->loader = nullptr;
+    }
     if (c) {
         hipSetDevice(c->device);
         hipStreamSynchronize(c->stream);
     }
+    if (r->copy_stream) hipStreamDestroy(r->copy_stream);
+    if (r->d_mark) hipFree(r->d_mark);
     hipFree(r->d);
     delete r;
     return SGX_OK;

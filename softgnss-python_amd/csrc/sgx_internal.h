@@ -4,6 +4,9 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "sgx.h"
@@ -45,7 +48,17 @@ struct sgx_if {
     int8_t* d = nullptr;   // device pointer; allocation is padded by SGX_IF_PAD zero bytes
     size_t n = 0;
     int device = 0;
+    // background file -> HBM streaming (sgx_if_open_file): samples [0, host_mark) are resident
+    std::thread* loader = nullptr;
+    std::atomic<size_t> host_mark{0};        // bytes whose copy has completed, as the host knows it
+    std::atomic<int> load_rc{0};             // SGX_OK while running / after success, an error code otherwise
+    std::atomic<bool> load_done{false};
+    unsigned long long* d_mark = nullptr;    // the same watermark in device memory, advanced in copy-stream order
+    hipStream_t copy_stream = nullptr;
+    char load_err[256] = {0};
 };
+// Block until samples [0, end) of a (possibly still streaming) record are resident; returns the loader's status.
+int sgx_if_require(const sgx_if* r, size_t end);
 #define SGX_IF_PAD 256
 
 struct sgx_ctx {
@@ -73,6 +86,9 @@ struct sgx_ctx {
     size_t trk_out_elems = 0;
     void* d_trk_aux = nullptr;   // per-call device state of sgx_track (channels, done, exchange, err, profile)
     size_t trk_aux_cap = 0;
+    // pinned staging buffers of the file streamer, kept between calls (pinning 64 MiB costs ~15 ms)
+    void* stage[2] = {nullptr, nullptr};
+    std::atomic<bool> stage_busy{false};
 };
 
 // sgx_host.cpp

@@ -70,6 +70,10 @@ extern "C" int sgx_probe_stats(sgx_ctx* c, const sgx_if* rec, size_t offset, siz
         sgx_set_error("ValueError: probeData needs at least %d samples for one Welch segment, got %zu", PROBE_NSEG, n);
         return SGX_E_RANGE;
     }
+    {
+        const int rq = sgx_if_require(rec, offset + n);
+        if (rq != SGX_OK) return rq;
+    }
     SGX_HIP(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const int step = PROBE_NSEG - PROBE_NOVERLAP;

@@ -51,6 +51,11 @@ void sgx_trk_spec_launch(int n_blocks, hipStream_t st, const int8_t* rec, const 
                          double* out, int* done, const TrkConst& K, long long* prof, unsigned long long* xch,
                          int* err);
 
+// sgx_trk_stream.hip: the cooperative kernel with watermark checks, for a record that is still streaming in
+void sgx_trk_stream_launch(int n_blocks, hipStream_t st, const int8_t* rec, const int8_t* codes, const TrkChan* chans,
+                           double* out, int* done, const TrkConst& K, long long* prof, unsigned long long* xch,
+                           int* err);
+
 // tracking.py:65-94: series start as zeros (absoluteSample, I/Q) or +Inf (the others)
 __global__ __launch_bounds__(256) void trk_fill_kernel(double* __restrict__ out, long long ms, long long total) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -89,6 +94,7 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
     }
     K.rec_len = (long long)r->n;
     K.rec_alloc = (long long)r->n + SGX_IF_PAD;
+    K.mark = nullptr;
     K.file_off = rec_file_offset;
     K.ms = ms;
     K.n_ch = n_ch;
@@ -202,9 +208,21 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
         if (!direct) trk_fill_kernel<<<(unsigned)((elems + 255) / 256), 256, 0, st>>>(d_out, ms, (long long)elems);
         const int n_blocks = ((n_ch + 7) / 8) * 8 * K.split;
         use_spec = (K.split > 1 && K.split == K.n_units) && (sp && sp[0] == '1');
+        // a record that is still streaming in: the cooperative kernel follows the device watermark; the other
+        // kernels (and a repeated launch) first wait for the whole record
+        const char* se2 = getenv("SGX_TRK_STREAM");
+        const bool streaming = r->loader && !r->load_done.load() && !use_spec && !(K.split == 1 && n_ch > 128) &&
+                               attempt == 0 && !(se2 && se2[0] == '0');
+        if (!streaming) {
+            const int rq = sgx_if_require(r, r->n);
+            if (rq != SGX_OK) return rq;
+        }
+        K.mark = streaming ? r->d_mark : nullptr;
         if (want_prof) SGX_HIP(hipMemsetAsync(d_prof, 0, sizeof(long long) * 64 * (size_t)n_ch, st));
         hipEventRecord(c->ev[3], st);
-        if (use_spec)
+        if (streaming)
+            sgx_trk_stream_launch(n_blocks, st, r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err);
+        else if (use_spec)
             sgx_trk_spec_launch(n_blocks, st, r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err);
         else if (K.split == 1 && n_ch > 128)
             sgx_trk_tp_launch(n_blocks, st, r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err);
@@ -269,6 +287,10 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
     if (h_err != 0) {
         sgx_set_error("tracking kernel: channel %d reported a timeout with split %d", h_err - 1, K.split);
         return SGX_E_HIP;
+    }
+    {
+        const int rq = r->loader ? r->load_rc.load() : SGX_OK;   // the loader failed while the kernel ran
+        if (rq != SGX_OK) return sgx_if_require(r, r->n);
     }
     hipEventElapsedTime(&c->timing.track_ms, c->ev[3], c->ev[4]);
     return SGX_OK;

@@ -51,6 +51,7 @@ struct TrkConst {
     double inv_nb[8];
     double inv_fs;        // RN(1 / fs)
     double inv_pi;        // RN(1 / pi)
+    const unsigned long long* mark;   // streaming record: bytes resident so far (device watermark), or null
 };
 
 struct TrkChan {
@@ -253,6 +254,24 @@ __device__ __forceinline__ void granule_store(unsigned long long* p, unsigned lo
         __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else
         __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// streaming record: wait until the first `need` bytes are resident (bounded; a stalled loader flags the channel).
+// `seen` caches the last watermark read: it only moves in 32 MiB steps, so the (slow, uncached) load is issued
+// once per several hundred blocks and not once per block.
+__device__ __forceinline__ void wait_mark(const unsigned long long* mark, long long need, unsigned long long& seen,
+                                          int* err, int ch) {
+    if ((unsigned long long)need <= seen) return;
+    int budget = 1 << 24;   // about half a minute
+    for (;;) {
+        seen = __hip_atomic_load(mark, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen >= (unsigned long long)need) break;
+        if (--budget == 0) {
+            atomicExch(err, 1 + ch);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(32);
+    }
 }
 
 __device__ __forceinline__ uint4 load_group(const int8_t* __restrict__ rec, long long addr, long long limit) {

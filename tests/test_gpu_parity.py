@@ -835,3 +835,45 @@ def test_post_processing_from_a_record_file(tmp_path):
     s2.samplingFreq, s2.IF = s.samplingFreq, s.IF
     a2, t2, n2 = s2.postProcessing(quiet)
     assert t2 is None and n2 is None and not np.any(a2.carrFreq)
+
+
+def test_streaming_record_overlaps_tracking_with_identical_results(full_run, tmp_path):
+    """sgx_if_open_file: the record fills in the background while the cooperative kernel follows the watermark."""
+    m, s, ctx, sc, rec, a, chans, series, done = full_run
+    path = str(tmp_path / "stream.bin")
+    n_bytes = m.synth.record_length(s.samplesPerCode, 6000)
+    rec.download(0, n_bytes).tofile(path)
+    for env in ({}, {"SGX_TRK_STREAM": "0"}, {"SGX_TRK_SPLIT": "1"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            r = ctx.open_file(path, 0, n_bytes)
+            s2, d2 = ctx.track(r, chans, 6000)           # starts while the file is still being read
+            assert np.all(d2 == 6000) and np.array_equal(s2[:, 0], series[:, 0, :6000])
+            if "SGX_TRK_SPLIT" in env:       # another reduction order: equal to rounding
+                assert _trk_err(s2, series[:, :, :6000]) < 1e-9
+            else:                            # the same arithmetic as the resident run: bit-identical
+                assert np.array_equal(s2, series[:, :, :6000])
+            assert np.array_equal(r.download(n_bytes - 5000, 5000), rec.download(n_bytes - 5000, 5000))
+            r.free()
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    # acquisition and statistics on a record that is still streaming wait for their window only
+    r = ctx.open_file(path, 0, n_bytes)
+    a2 = m.AcquisitionResult(s, device=0)
+    a2.acquire(m.DeviceSignal(r, 0, 11 * s.samplesPerCode))
+    assert np.array_equal(a2.carrFreq, a.carrFreq) and np.array_equal(a2.codePhase, a.codePhase)
+    r.wait()
+    r.free()
+    # an unaligned window of the file, freed while the transfer is still running
+    r = ctx.open_file(path, 12345, 40 * 1000 * 1000)
+    assert len(r) == 40 * 1000 * 1000
+    r.free()
+    # the tracker's short-read behaviour on a streaming record
+    r = ctx.open_file(path, 0, 50 * s.samplesPerCode)
+    s3, d3 = ctx.track(r, chans, 100)
+    assert np.all(d3 < 100) and np.all(d3 >= 47)
+    r.free()
+    with pytest.raises(RuntimeError):
+        ctx.open_file(str(tmp_path / "missing.bin"), 0, 10)
