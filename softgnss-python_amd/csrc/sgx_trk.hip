@@ -42,7 +42,7 @@
 #define TRK_MINW 1
 #include "sgx_trk_kernel.inc"
 
-// sgx_trk_tp.hip: the same kernel compiled for two workgroups per CU
+// sgx_trk_tp.hip: throughput-mode kernel (one lane per prompt chip, two workgroups per CU) for split == 1, > 128 channels
 void sgx_trk_tp_launch(int n_blocks, hipStream_t st, const int8_t* rec, const int8_t* codes, const void* chans,
                        double* out, int* done, const TrkConst& K, long long* prof, unsigned long long* xch, int* err);
 

@@ -877,3 +877,20 @@ def test_streaming_record_overlaps_tracking_with_identical_results(full_run, tmp
     r.free()
     with pytest.raises(RuntimeError):
         ctx.open_file(str(tmp_path / "missing.bin"), 0, 10)
+
+
+@pytest.mark.slow
+def test_full_config3_run_against_the_oracle(full_run):
+    """BASELINE config 3 at its full size against the oracle itself (not only through properties): 8 channels x
+    37 000 ms = 296 000 dependent blocks; the numpy restatement runs in eight host processes (about 40 s)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from concurrent.futures import ProcessPoolExecutor
+    from full_parity import oracle_channel
+    m, s, ctx, sc, rec, a, chans, series, done = full_run
+    host = rec.download()
+    with ProcessPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        want = np.stack(list(ex.map(oracle_channel, [(host, p, f, c, 37000) for p, f, c in chans])))
+    assert np.array_equal(series[:, 0], want[:, 0])                  # every block boundary of the run
+    assert _trk_err(series, want) < 1e-9                              # bar: 1e-6
+    assert np.max(np.abs(series[:, 1] - want[:, 1])) < 1e-8 and np.max(np.abs(series[:, 2] - want[:, 2])) < 1e-7
