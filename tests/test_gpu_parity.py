@@ -894,3 +894,33 @@ def test_full_config3_run_against_the_oracle(full_run):
     assert np.array_equal(series[:, 0], want[:, 0])                  # every block boundary of the run
     assert _trk_err(series, want) < 1e-9                              # bar: 1e-6
     assert np.max(np.abs(series[:, 1] - want[:, 1])) < 1e-8 and np.max(np.abs(series[:, 2] - want[:, 2])) < 1e-7
+
+
+@pytest.mark.slow
+def test_config4_full_noncoherent_acquisition_against_the_oracle(default_record):
+    """BASELINE config 4 at its full size: 32 PRNs, 10 x 1 ms non-coherent, 29 bins (9 280 correlations); the
+    oracle takes about half a minute of host time."""
+    m = pkg()
+    s = m.Settings()
+    n = s.samplesPerCode
+    a = m.AcquisitionResult(s, device=0)
+    a.acquire(default_record[:20 * n], n_blocks=10, noncoh=True)
+    r = orc.acquire(orc.OracleSettings(), default_record[:20 * n], n_blocks=10, noncoh=True)
+    assert np.array_equal(a.codePhase, r["codePhase"]) and np.array_equal(a.carrFreq, r["carrFreq"])
+    assert np.array_equal(a.internals["freqBin"], r["freqBin"])
+    assert np.allclose(a.peakMetric, r["peakMetric"], rtol=1e-9, atol=0)
+    assert np.count_nonzero(a.carrFreq) == 8
+
+
+def test_config5_full_64_replicated_channels(full_run):
+    """BASELINE config 5 at its full size on one GPU: 64 channels (8 initialisations x 8 replicas) x 37 000 ms.
+    Replicas are bit-identical; block boundaries equal the 8-channel run's, sums agree to rounding (the launch
+    uses 4 cooperating workgroups per channel instead of 10, i.e. another summation order)."""
+    m, s, ctx, sc, rec, a, chans, series, done = full_run
+    many = [chans[i % 8] for i in range(64)]
+    s64, d64 = ctx.track(rec, many, 37000)
+    assert np.all(d64 == 37000)
+    for i in range(8, 64):
+        assert np.array_equal(s64[i], s64[i % 8])
+    assert np.array_equal(s64[:8, 0], series[:, 0])
+    assert _trk_err(s64[:8], series) < 1e-9
