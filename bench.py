@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--many-channels", type=int, default=2048,
                     help="extra leg at N=1: channels of the many-channel (bandwidth-regime) tracking run, 0 = skip")
     ap.add_argument("--many-ms", type=int, default=500)
+    ap.add_argument("--concurrent", type=int, default=3,
+                    help="extra leg at N=1: this many independent records processed at once on one GPU (0 = skip)")
     ap.add_argument("--cpu-trk-ms", type=int, default=4000, help="ms of 1-channel oracle tracking timed")
     ap.add_argument("--cpu-acq-prns", type=int, default=16, help="PRNs of oracle acquisition timed")
     return ap.parse_args()
@@ -86,6 +88,86 @@ def cpu_baseline(pkg, scene, n_code, args, total_samples, n_ch, ms):
                       "channel x %d ms tracking each (%.2f s), scaled linearly to 32 PRNs + %d channels x %d ms"
                       % (workers, k_prn, t_acq, args.cpu_trk_ms, t_trk, n_ch, ms),
             "seconds_extrapolated": full, "single_core_value": total_samples / one / 1e6}
+
+
+def guarded(label, seconds, fn, *a):
+    """Run an optional leg with a deadline: the headline JSON line must come out whatever the extras do."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box["out"] = fn(*a)
+        except Exception as e:   # noqa: BLE001 - reported, never fatal
+            box["out"] = {"error": "%s: %r" % (label, e)}
+
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        return {"error": "%s did not finish within %d s" % (label, seconds)}
+    return box["out"]
+
+
+def concurrent_records(pkg, s, scene, rec_len, n_code, local, args):
+    """One receiver keeps 80 of the 256 CUs busy (8 channels x 10 cooperating workgroups), so a GPU can serve several
+    independent records at once: each thread below owns a context (stream, scratch, record) and runs the same
+    step as the headline measurement; the aggregate is reported next to it, never instead of it."""
+    import threading
+    n = args.concurrent
+    ready = threading.Barrier(n + 1)
+    go = threading.Barrier(n + 1)
+    fin = threading.Barrier(n + 1)
+    errors = []
+
+    def worker():
+        try:
+            with pkg.engine.private_context(s, local) as ctx:
+                rec = ctx.synth(scene, rec_len)
+                signal = pkg.DeviceSignal(rec, 0, 11 * n_code)
+
+                def one():
+                    acq = pkg.AcquisitionResult(s, device=local)
+                    acq.acquire(signal)
+                    acq.preRun()
+                    trk = pkg.TrackingResult(acq, device=local)
+                    trk.track(pkg.DeviceFile(rec))
+                    if trk.series is None:
+                        raise RuntimeError("tracking ran out of record")
+
+                one()
+                ready.wait()
+                go.wait()
+                for _ in range(args.steps):
+                    one()
+                ctx.sync()
+                fin.wait()
+                rec.free()
+        except Exception as e:   # noqa: BLE001 - reported in the JSON line
+            errors.append(repr(e))
+            for b in (ready, go, fin):
+                b.abort()
+
+    threads = [threading.Thread(target=worker) for _ in range(n)]
+    for t in threads:
+        t.start()
+    try:
+        ready.wait()
+        t0 = time.perf_counter()
+        go.wait()
+        fin.wait()
+        dt = time.perf_counter() - t0
+    except threading.BrokenBarrierError:
+        dt = None
+    for t in threads:
+        t.join()
+    if dt is None or errors:
+        return {"records": n, "error": "; ".join(errors) or "barrier broken"}
+    value = n * float(rec_len) * args.steps / dt / 1e6
+    return {"records": n, "steps_each": args.steps, "value": value, "unit": "Msamples/s",
+            "x_realtime_aggregate": value / REALTIME_MSPS, "ms_per_step_each": dt / args.steps * 1e3,
+            "note": "independent records on one GPU at once (one context, stream and 1.4 GB record per thread); "
+                    "every record is still processed at its own latency-bound rate"}
 
 
 def pmc_traffic(channels, ms):
@@ -244,23 +326,29 @@ def main():
                                  "CUs busy: latency-bound, not bandwidth-bound (DESIGN.md section 5)"},
         }
         if world == 1 and args.many_channels > 0:
-            # the same kernel where bandwidth, not the 37 000-step dependency chain, is the limit: one CU per
-            # channel (two channels per CU), replicas of the acquired channels, HIP-event kernel time
-            chans = [(int(c.PRN), float(c.acquiredFreq), float(c.codePhase)) for c in acq.channels if c.PRN != 0]
-            many = [chans[i % len(chans)] for i in range(args.many_channels)]
-            ctx.track(rec, many, 20)
-            ser, dn = ctx.track(rec, many, args.many_ms)
-            t_ms = ctx.timing()["track_ms"]
-            b_many = float(np.sum(ser[:, 0, -1] - np.array([c[2] for c in many]))) + len(many) * args.many_ms * 13 * 8.0
-            out["roofline_many_channels"] = {
-                "kernel": "trk_kernel_tp", "bound": "hbm", "channels": len(many), "ms": args.many_ms,
-                "achieved": b_many / (t_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": b_many / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": t_ms,
-                "frac_of_measured_read": b_many / (t_ms * 1e-3) / 1e9 / read_gbs,
-                "note": "throughput-mode kernel (one lane per prompt chip, split=1): channels x ms code periods of "
-                        "independent work; fp64 VALU-bound at >= 4 instructions per sample"}
+            # the throughput-mode kernel, where bandwidth and not the 37 000-step dependency chain is the limit: one
+            # CU per channel (two channels per CU), replicas of the acquired channels, HIP-event kernel time
+            def many_leg():
+                chans = [(int(c.PRN), float(c.acquiredFreq), float(c.codePhase)) for c in acq.channels if c.PRN != 0]
+                many = [chans[i % len(chans)] for i in range(args.many_channels)]
+                ctx.track(rec, many, 20)
+                ser, dn = ctx.track(rec, many, args.many_ms)
+                t_ms = ctx.timing()["track_ms"]
+                b_many = float(np.sum(ser[:, 0, -1] - np.array([c[2] for c in many]))) + \
+                    len(many) * args.many_ms * 13 * 8.0
+                return {"kernel": "trk_kernel_tp", "bound": "hbm", "channels": len(many), "ms": args.many_ms,
+                        "achieved": b_many / (t_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": b_many / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": t_ms,
+                        "frac_of_measured_read": b_many / (t_ms * 1e-3) / 1e9 / read_gbs,
+                        "note": "throughput-mode kernel (one lane per prompt chip, split=1): channels x ms code "
+                                "periods of independent work; fp64 VALU-bound at >= 4 instructions per sample"}
+            out["roofline_many_channels"] = guarded("roofline_many_channels", 180, many_leg)
+        if world == 1 and args.concurrent > 1:
+            out["concurrent_records"] = guarded("concurrent_records", 180, concurrent_records, pkg, s, scene, rec_len,
+                                                n_code, local, args)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pkg, scene, n_code, args, samples_per_step, args.channels, args.ms)
+            out["cpu_baseline"] = guarded("cpu_baseline", 600, cpu_baseline, pkg, scene, n_code, args, samples_per_step,
+                                          args.channels, args.ms)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
