@@ -11,6 +11,8 @@
 // MFMA is deliberately unused (BASELINE.json north_star).
 #include <math.h>
 
+#include <mutex>
+
 #include "sgx_internal.h"
 
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) {
@@ -269,7 +271,10 @@ static const int kRadixList[] = {16, 8, 4, 2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 3
 static cplx* g_wr[32] = {nullptr};   // per-radix root tables on the current device
 static int g_wr_device = -1;
 
+static std::mutex g_wr_lock;   // contexts of several host threads share the tables
+
 static int ensure_roots(int R) {
+    std::lock_guard<std::mutex> hold(g_wr_lock);
     int dev = 0;
     SGX_HIP(hipGetDevice(&dev));
     if (g_wr_device != dev) {

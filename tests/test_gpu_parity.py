@@ -924,3 +924,42 @@ def test_config5_full_64_replicated_channels(full_run):
         assert np.array_equal(s64[i], s64[i % 8])
     assert np.array_equal(s64[:8, 0], series[:, 0])
     assert _trk_err(s64[:8], series) < 1e-9
+
+
+def test_independent_records_on_one_gpu_at_once(default_record):
+    """Three threads, each with a private context (stream, scratch, record), acquire and track at the same time:
+    every one of them reproduces the reference's golden output."""
+    import threading
+    g = load_golden("trk_default.npz")
+    ga = load_golden("acq_default.npz")
+    m = pkg()
+    out, errs = {}, []
+
+    def worker(k):
+        try:
+            s = m.Settings()
+            s.numberOfChannels = 4
+            s.msToProcess = 400.0
+            with m.engine.private_context(s, 0) as ctx:
+                rec = ctx.upload(default_record)
+                a = m.AcquisitionResult(s, device=0)
+                a.acquire(m.DeviceSignal(rec, 0, 11 * 38192))
+                a.preRun()
+                t = m.TrackingResult(a, device=0)
+                t.track(m.DeviceFile(rec))
+                out[k] = (a.carrFreq.copy(), a.codePhase.copy(), t.series.copy())
+                rec.free()
+        except Exception as e:   # noqa: BLE001
+            errs.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    for k in range(3):
+        cf, cp, series = out[k]
+        assert np.array_equal(cf, ga["carrFreq"]) and np.array_equal(cp, ga["codePhase"])
+        assert np.array_equal(series[:, 0], g["series"][:, 0]) and _trk_err(series, g["series"]) < TRK_TOL
+        assert np.array_equal(series, out[0][2])
