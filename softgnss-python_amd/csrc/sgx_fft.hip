@@ -268,8 +268,8 @@ __global__ __launch_bounds__(TPB) void fft_pass_kernel(PassArgs a) {
 // ---- plan -----------------------------------------------------------------------------------
 
 static const int kRadixList[] = {16, 8, 4, 2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31};
-static cplx* g_wr[32] = {nullptr};   // per-radix root tables on the current device
-static int g_wr_device = -1;
+#define SGX_MAX_DEVICES 16
+static cplx* g_wr[SGX_MAX_DEVICES][32] = {{nullptr}};   // per-device, per-radix root tables
 
 static std::mutex g_wr_lock;   // contexts of several host threads share the tables
 
@@ -277,18 +277,18 @@ static int ensure_roots(int R) {
     std::lock_guard<std::mutex> hold(g_wr_lock);
     int dev = 0;
     SGX_HIP(hipGetDevice(&dev));
-    if (g_wr_device != dev) {
-        for (auto& p : g_wr) p = nullptr;   // tables of another device are left allocated there
-        g_wr_device = dev;
+    if (dev < 0 || dev >= SGX_MAX_DEVICES) {
+        sgx_set_error("device index %d not supported (max %d)", dev, SGX_MAX_DEVICES - 1);
+        return SGX_E_ARG;
     }
-    if (g_wr[R]) return SGX_OK;
+    if (g_wr[dev][R]) return SGX_OK;
     std::vector<cplx> w((size_t)R);
     for (int m = 0; m < R; ++m) {
         const long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)m / (long double)R;
         w[(size_t)m] = make_double2((double)cosl(ang), (double)sinl(ang));
     }
-    SGX_HIP(hipMalloc((void**)&g_wr[R], sizeof(cplx) * (size_t)R));
-    SGX_HIP(hipMemcpy(g_wr[R], w.data(), sizeof(cplx) * (size_t)R, hipMemcpyHostToDevice));
+    SGX_HIP(hipMalloc((void**)&g_wr[dev][R], sizeof(cplx) * (size_t)R));
+    SGX_HIP(hipMemcpy(g_wr[dev][R], w.data(), sizeof(cplx) * (size_t)R, hipMemcpyHostToDevice));
     return SGX_OK;
 }
 
@@ -380,6 +380,9 @@ int sgx_fft_forward_fused(const FftPlan* p, cplx* a, cplx* b, int64_t rows, hipS
         sgx_set_error("sgx_fft_forward: bad plan or row count %lld", (long long)rows);
         return SGX_E_ARG;
     }
+    int cur_dev = 0;
+    SGX_HIP(hipGetDevice(&cur_dev));
+    if (cur_dev < 0 || cur_dev >= SGX_MAX_DEVICES) return SGX_E_ARG;
     cplx* src = a;
     cplx* dst = b;
     long long ns = 1;
@@ -419,7 +422,7 @@ int sgx_fft_forward_fused(const FftPlan* p, cplx* a, cplx* b, int64_t rows, hipS
         pa.out = dst;
         pa.tw_hi = p->tw_hi;
         pa.tw_lo = p->tw_lo;
-        pa.wr = g_wr[r];
+        pa.wr = g_wr[cur_dev][r];
         pa.n = p->n;
         pa.ns = ns;
         pa.nonzero_len = first ? nonzero_len : p->n;
