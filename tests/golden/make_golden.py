@@ -7,8 +7,14 @@ installs the three numpy alias shims it needs (np.int / np.long / np.Inf), feeds
 from this repo's deterministic generator and stores ONLY inputs' parameters and the
 reference's outputs as small .npz fixtures next to this file.
 
-    python tests/golden/make_golden.py            # regenerates every fixture (~10 min)
-    SGX_GOLDEN_ONLY=probe python tests/golden/make_golden.py   # only probe_default.npz
+    python tests/golden/make_golden.py            # regenerates every fixture (~30 min, one core, < 4 GiB)
+    SGX_GOLDEN_ONLY=<part> python tests/golden/make_golden.py  # one part only:
+        probe  probe_default.npz   Settings.probeData (Welch PSD, histogram)
+        eph    eph_cases.npz       ephemeris.ephemeris on the generator's navigation frames
+        geo    geo_cases.npz       satpos, leastSquarePos, cart2geo, findUtmZone, cart2utm and helpers
+        nav    nav_preambles.npz   track 2 x 10 s + findPreambles + calculatePseudoranges
+        fix    fix_scene.npz       acquire + track 6 x 37 s + postNavigate on the consistent scene (~12 min)
+    (codes, acq_*, trk_*, rate2 come from the default run.)
 """
 import importlib
 import io
