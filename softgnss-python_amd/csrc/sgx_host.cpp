@@ -430,7 +430,15 @@ extern "C" int sgx_if_open_file(sgx_ctx* c, const char* path, uint64_t file_offs
         return rc;
     }
     hipError_t e = hipStreamSynchronize(c->stream);   // the zero pad is in place
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) {
+        // A stream of the highest priority: HIP keeps separate hardware queues per priority, so the copies and the
+        // watermark updates never queue up behind the (normal-priority) stream that runs the tracking kernel.
+        int lo = 0, hi = 0;
+        e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+        const char* pe = getenv("SGX_STREAM_PRIO");   // test hook: "0" = a normal-priority copy stream
+        if (pe && pe[0] == '0') hi = 0;
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&r->copy_stream, hipStreamNonBlocking, hi);
+    }
     if (e == hipSuccess) e = hipMalloc((void**)&r->d_mark, 256);
     if (e == hipSuccess) e = hipMemset(r->d_mark, 0, 256);
     if (e != hipSuccess) {

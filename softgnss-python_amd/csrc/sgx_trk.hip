@@ -236,6 +236,14 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         const char* th = getenv("SGX_TRK_TEST_TIMEOUT");   // test hook: treat the first attempt as timed out
         if (e == hipSuccess && th && th[0] == '1' && attempt == 0 && K.split > 1) h_err = 1;
+        if (e == hipSuccess && (h_err & TRK_ERR_STREAM) && attempt == 0) {
+            // the streaming record's watermark stalled (the copy stream could not run beside the kernel): repeat
+            // with the same decomposition once the whole record is resident
+            fprintf(stderr, "[sgx] tracking: the record did not stream in beside the kernel; repeating the launch "
+                            "on the resident record\n");
+            continue;
+        }
+        h_err &= ~TRK_ERR_STREAM;
         if (e != hipSuccess || h_err == 0 || K.split == 1) break;
         fprintf(stderr, "[sgx] tracking: channel %d timed out waiting for a cooperating workgroup (split %d, are the "
                         "CUs shared?); repeating the launch with one workgroup per channel\n", h_err - 1, K.split);

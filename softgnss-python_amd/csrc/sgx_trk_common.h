@@ -259,15 +259,19 @@ __device__ __forceinline__ void granule_store(unsigned long long* p, unsigned lo
 // streaming record: wait until the first `need` bytes are resident (bounded; a stalled loader flags the channel).
 // `seen` caches the last watermark read: it only moves in 32 MiB steps, so the (slow, uncached) load is issued
 // once per several hundred blocks and not once per block.
+#define TRK_ERR_STREAM 0x40000000   // error word: the watermark of a streaming record did not advance in time
+
 __device__ __forceinline__ void wait_mark(const unsigned long long* mark, long long need, unsigned long long& seen,
                                           int* err, int ch) {
     if ((unsigned long long)need <= seen) return;
-    int budget = 1 << 24;   // about half a minute
+    int budget = 1 << 19;   // about a second
     for (;;) {
         seen = __hip_atomic_load(mark, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
         if (seen >= (unsigned long long)need) break;
         if (--budget == 0) {
-            atomicExch(err, 1 + ch);
+            // give up for good (the host repeats the launch once the whole record is resident): no further waits
+            atomicExch(err, TRK_ERR_STREAM | (1 + ch));
+            seen = ~0ull;
             break;
         }
         __builtin_amdgcn_s_sleep(32);

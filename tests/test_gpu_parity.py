@@ -963,3 +963,39 @@ def test_independent_records_on_one_gpu_at_once(default_record):
         assert np.array_equal(cf, ga["carrFreq"]) and np.array_equal(cp, ga["codePhase"])
         assert np.array_equal(series[:, 0], g["series"][:, 0]) and _trk_err(series, g["series"]) < TRK_TOL
         assert np.array_equal(series, out[0][2])
+
+
+def test_streaming_record_with_many_live_streams(full_run, tmp_path, capfd):
+    """HIP maps streams onto a few hardware queues.  The copy stream of a streaming record has the highest
+    priority (its own queue pool), so it runs beside the tracking kernel however many streams are alive; with a
+    normal-priority copy stream (test hook) the watermark can stall behind the kernel - then the kernel gives up
+    after about a second and the launch is repeated on the resident record.  Results identical in every case."""
+    m, s, ctx, sc, rec, a, chans, series, done = full_run
+    path = str(tmp_path / "stream.bin")
+    ms = 3000
+    n_bytes = m.synth.record_length(s.samplesPerCode, ms)
+    rec.download(0, n_bytes).tofile(path)
+    extra = []
+    for k in range(13):
+        s2 = m.Settings()
+        s2.acqThreshold = 2.5 + 0.01 * (k + 1)
+        extra.append(m._native.Context(s2, 0))
+    try:
+        for _ in range(4):
+            r = ctx.open_file(path, 0, n_bytes)
+            s2_, d2 = ctx.track(r, chans, ms)
+            r.free()
+            assert np.all(d2 == ms) and np.array_equal(s2_, series[:, :, :ms])
+        assert "did not stream in" not in capfd.readouterr().err
+        os.environ["SGX_STREAM_PRIO"] = "0"
+        try:
+            for _ in range(3):
+                r = ctx.open_file(path, 0, n_bytes)
+                s3, d3 = ctx.track(r, chans, ms)
+                r.free()
+                assert np.all(d3 == ms) and np.array_equal(s3, series[:, :, :ms])
+        finally:
+            os.environ.pop("SGX_STREAM_PRIO", None)
+    finally:
+        for c in extra:
+            c.close()
