@@ -438,6 +438,10 @@ extern "C" int sgx_if_open_file(sgx_ctx* c, const char* path, uint64_t file_offs
         const char* pe = getenv("SGX_STREAM_PRIO");   // test hook: "0" = a normal-priority copy stream
         if (pe && pe[0] == '0') hi = 0;
         if (e == hipSuccess) e = hipStreamCreateWithPriority(&r->copy_stream, hipStreamNonBlocking, hi);
+        if (e != hipSuccess) {   // no stream priorities here: an ordinary stream (the kernel's bounded wait covers it)
+            (void)hipGetLastError();
+            e = hipStreamCreateWithFlags(&r->copy_stream, hipStreamNonBlocking);
+        }
     }
     if (e == hipSuccess) e = hipMalloc((void**)&r->d_mark, 256);
     if (e == hipSuccess) e = hipMemset(r->d_mark, 0, 256);
