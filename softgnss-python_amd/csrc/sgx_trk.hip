@@ -56,6 +56,11 @@ void sgx_trk_stream_launch(int n_blocks, hipStream_t st, const int8_t* rec, cons
                            double* out, int* done, const TrkConst& K, long long* prof, unsigned long long* xch,
                            int* err);
 
+// sgx_trk_multi.hip: the cooperative kernel with a per-sample replica lookup, for low sampling rates
+void sgx_trk_multi_launch(int n_blocks, hipStream_t st, const int8_t* rec, const int8_t* codes, const TrkChan* chans,
+                          double* out, int* done, const TrkConst& K, long long* prof, unsigned long long* xch,
+                          int* err);
+
 // tracking.py:65-94: series start as zeros (absoluteSample, I/Q) or +Inf (the others)
 __global__ __launch_bounds__(256) void trk_fill_kernel(double* __restrict__ out, long long ms, long long total) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -95,6 +100,10 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
     K.rec_len = (long long)r->n;
     K.rec_alloc = (long long)r->n + SGX_IF_PAD;
     K.mark = nullptr;
+    // 16 consecutive samples span 15 code-phase steps: below one chip (with margin for the code NCO's excursions)
+    // a group holds at most one switch per ramp, which the fast map relies on
+    K.multi = (15.0 * 1.001 * S.codeFreqBasis / S.samplingFreq >= 1.0) ? 1 : 0;
+    K.pad_ = 0;
     K.file_off = rec_file_offset;
     K.ms = ms;
     K.n_ch = n_ch;
@@ -207,12 +216,12 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
         SGX_HIP(hipMemsetAsync(aux + sz_ch, 0, sz_done + sz_xch + 256, st));   // done, every polled word, err
         if (!direct) trk_fill_kernel<<<(unsigned)((elems + 255) / 256), 256, 0, st>>>(d_out, ms, (long long)elems);
         const int n_blocks = ((n_ch + 7) / 8) * 8 * K.split;
-        use_spec = (K.split > 1 && K.split == K.n_units) && (sp && sp[0] == '1');
+        use_spec = (K.split > 1 && K.split == K.n_units) && (sp && sp[0] == '1') && !K.multi;
         // a record that is still streaming in: the cooperative kernel follows the device watermark; the other
         // kernels (and a repeated launch) first wait for the whole record
         const char* se2 = getenv("SGX_TRK_STREAM");
         const bool streaming = r->loader && !r->load_done.load() && !use_spec && !(K.split == 1 && n_ch > 128) &&
-                               attempt == 0 && !(se2 && se2[0] == '0');
+                               attempt == 0 && !(se2 && se2[0] == '0') && !K.multi;
         if (!streaming) {
             const int rq = sgx_if_require(r, r->n);
             if (rq != SGX_OK) return rq;
@@ -224,8 +233,10 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
             sgx_trk_stream_launch(n_blocks, st, r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err);
         else if (use_spec)
             sgx_trk_spec_launch(n_blocks, st, r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err);
-        else if (K.split == 1 && n_ch > 128)
+        else if (K.split == 1 && n_ch > 128)   // (general in the sampling rate: one lane per prompt chip)
             sgx_trk_tp_launch(n_blocks, st, r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err);
+        else if (K.multi)
+            sgx_trk_multi_launch(n_blocks, st, r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err);
         else
             trk_kernel<<<n_blocks, TRK_THREADS, 0, st>>>(r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch,
                                                             d_err);

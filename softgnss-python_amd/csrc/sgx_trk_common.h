@@ -52,6 +52,8 @@ struct TrkConst {
     double inv_fs;        // RN(1 / fs)
     double inv_pi;        // RN(1 / pi)
     const unsigned long long* mark;   // streaming record: bytes resident so far (device watermark), or null
+    int multi;            // fewer than ~15 samples per chip: a 16-sample group can hold several chip switches
+    int pad_;
 };
 
 struct TrkChan {

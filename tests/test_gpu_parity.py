@@ -999,3 +999,39 @@ def test_streaming_record_with_many_live_streams(full_run, tmp_path, capfd):
     finally:
         for c in extra:
             c.close()
+
+
+@pytest.mark.parametrize("fs,IF", [(5456000.0, 1364000.0), (61380000.0, 15345000.0), (4092000.0, 1023000.0)])
+def test_other_front_ends_against_oracle(fs, IF):
+    """Sampling rates far from the default: samplesPerCode 5456 (two tracking units), 61 380 = 2^2 3^2 5 11 31
+    (fifteen units, other FFT radices) and 4092 (one unit, exactly four samples per chip)."""
+    m = pkg()
+    s = m.Settings()
+    os_ = orc.OracleSettings()
+    for o in (s, os_):
+        o.samplingFreq, o.IF = fs, IF
+        o.acqSatelliteList = range(1, 7)
+        o.numberOfChannels = 2
+        o.msToProcess = 50.0
+    n = s.samplesPerCode
+    assert n == int(round(fs / 1000))
+    sc = m.synth.Scene.make(0xFE000 + n, fs, IF, [2, 5], [1750.0, -3300.0], [n // 3, n - 5], [9, 8])
+    rec = m.synth.generate(sc, m.synth.record_length(n, 50))
+    a, t = _oracle_vs_gpu(m, s, os_, rec, 50)
+    assert t is not None and sorted(int(p) for p in a.channels.PRN) == [2, 5]
+    # the other kernels on the same front end: one workgroup per channel, and the throughput-mode kernel
+    ctx = m.engine.get_context(s, 0)
+    dev = ctx.upload(rec)
+    chans = [(int(c.PRN), float(c.acquiredFreq), float(c.codePhase)) for c in a.channels]
+    os.environ["SGX_TRK_SPLIT"] = "1"
+    try:
+        one, d1 = ctx.track(dev, chans, 50)
+    finally:
+        os.environ.pop("SGX_TRK_SPLIT", None)
+    many, dm = ctx.track(dev, [chans[i % 2] for i in range(130)], 50)
+    dev.free()
+    assert np.all(d1 == 50) and np.all(dm == 50)
+    assert np.array_equal(one[:, 0], t.series[:, 0]) and _trk_err(one, t.series) < 1e-9
+    assert np.array_equal(many[:2, 0], t.series[:, 0]) and _trk_err(many[:2], t.series) < 1e-9
+    for i in range(2, 130):
+        assert np.array_equal(many[i], many[i % 2])
