@@ -74,6 +74,11 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
                          int32_t n_ch, int32_t ms, double* out, int32_t* ms_done) {
     SGX_CHECK_ARG(c && r && ch && out && ms_done);
     SGX_CHECK_ARG(n_ch >= 1 && n_ch <= 65535 && ms >= 1);
+    if (!(c->s.dllCorrelatorSpacing > 0.0 && c->s.dllCorrelatorSpacing < 1.0)) {
+        // beyond one chip the reference's replica index ceil(t) leaves its 1025-entry code table (or wraps)
+        sgx_set_error("dllCorrelatorSpacing %g outside (0, 1) chips", c->s.dllCorrelatorSpacing);
+        return SGX_E_ARG;
+    }
     SGX_HIP(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const sgx_settings& S = c->s;

@@ -585,8 +585,19 @@ def _oracle_vs_gpu(m, s, os_, rec_host, ms, split_env=None):
     return a, t
 
 
+def test_correlator_spacing_outside_one_chip_is_refused(default_record):
+    m = pkg()
+    g = load_golden("trk_default.npz")
+    for bad in (0.0, 1.0, 1.5, -0.25):
+        s, t = _golden_tracker(m, g, ms=10)
+        s.dllCorrelatorSpacing = bad
+        t = m.TrackingResult(type("A", (), {"channels": t._channels, "settings": s})(), device=0)
+        with pytest.raises(RuntimeError):
+            t.track(m.DeviceFile(m.engine.get_context(s, 0).upload(default_record[:40 * 38192])))
+
+
 @pytest.mark.parametrize("spacing,dll_bw,pll_bw,band,split", [(0.25, 1.0, 15.0, 10.0, None), (0.4, 4.0, 40.0, 6.0, "1"),
-                                                              (0.1, 2.0, 25.0, 14.0, "3")])
+                                                              (0.1, 2.0, 25.0, 14.0, "3"), (0.8, 2.0, 25.0, 14.0, None)])
 def test_non_default_loop_and_search_settings(spacing, dll_bw, pll_bw, band, split):
     """Correlator spacing, loop bandwidths, damping, search band and threshold off the defaults: the three code
     ramps then switch chips at different samples (exact per-sample path of the map)."""
