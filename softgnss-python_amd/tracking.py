@@ -33,10 +33,14 @@ class TrackingResult(Result):
     def _window(self, fid, first, need):
         """Bytes [first, first+need) of the reference's file, as an HBM record."""
         ctx = engine.get_context(self._settings, self._device)
+        if np.dtype(self._settings.dataType) != np.dtype(np.int8):
+            # the reference seeks in bytes but counts in samples (tracking.py:107), i.e. it too is only
+            # consistent for one-byte samples
+            raise TypeError("the GPU path takes int8 IF samples (Settings.dataType %r)" % (self._settings.dataType,))
         # a real file on disk: stream it natively (pinned double buffering, no numpy copy of the record), and let
         # tracking start while the transfer is still running
         name = getattr(fid, 'name', None)
-        if isinstance(name, (str, bytes)) and os.path.isfile(name) and self._settings.dataType == 'int8':
+        if isinstance(name, (str, bytes)) and os.path.isfile(name):
             return ctx.open_file(name, first, need)      # fills in the background; the kernel follows the watermark
         fid.seek(first, 0)
         if hasattr(fid, 'fileno'):

@@ -1046,3 +1046,25 @@ def test_other_front_ends_against_oracle(fs, IF):
     assert np.array_equal(many[:2, 0], t.series[:, 0]) and _trk_err(many[:2], t.series) < 1e-9
     for i in range(2, 130):
         assert np.array_equal(many[i], many[i % 2])
+
+
+def test_tiny_runs_and_unsupported_sample_type(default_record):
+    """msToProcess of 1, 2 and 3 code periods (first block, first filter update) and a non-int8 dataType."""
+    g = load_golden("trk_default.npz")
+    m = pkg()
+    for ms in (1, 2, 3):
+        s, t = _golden_tracker(m, g, ms=ms)
+        with tempfile.NamedTemporaryFile(suffix=".bin") as f:
+            default_record[:6 * 38192].tofile(f.name)
+            with open(f.name, "rb") as fid:
+                t.track(fid)
+        assert t.series.shape == (4, 13, ms)
+        assert np.array_equal(t.series[:, 0], g["series"][:, 0, :ms])
+        assert _trk_err(t.series, g["series"][:, :, :ms]) < TRK_TOL
+    s, t = _golden_tracker(m, g, ms=5)
+    s.dataType = 'int16'
+    with tempfile.NamedTemporaryFile(suffix=".bin") as f:
+        default_record[:8 * 38192].tofile(f.name)
+        with open(f.name, "rb") as fid:
+            with pytest.raises(TypeError):
+                t.track(fid)
