@@ -117,8 +117,10 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
         // resident at once (they wait for each other), so split * n_ch <= CU count
         int cus = 0;
         SGX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-        // units needed by the longest possible block (samplesPerCode + 2 samples, worst alignment)
-        K.n_units = (int)((c->n_code + 2 + 15 + 15) / 16 + TRK_THREADS - 1) / TRK_THREADS;
+        // units needed by the longest possible block, worst alignment.  A block is samplesPerCode +- 1 samples long
+        // while the code NCO stays near its basis; the allowance of 64 samples corresponds to a code-rate error of
+        // 0.17 % (1.7 kHz at 1.023 MHz), three orders of magnitude beyond what the DLL's filter can command.
+        K.n_units = (int)((c->n_code + 64 + 15 + 15) / 16 + TRK_THREADS - 1) / TRK_THREADS;
         int split = cus / (n_ch > 0 ? ((n_ch + 7) / 8) * 8 : 8);
         if (split > TRK_MAX_SPLIT) split = TRK_MAX_SPLIT;
         if (K.n_units > 16) {
