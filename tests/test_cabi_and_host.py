@@ -325,3 +325,31 @@ def test_ephemeris_decode_matches_reference():
         orc.ephemeris(list(four), str(int(tab[start + 899])))
     with pytest.raises(UnboundLocalError):
         eph_mod.ephemeris(four, str(int(tab[start + 899])))
+
+
+def test_ephemeris_round_trip_of_random_parameters():
+    """Encode random clock / orbit parameters into subframes 1-3 (synth.encode_ephemeris + parity + random stream
+    polarity), decode them with sgx_ephemeris and the oracle: both must return every field quantised to its
+    message LSB - computed here independently of either decoder."""
+    import random
+    import oracle.softgnss_oracle as orc
+    synth = pkg("synth")
+    eph_mod = pkg("ephemeris")
+    for seed in range(40):
+        e = synth.make_ephemeris(9000 + seed, toe=16 * random.Random(seed).randrange(0, 37800))
+        tab = synth.nav_message_bits(seed, 0, 2048, 50000 + seed, 1 + seed % 5, e)
+        if seed % 2:
+            tab = 1 - tab
+        bits = [str(int(b)) for b in tab[300:1800]]
+        d30 = str(int(tab[299]))
+        got, tow = eph_mod.ephemeris(bits, d30)
+        ref, tow2 = orc.ephemeris(list(bits), d30)
+        assert got == ref and tow == tow2 == (50000 + seed) * 6
+        for sid, fields in synth.EPH_LAYOUT.items():
+            for name, exp, times_pi, signed, slices in fields:
+                v = e["IODE_sf2"] if name == "IODE_sf3" else e[name]
+                v = v - 1024 if name == "weekNumber" else v
+                q = int(round(v / (synth.GPS_PI if times_pi else 1.0) / 2.0 ** exp))
+                want = q * 2.0 ** exp * (synth.GPS_PI if times_pi else 1.0) + (1024 if name == "weekNumber" else 0)
+                have = got[eph_mod.FIELDS.index(name)]
+                assert have == want or abs(have - want) <= 1e-15 * abs(want), (name, have, want)
