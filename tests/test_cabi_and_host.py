@@ -344,7 +344,7 @@ def test_ephemeris_round_trip_of_random_parameters():
         d30 = str(int(tab[299]))
         got, tow = eph_mod.ephemeris(bits, d30)
         ref, tow2 = orc.ephemeris(list(bits), d30)
-        assert got == ref and tow == tow2 == (50000 + seed) * 6
+        assert got == ref and tow == tow2 == (50000 + seed + 1) * 6     # the stream starts one subframe in
         for sid, fields in synth.EPH_LAYOUT.items():
             for name, exp, times_pi, signed, slices in fields:
                 v = e["IODE_sf2"] if name == "IODE_sf3" else e[name]
