@@ -1068,3 +1068,28 @@ def test_tiny_runs_and_unsupported_sample_type(default_record):
         with open(f.name, "rb") as fid:
             with pytest.raises(TypeError):
                 t.track(fid)
+
+
+@pytest.mark.parametrize("seed", list(range(31, 43)))
+def test_random_front_ends_and_scenes_against_oracle(seed):
+    """Random sampling rate (other FFT factorisations: 26 000 = 2^4 5^3 13, 20 460 = 2^2 3 5 11 31, 12 276 =
+    2^2 3^2 11 31), IF, Doppler up to the band edge, code phase, amplitude and loop settings."""
+    m = pkg()
+    rng = np.random.default_rng(seed)
+    fs = float(rng.choice([38192000.0, 16367600.0, 26000000.0, 20460000.0, 12276000.0, 5456000.0]))
+    IF = float(rng.choice([0.25, 0.2, 0.31]) * fs)
+    s = m.Settings()
+    os_ = orc.OracleSettings()
+    kw = dict(samplingFreq=fs, IF=IF, acqSatelliteList=range(1, 6), numberOfChannels=2, msToProcess=30.0,
+              dllCorrelatorSpacing=float(rng.choice([0.5, 0.5, 0.3, 0.7])), dllNoiseBandwidth=float(rng.choice([2.0, 1.0, 5.0])),
+              pllNoiseBandwidth=float(rng.choice([25.0, 10.0, 50.0])), acqSearchBand=float(rng.choice([14.0, 14.0, 8.0])))
+    for k, v in kw.items():
+        setattr(s, k, v)
+        setattr(os_, k, v)
+    n = s.samplesPerCode
+    half = kw["acqSearchBand"] * 500.0
+    prns = sorted(rng.choice(np.arange(1, 6), size=2, replace=False).tolist())
+    sc = m.synth.Scene.make(0xAB000 + seed, fs, IF, prns, [float(rng.uniform(-half, half)) for _ in prns],
+                            [int(rng.integers(0, n)) for _ in prns], [int(rng.integers(4, 10)) for _ in prns])
+    rec = m.synth.generate(sc, m.synth.record_length(n, 30))
+    _oracle_vs_gpu(m, s, os_, rec, 30)
