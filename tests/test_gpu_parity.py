@@ -1093,3 +1093,32 @@ def test_random_front_ends_and_scenes_against_oracle(seed):
                             [int(rng.integers(0, n)) for _ in prns], [int(rng.integers(4, 10)) for _ in prns])
     rec = m.synth.generate(sc, m.synth.record_length(n, 30))
     _oracle_vs_gpu(m, s, os_, rec, 30)
+
+
+def test_tracking_channels_without_a_signal(default_record):
+    """Channels started on PRNs that are not in the record (noise only: the loops wander, the discriminators see
+    arbitrary ratios) and with a 4 kHz frequency error: the GPU must still follow the reference's arithmetic."""
+    m = pkg()
+    g = load_golden("trk_default.npz")
+    s = m.Settings()
+    s.numberOfChannels = 3
+    s.msToProcess = 150.0
+    freqs = np.array([9548000.0 + 321.0, 9548000.0 - 2750.0, float(g["ch_acquiredFreq"][0]) + 4000.0])
+    prn = np.array([9, 28, int(g["ch_PRN"][0])])
+    phase = np.array([17.0, 30011.0, float(g["ch_codePhase"][0])])
+    a = m.AcquisitionResult(s, device=0)
+    a._channels = np.rec.fromarrays([prn, freqs, phase, ['T'] * 3], names='PRN,acquiredFreq,codePhase,status')
+    t = m.TrackingResult(a, device=0)
+    ctx = m.engine.get_context(s, 0)
+    rec = ctx.upload(default_record[:160 * 38193])
+    t.track(m.DeviceFile(rec))
+    rec.free()
+    os_ = orc.OracleSettings(numberOfChannels=3, msToProcess=150.0)
+    want = orc.stack_series(orc.track(os_, dict(PRN=prn, acquiredFreq=freqs, codePhase=phase, status=np.array(['T'] * 3)),
+                                      default_record[:160 * 38193]))
+    assert np.array_equal(t.series[:, 0], want[:, 0])
+    # without a signal the sums are noise of magnitude ~1e4: compare on that scale
+    scale = np.sqrt(np.mean(want[:, 3:9] ** 2, axis=(1, 2)))
+    err = np.max(np.abs(t.series[:, 3:9] - want[:, 3:9]), axis=(1, 2)) / scale
+    assert err.max() < 1e-6, err
+    assert np.max(np.abs(t.series[:, 1:3] - want[:, 1:3])) < 1e-5
