@@ -6,7 +6,9 @@
  *   AcquisitionResult.preRun()            reference acquisition.py:259-306  (host glue, stays in Python)
  *   TrackingResult.track(fid)             reference tracking.py:13-295
  * The entry points below sit directly under those methods: the drop-in Python modules in
- * softgnss-python_amd/ bind them with ctypes (INTEGRATION.md shows the stub).
+ * softgnss-python_amd/ bind them with ctypes (INTEGRATION.md shows the stub).  Further down: the stages either
+ * side of that path - Settings.probeData statistics, the navigation chain of
+ * postNavigation.py / ephemeris.py / geoFunctions - each citing the reference lines it replaces.
  *
  * Conventions: plain C, int status return (0 = SGX_OK, <0 = error; text via sgx_last_error),
  * no exceptions/callbacks across the boundary, the CALLER owns every host buffer (the library
@@ -31,7 +33,8 @@ extern "C" {
 #define SGX_E_INDEX    -4   /* the reference's IndexError: coarse code phase == samples-per-chip
                                (acquisition.py:152-153 builds index N) */
 #define SGX_E_RCCL     -5   /* RCCL error / library not loadable */
-#define SGX_E_RANGE    -6   /* record too short for the request */
+#define SGX_E_RANGE    -6   /* record too short for the request; also where the reference's numpy code raises on
+                               out-of-range data (the error text then starts with the exception's name) */
 
 #define SGX_NUM_SERIES 13   /* per-ms tracking series, in this order (tracking.py:255-275):
                                absoluteSample codeFreq carrFreq I_P I_E I_L Q_E Q_P Q_L
@@ -71,7 +74,7 @@ typedef struct sgx_chan_init {
  * bit-identical. */
 typedef struct sgx_sat {
     uint64_t code_fcw;  /* 32.32 chips per sample */
-    uint64_t code_c0;   /* 32.32 code phase at sample 0, < 1023 << 32 */
+    uint64_t code_c0;   /* 32.32 code phase at sample 0 (whole code periods shift the navigation bit edges) */
     uint64_t nav_seed;
     uint32_t car_fcw;   /* carrier NCO word, cycles per sample * 2^32 */
     uint32_t car_ph0;
