@@ -120,9 +120,11 @@ def concurrent_records(pkg, s, scene, rec_len, n_code, local, args):
     fin = threading.Barrier(n + 1)
     errors = []
 
-    def worker():
+    def worker(k):
         try:
-            with pkg.engine.private_context(s, local) as ctx:
+            # three stream priority classes = three disjoint sets of hardware queues: the persistent kernels of
+            # different records then never queue up behind each other
+            with pkg.engine.private_context(s, local, priority=(-1, 1, 0)[k % 3]) as ctx:
                 rec = ctx.synth(scene, rec_len)
                 signal = pkg.DeviceSignal(rec, 0, 11 * n_code)
 
@@ -148,7 +150,7 @@ def concurrent_records(pkg, s, scene, rec_len, n_code, local, args):
             for b in (ready, go, fin):
                 b.abort()
 
-    threads = [threading.Thread(target=worker) for _ in range(n)]
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(n)]
     for t in threads:
         t.start()
     try:

@@ -118,6 +118,10 @@ int sgx_calc_loop_coef(double lbw, double zeta, double k, double* tau1, double* 
 /* ---- device context and IF records --------------------------------------------------------- */
 int sgx_device_count(int* n);
 int sgx_ctx_create(const sgx_settings* s, int device, sgx_ctx** out);
+/* The same with a stream priority class (-1 high, 0 normal, +1 low).  HIP multiplexes the streams of one priority
+ * onto a few hardware queues, where two persistent tracking kernels would run one after the other; contexts that
+ * are meant to run AT THE SAME TIME on one GPU (independent records) therefore take different classes. */
+int sgx_ctx_create_prio(const sgx_settings* s, int device, int priority, sgx_ctx** out);
 int sgx_ctx_destroy(sgx_ctx* c);
 int sgx_ctx_sync(sgx_ctx* c);                     /* hipStreamSynchronize on the context stream */
 int sgx_get_timing(sgx_ctx* c, sgx_timing* out);

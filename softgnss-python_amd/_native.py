@@ -66,6 +66,7 @@ _PROTOS = {
                                      C.POINTER(C.c_double)]),
     "sgx_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "sgx_ctx_create": (C.c_int, [C.POINTER(Settings), C.c_int, C.POINTER(_P)]),
+    "sgx_ctx_create_prio": (C.c_int, [C.POINTER(Settings), C.c_int, C.c_int, C.POINTER(_P)]),
     "sgx_ctx_destroy": (C.c_int, [_P]),
     "sgx_ctx_sync": (C.c_int, [_P]),
     "sgx_get_timing": (C.c_int, [_P, C.POINTER(Timing)]),
@@ -233,10 +234,12 @@ def nav_bits(i_p_row, sub_frame_start):
 class Context(object):
     """One device context (hipStream + scratch) per GPU."""
 
-    def __init__(self, settings, device=0):
+    def __init__(self, settings, device=0, priority=0):
+        """priority: stream priority class (-1 high, 0 normal, +1 low); contexts meant to run at the same time on
+        one GPU take different classes (they then never share a hardware queue)."""
         self._h = _P()
         self._s = settings_struct(settings)
-        check(lib().sgx_ctx_create(C.byref(self._s), int(device), C.byref(self._h)))
+        check(lib().sgx_ctx_create_prio(C.byref(self._s), int(device), int(priority), C.byref(self._h)))
         self.device = int(device)
 
     def close(self):

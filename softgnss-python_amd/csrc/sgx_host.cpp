@@ -138,7 +138,11 @@ extern "C" int sgx_device_count(int* n) {
 }
 
 extern "C" int sgx_ctx_create(const sgx_settings* s, int device, sgx_ctx** out) {
-    SGX_CHECK_ARG(s && out);
+    return sgx_ctx_create_prio(s, device, 0, out);
+}
+
+extern "C" int sgx_ctx_create_prio(const sgx_settings* s, int device, int priority, sgx_ctx** out) {
+    SGX_CHECK_ARG(s && out && priority >= -1 && priority <= 1);
     SGX_CHECK_ARG(s->codeLength == 1023 && s->samplingFreq > 0 && s->codeFreqBasis > 0);
     SGX_HIP(hipSetDevice(device));
     sgx_ctx* c = new sgx_ctx();
@@ -146,7 +150,14 @@ extern "C" int sgx_ctx_create(const sgx_settings* s, int device, sgx_ctx** out) 
     c->device = device;
     c->n_code = sgx_host_samples_per_code(s);
     memset(&c->timing, 0, sizeof(c->timing));
-    SGX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->priority = priority;
+    if (priority == 0) {
+        SGX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    } else {
+        int least = 0, greatest = 0;   // numerically: greatest priority <= least priority
+        SGX_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        SGX_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, priority < 0 ? greatest : least));
+    }
     for (int i = 0; i < 6; ++i) SGX_HIP(hipEventCreate(&c->ev[i]));
     std::vector<int8_t> codes(32 * 1023);
     for (int p = 0; p < 32; ++p) sgx_host_ca_code(p, codes.data() + p * 1023);
@@ -437,6 +448,7 @@ extern "C" int sgx_if_open_file(sgx_ctx* c, const char* path, uint64_t file_offs
         e = hipDeviceGetStreamPriorityRange(&lo, &hi);
         const char* pe = getenv("SGX_STREAM_PRIO");   // test hook: "0" = a normal-priority copy stream
         if (pe && pe[0] == '0') hi = 0;
+        if (c->priority < 0) hi = 0;   // the context itself runs at the highest priority: copies go one level below
         if (e == hipSuccess) e = hipStreamCreateWithPriority(&r->copy_stream, hipStreamNonBlocking, hi);
         if (e != hipSuccess) {   // no stream priorities here: an ordinary stream (the kernel's bounded wait covers it)
             (void)hipGetLastError();

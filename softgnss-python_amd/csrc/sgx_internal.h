@@ -64,6 +64,7 @@ int sgx_if_require(const sgx_if* r, size_t end);
 struct sgx_ctx {
     sgx_settings s;
     int device = 0;
+    int priority = 0;            // stream priority class of the context: -1 high, 0 normal, +1 low
     hipStream_t stream = nullptr;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     sgx_timing timing;

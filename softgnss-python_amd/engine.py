@@ -36,11 +36,12 @@ def get_context(settings, device=None):
 
 
 @contextlib.contextmanager
-def private_context(settings, device=None):
-    """A context used only by the calling thread for the duration of the block (closed afterwards)."""
+def private_context(settings, device=None, priority=0):
+    """A context used only by the calling thread for the duration of the block (closed afterwards).
+    priority: stream priority class (-1, 0, +1) - give contexts that run concurrently different classes."""
     dev = default_device() if device is None else int(device)
     key = (bytes(_native.settings_struct(settings)), dev)
-    ctx = _native.Context(settings, dev)
+    ctx = _native.Context(settings, dev, priority)
     prev = getattr(_local, "ctx", None)
     _local.ctx = (key, ctx)
     try:

@@ -951,7 +951,7 @@ def test_independent_records_on_one_gpu_at_once(default_record):
             s = m.Settings()
             s.numberOfChannels = 4
             s.msToProcess = 400.0
-            with m.engine.private_context(s, 0) as ctx:
+            with m.engine.private_context(s, 0, priority=(-1, 1, 0)[k]) as ctx:
                 rec = ctx.upload(default_record)
                 a = m.AcquisitionResult(s, device=0)
                 a.acquire(m.DeviceSignal(rec, 0, 11 * 38192))
