@@ -92,7 +92,23 @@ class AcquisitionResult(Result):
         return
 
     def plot(self):
-        raise NotImplementedError("plotting is outside the accelerated path (reference acquisition.py:206-256)")
+        """Bar chart of the acquisition metric per PRN, acquired signals highlighted (reference
+        acquisition.py:206-256).  Needs matplotlib; prints a notice and returns without it."""
+        from .initialize import _pyplot
+        plt = _pyplot("AcquisitionResult.plot")
+        if plt is None:
+            return
+        assert isinstance(self._results, np.recarray)
+        plt.figure(101)
+        plt.clf()
+        prn = np.arange(1, len(self.peakMetric) + 1)
+        plt.bar(prn, self.peakMetric)
+        found = self.carrFreq > 0
+        plt.bar(prn[found], self.peakMetric[found], color=(0, 0.8, 0))
+        plt.title('Acquisition results')
+        plt.xlabel('PRN number (no bar - SV is not in the acquisition list)')
+        plt.ylabel('Acquisition Metric')
+        plt.legend(['Not acquired signals', 'Acquired signals'])
 
     def preRun(self):
         """Channel table from the acquisition results (reference acquisition.py:259-306): stable

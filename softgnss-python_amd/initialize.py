@@ -42,6 +42,17 @@ class Result(object):
         pass
 
 
+def _pyplot(what):
+    """matplotlib.pyplot, or None (with a one-line notice) where matplotlib is not installed: a script that calls
+    plot() like the reference's postProcessing does keeps running."""
+    try:
+        import matplotlib.pyplot as plt
+        return plt
+    except ImportError:
+        print("   (%s: matplotlib is not installed, nothing drawn)" % what)
+        return None
+
+
 class TruePosition(object):
     """E/N/U holder (reference initialize.py:49-77)."""
 

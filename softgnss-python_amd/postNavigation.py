@@ -183,4 +183,36 @@ class NavigationResult(Result):
         return out
 
     def plot(self):
-        raise NotImplementedError("plotting is outside the accelerated path (reference postNavigation.py:307-439)")
+        """Coordinate variations around the mean fix, the fixes in the UTM plane and the satellites' azimuth /
+        elevation (the panels of reference postNavigation.py:307-439).  Needs matplotlib; prints a notice and
+        returns without it."""
+        from .initialize import _pyplot
+        plt = _pyplot("NavigationResult.plot")
+        if plt is None:
+            return
+        if self._solutions is None:
+            print('PLOTNAVIGATION: No navigation data to plot.')
+            return
+        sol = self._solutions[0]
+        ref = [np.nanmean(sol.E), np.nanmean(sol.N), np.nanmean(sol.U)]
+        plt.figure(300)
+        plt.clf()
+        ax = plt.subplot(2, 2, (1, 2))
+        for series, r0 in zip((sol.E, sol.N, sol.U), ref):
+            ax.plot(series - r0)
+        ax.set_title('Coordinates variations in UTM system')
+        ax.legend(['E', 'N', 'U'])
+        ax.set_xlabel('Measurement period: %i ms' % self._settings.navSolPeriod)
+        ax.set_ylabel('Variations (m)')
+        ax = plt.subplot(2, 2, 3)
+        ax.plot(sol.E - ref[0], sol.N - ref[1], '+')
+        ax.set_title('Positions in UTM system')
+        ax.set_xlabel('East (m)')
+        ax.set_ylabel('North (m)')
+        ax.axis('equal')
+        ax = plt.subplot(2, 2, 4, projection='polar')
+        ch = sol.channel[0]
+        ax.plot(np.radians(ch.az.T), 90 - ch.el.T, '.')
+        ax.set_theta_zero_location('N')
+        ax.set_theta_direction(-1)
+        ax.set_title('Sky plot (mean PDOP: %.2f)' % np.nanmean(np.where(sol.DOP[1] > 0, sol.DOP[1], np.nan)))

@@ -105,4 +105,38 @@ class TrackingResult(Result):
         return
 
     def plot(self):
-        raise NotImplementedError("plotting is outside the accelerated path (reference tracking.py:297-426)")
+        """One figure per tracked channel: discrete-time scatter, navigation bits, raw and filtered discriminators,
+        correlator magnitudes (the panels of reference tracking.py:297-426).  Needs matplotlib; prints a notice
+        and returns without it."""
+        from .initialize import _pyplot
+        plt = _pyplot("TrackingResult.plot")
+        if plt is None:
+            return
+        assert isinstance(self._results, np.recarray)
+        t = np.arange(int(self._settings.msToProcess)) / 1000.0
+        for k, r in enumerate(self._results):
+            plt.figure(200 + k)
+            plt.clf()
+            plt.suptitle('Channel %d (PRN %d) results' % (k, int(r.PRN)))
+            ax = plt.subplot(3, 3, 1)
+            ax.plot(r.I_P, r.Q_P, '.')
+            ax.set_title('Discrete-Time Scatter Plot')
+            ax.set_xlabel('I prompt')
+            ax.set_ylabel('Q prompt')
+            ax.axis('equal')
+            ax = plt.subplot(3, 3, (2, 3))
+            ax.plot(t, r.I_P)
+            ax.set_title('Bits of the navigation message')
+            ax.set_xlabel('Time (s)')
+            for pos, series, title in ((4, r.pllDiscr, 'Raw PLL discriminator'), (7, r.pllDiscrFilt, 'Filtered PLL discriminator'),
+                                       (6, r.dllDiscr, 'Raw DLL discriminator'), (9, r.dllDiscrFilt, 'Filtered DLL discriminator')):
+                ax = plt.subplot(3, 3, pos)
+                ax.plot(t, series)
+                ax.set_title(title)
+                ax.set_xlabel('Time (s)')
+            ax = plt.subplot(3, 3, (5, 8))
+            ax.plot(t, np.sqrt(r.I_E ** 2 + r.Q_E ** 2), t, np.sqrt(r.I_P ** 2 + r.Q_P ** 2),
+                    t, np.sqrt(r.I_L ** 2 + r.Q_L ** 2), '-*')
+            ax.set_title('Correlation results')
+            ax.set_xlabel('Time (s)')
+            ax.legend(['E', 'P', 'L'])

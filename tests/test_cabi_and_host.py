@@ -353,3 +353,40 @@ def test_ephemeris_round_trip_of_random_parameters():
                 want = q * 2.0 ** exp * (synth.GPS_PI if times_pi else 1.0) + (1024 if name == "weekNumber" else 0)
                 have = got[eph_mod.FIELDS.index(name)]
                 assert have == want or abs(have - want) <= 1e-15 * abs(want), (name, have, want)
+
+
+def test_plot_methods_run_headless():
+    """plot() of the three result classes draws with matplotlib when it is installed (Agg backend here) and
+    returns quietly when it is not - a script written for the reference, which calls them, keeps running."""
+    mpl = pytest.importorskip("matplotlib")
+    mpl.use("Agg")
+    m = pkg()
+    s = m.Settings()
+    s.numberOfChannels, s.msToProcess = 2, 50.0
+    a = m.AcquisitionResult(s)
+    cf = np.zeros(32)
+    cf[[0, 6]] = 9.55e6
+    a.results = np.rec.fromarrays([cf, np.zeros(32), np.linspace(1, 4, 32)], names='carrFreq,codePhase,peakMetric')
+    a.plot()
+    t = m.TrackingResult.__new__(m.TrackingResult)
+    t._settings = s
+    tr = pkg("tracking")
+    t._results = np.recarray((2,), dtype=tr.RESULT_DTYPE)
+    rng = np.random.default_rng(0)
+    for i in range(2):
+        for name in t._results.dtype.names[1:-1]:
+            t._results[i][name] = rng.normal(size=50)
+        t._results[i].status, t._results[i].PRN = b'T', 3 + i
+    t.plot()
+    g = load_golden("fix_scene.npz")
+    nav = m.NavigationResult.__new__(m.NavigationResult)
+    nav._settings = s
+    channel = np.rec.array([(g["chPRN"], g["el"], g["az"], g["rawP"], g["correctedP"])], formats=['O'] * 5,
+                           names='PRN,el,az,rawP,correctedP')
+    nav._solutions = np.rec.array([(channel, g["DOP"], g["X"], g["Y"], g["Z"], g["dt"], g["latitude"], g["longitude"],
+                                    g["height"], float(g["utmZone"]), g["E"], g["N"], g["U"])], formats=['O'] * 13,
+                                  names='channel,DOP,X,Y,Z,dt,latitude,longitude,height,utmZone,E,N,U')
+    nav.plot()
+    import matplotlib.pyplot as plt
+    assert len(plt.get_fignums()) >= 4
+    plt.close('all')
