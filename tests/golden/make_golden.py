@@ -127,7 +127,7 @@ def traced_acquire(acq, data):
 
 
 class PlotRecorder(types.ModuleType):
-    """Stand-in for matplotlib.pyplot (not installed here): records what probeData plots.  hist() bins like
+    """Stand-in for matplotlib.pyplot that records what probeData plots.  hist() bins like
     matplotlib does, through np.histogram."""
 
     def __init__(self):
