@@ -57,48 +57,32 @@ class TruePosition(object):
     """E/N/U holder (reference initialize.py:49-77)."""
 
     def __init__(self):
-        self.E = None
-        self.N = None
-        self.U = None
+        self.E = self.N = self.U = None
+
+
+# attribute -> default, the receiver configuration of reference initialize.py:85-173 (same names, same values)
+_DEFAULTS = (
+    ("msToProcess", 37000.0), ("numberOfChannels", 8), ("skipNumberOfBytes", 0),
+    ("fileName", 'GPSdata-DiscreteComponents-fs38_192-if9_55.bin'), ("dataType", 'int8'),
+    ("IF", 9548000.0), ("samplingFreq", 38192000.0), ("codeFreqBasis", 1023000.0), ("codeLength", 1023),
+    ("skipAcquisition", False), ("acqSearchBand", 14.0), ("acqThreshold", 2.5),
+    ("dllDampingRatio", 0.7), ("dllNoiseBandwidth", 2.0), ("dllCorrelatorSpacing", 0.5),
+    ("pllDampingRatio", 0.7), ("pllNoiseBandwidth", 25.0),
+    ("navSolPeriod", 500.0), ("elevationMask", 10.0), ("useTropCorr", True), ("plotTracking", True),
+)
 
 
 class Settings(object):
     """Receiver configuration; attribute names and defaults of reference initialize.py:81-173."""
 
+    c = property(lambda self: 299792458.0, doc="speed of light, m/s (read-only, initialize.py:170)")
+    startOffset = property(lambda self: 68.802, doc="initial travel-time guess, ms (read-only, initialize.py:172)")
+
     def __init__(self):
-        self.msToProcess = 37000.0
-        self.numberOfChannels = 8
-        self.skipNumberOfBytes = 0
-        self.fileName = 'GPSdata-DiscreteComponents-fs38_192-if9_55.bin'
-        self.dataType = 'int8'
-        self.IF = 9548000.0
-        self.samplingFreq = 38192000.0
-        self.codeFreqBasis = 1023000.0
-        self.codeLength = 1023
-        self.skipAcquisition = False
-        self.acqSatelliteList = range(1, 33)
-        self.acqSearchBand = 14.0
-        self.acqThreshold = 2.5
-        self.dllDampingRatio = 0.7
-        self.dllNoiseBandwidth = 2.0
-        self.dllCorrelatorSpacing = 0.5
-        self.pllDampingRatio = 0.7
-        self.pllNoiseBandwidth = 25.0
-        self.navSolPeriod = 500.0
-        self.elevationMask = 10.0
-        self.useTropCorr = True
+        for name, value in _DEFAULTS:
+            setattr(self, name, value)
+        self.acqSatelliteList = range(1, 33)      # PRN indices 0..31 are searched (acquisition.py:103)
         self.truePosition = TruePosition()
-        self.plotTracking = True
-        self._c = 299792458.0
-        self._startOffset = 68.802
-
-    @property
-    def c(self):
-        return self._c
-
-    @property
-    def startOffset(self):
-        return self._startOffset
 
     @property
     def samplesPerCode(self):
