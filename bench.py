@@ -6,15 +6,22 @@ in HBM: AcquisitionResult.acquire (32 PRNs, 2 x 1 ms coherent blocks, 29 Doppler
 -> preRun -> TrackingResult.track (8 channels x 37 000 ms).  BASELINE.json configs[1] + configs[2].
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-N > 1 is launched one process per GPU by `python -m torch.distributed.run`; every rank tracks its
-own 8 channels on its own copy of the record (weak scaling, BASELINE.json config 5) and searches
-32/N of the PRNs, the peaks being all-gathered with RCCL (config 4's exchange).
-Rank 0 prints ONE JSON line.
+
+N > 1 runs one process per GPU.  Either the driver starts the ranks (`python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N`: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the
+environment), or - when WORLD_SIZE is not set - this script starts them itself, as children, before it
+touches the GPU (`launch_ranks`), and exits non-zero when the node has fewer than N devices.  Every rank
+tracks its own 8 channels on its own copy of the record (weak scaling, BASELINE.json config 5) and
+searches 32/N of the PRNs, the peaks being all-gathered with RCCL (config 4's exchange).  The
+`acq_config4` leg reports BASELINE.json config 4 itself: 32 PRNs x 10 ms non-coherent, PRNs sharded over
+the ranks, gather included, next to the same search on one GPU.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,6 +32,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md)
+FP64_PEAK_TFLOPS = 78.6  # MI355X vector fp64 datasheet peak (256 CUs x 4 SIMDs x 16 FMA lanes x 2 x 2.4 GHz)
 REALTIME_MSPS = 38.192
 
 
@@ -41,16 +49,64 @@ def parse():
     ap.add_argument("--many-ms", type=int, default=500)
     ap.add_argument("--concurrent", type=int, default=3,
                     help="extra leg at N=1: this many independent records processed at once on one GPU (0 = skip)")
-    ap.add_argument("--cpu-trk-ms", type=int, default=4000, help="ms of 1-channel oracle tracking timed")
-    ap.add_argument("--cpu-acq-prns", type=int, default=16, help="PRNs of oracle acquisition timed")
+    ap.add_argument("--cpu-trk-ms", type=int, default=1000, help="ms of oracle tracking timed per channel (BASELINE.md 3)")
+    ap.add_argument("--no-config4", action="store_true", help="skip the acq_config4 leg")
     return ap.parse_args()
 
 
+# ---- self-launch -----------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def count_devices_in_child():
+    """Number of HIP devices, asked in a child process: the launcher itself must stay clear of the GPU runtime
+    (it goes on to start other programs)."""
+    code = ("import importlib,sys; sys.path.insert(0, %r); "
+            "print(importlib.import_module('softgnss-python_amd')._native.device_count())" % ROOT)
+    try:
+        r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        return int(r.stdout.decode().strip().splitlines()[-1])
+    except Exception:   # noqa: BLE001 - reported as "no devices"
+        return 0
+
+
+def launch_ranks(n, argv):
+    """Start `n` ranks of this script (one per GPU), relay rank 0's JSON line, return the exit code."""
+    have = count_devices_in_child()
+    if have < n:
+        sys.stderr.write("[bench] --gpus %d asked for, %d HIP device(s) visible: refusing to report a %d-GPU number\n"
+                         % (n, have, n))
+        return 3
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), SGX_DEVICE=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        sys.stderr.write("[bench] ranks failed: %s\n" % bad)
+        return 1
+    return 0
+
+
+# ---- CPU baseline (numpy oracle; runs before this process touches the GPU) ---------------------------
 def _cpu_acq(job):
     from oracle import softgnss_oracle as orc
-    host, n_prn = job
+    host, prns = job
     t0 = time.perf_counter()
-    r = orc.acquire(orc.OracleSettings(acqSatelliteList=list(range(1, n_prn + 1))), host, as_written=True)
+    r = orc.acquire(orc.OracleSettings(), host, as_written=True, prn_indices=prns)
     return time.perf_counter() - t0, r
 
 
@@ -65,48 +121,51 @@ def _cpu_trk(job):
 
 
 def cpu_baseline(pkg, scene, n_code, args, total_samples, n_ch, ms):
-    """Time the numpy oracle (a port of the reference's algorithm, as written) on a bounded sample of the same
-    workload, one process per host core up to 8 (PRNs and channels are independent, numpy's FFT and ufuncs are
-    single-threaded), and extrapolate linearly to the full step."""
+    """the numpy oracle (a port of the reference's algorithm, as written) on the host cores of
+    this box, one process per core up to 8 (PRNs and channels are independent; numpy's FFT and ufuncs are
+    single-threaded).  Config 2 (32 PRNs, as written) runs IN FULL; config 3 is timed on `cpu_trk_ms` ms x n_ch
+    channels and scaled linearly to `ms`."""
     from concurrent.futures import ProcessPoolExecutor
     from oracle import softgnss_oracle as orc
     workers = max(1, min(8, os.cpu_count() or 1))
     host = pkg.synth.generate(scene, pkg.synth.record_length(n_code, args.cpu_trk_ms))
-    k_prn = max(1, args.cpu_acq_prns // workers)
+    shards = [list(range(32))[w::workers] for w in range(workers)]
     with ProcessPoolExecutor(max_workers=workers) as ex:
         t0 = time.perf_counter()
-        res = list(ex.map(_cpu_acq, [(host[:11 * n_code], k_prn)] * workers))
-        t_acq = time.perf_counter() - t0                       # `workers` x k_prn PRN searches in parallel
-        ch = orc.pre_run(orc.OracleSettings(numberOfChannels=1), res[0][1])   # PRN 1 is in the scene
+        res = list(ex.map(_cpu_acq, [(host[:11 * n_code], sh) for sh in shards]))
+        t_acq = time.perf_counter() - t0                       # all 32 PRN searches, `workers` at a time
+        merged = res[0][1]
+        for _, r in res[1:]:
+            for k in ("carrFreq", "codePhase", "peakMetric"):
+                merged[k] = merged[k] + r[k]                    # disjoint PRN sets: the other entries are zero
+        chans = orc.pre_run(orc.OracleSettings(numberOfChannels=n_ch), merged)
+        jobs = []
+        for i in range(n_ch):
+            if chans["PRN"][i] != 0:
+                one = dict(PRN=chans["PRN"][i:i + 1], acquiredFreq=chans["acquiredFreq"][i:i + 1],
+                           codePhase=chans["codePhase"][i:i + 1], status=chans["status"][i:i + 1])
+                jobs.append((host, one, args.cpu_trk_ms))
         t0 = time.perf_counter()
-        t_each = list(ex.map(_cpu_trk, [(host, ch, args.cpu_trk_ms)] * workers))
-        t_trk = time.perf_counter() - t0                       # `workers` channels x cpu_trk_ms in parallel
-    full = t_acq * (32.0 / (workers * k_prn)) + t_trk * (n_ch * ms / float(workers * args.cpu_trk_ms))
-    one = np.mean([r[0] for r in res]) * (32.0 / k_prn) + np.mean(t_each) * (n_ch * ms / float(args.cpu_trk_ms))
+        t_each = list(ex.map(_cpu_trk, jobs))
+        t_trk = time.perf_counter() - t0                       # n_ch channels x cpu_trk_ms, `workers` at a time
+    full = t_acq + t_trk * (ms / float(args.cpu_trk_ms))
+    one_core = sum(r[0] for r in res) + sum(t_each) * (ms / float(args.cpu_trk_ms))
     return {"value": total_samples / full / 1e6, "unit": "Msamples/s", "cores": workers, "kind": "port",
-            "sample": "numpy oracle in %d processes: as-written acquisition of %d PRNs each on 11 ms (%.2f s) + one "
-                      "channel x %d ms tracking each (%.2f s), scaled linearly to 32 PRNs + %d channels x %d ms"
-                      % (workers, k_prn, t_acq, args.cpu_trk_ms, t_trk, n_ch, ms),
-            "seconds_extrapolated": full, "single_core_value": total_samples / one / 1e6}
+            "sample": "numpy oracle in %d processes: config 2 in full (as-written acquisition of all 32 PRNs on 11 ms, "
+                      "%.2f s) + %d channels x %d ms of tracking (%.2f s) scaled linearly to %d ms"
+                      % (workers, t_acq, len(jobs), args.cpu_trk_ms, t_trk, ms),
+            "seconds_extrapolated": full, "acq_config2_seconds": t_acq,
+            "single_core_value": total_samples / one_core / 1e6,
+            "single_core_acq_config2_seconds": sum(r[0] for r in res)}
 
 
-def guarded(label, seconds, fn, *a):
-    """Run an optional leg with a deadline: the headline JSON line must come out whatever the extras do."""
-    import threading
-    box = {}
-
-    def run():
-        try:
-            box["out"] = fn(*a)
-        except Exception as e:   # noqa: BLE001 - reported, never fatal
-            box["out"] = {"error": "%s: %r" % (label, e)}
-
-    t = threading.Thread(target=run, daemon=True)
-    t.start()
-    t.join(seconds)
-    if t.is_alive():
-        return {"error": "%s did not finish within %d s" % (label, seconds)}
-    return box["out"]
+# ---- optional GPU legs -------------------------------------------------------------------------------
+def leg(label, fn, *a):
+    """Run an optional leg on the main thread; an exception is reported in the JSON line, never fatal."""
+    try:
+        return fn(*a)
+    except Exception as e:   # noqa: BLE001
+        return {"error": "%s: %r" % (label, e)}
 
 
 def concurrent_records(pkg, s, scene, rec_len, n_code, local, args):
@@ -138,12 +197,12 @@ def concurrent_records(pkg, s, scene, rec_len, n_code, local, args):
                         raise RuntimeError("tracking ran out of record")
 
                 one()
-                ready.wait()
-                go.wait()
+                ready.wait(600)
+                go.wait(600)
                 for _ in range(args.steps):
                     one()
                 ctx.sync()
-                fin.wait()
+                fin.wait(600)
                 rec.free()
         except Exception as e:   # noqa: BLE001 - reported in the JSON line
             errors.append(repr(e))
@@ -154,10 +213,10 @@ def concurrent_records(pkg, s, scene, rec_len, n_code, local, args):
     for t in threads:
         t.start()
     try:
-        ready.wait()
+        ready.wait(600)
         t0 = time.perf_counter()
-        go.wait()
-        fin.wait()
+        go.wait(600)
+        fin.wait(600)
         dt = time.perf_counter() - t0
     except threading.BrokenBarrierError:
         dt = None
@@ -172,46 +231,59 @@ def concurrent_records(pkg, s, scene, rec_len, n_code, local, args):
                     "every record is still processed at its own latency-bound rate"}
 
 
-def pmc_traffic(channels, ms):
-    """HBM bytes per trk_kernel launch from the committed rocprofv3 PMC passes (profiles/), if they
-    were taken on this workload; None otherwise.  Counters cannot be read from inside the process."""
+def pmc_file(suffix, match):
+    """A committed rocprofv3 PMC summary under profiles/ (counters cannot be read from inside the process):
+    the newest file `*<suffix>` whose "workload" dict contains `match`."""
     best = None
     pdir = os.path.join(ROOT, "profiles")
     for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
-        if name.endswith("_pmc_trk_kernel.json"):
+        if name.endswith(suffix):
             try:
                 with open(os.path.join(pdir, name)) as f:
                     d = json.load(f)
             except (OSError, ValueError):
                 continue
             w = d.get("workload", {})
-            if w.get("channels") == channels and w.get("ms") == ms:
-                best = (d["hbm_bytes_per_launch"], "profiles/" + name)
+            if all(w.get(k) == v for k, v in match.items()):
+                best = (d, "profiles/" + name)
     return best
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("SGX_DEVICE", os.environ.get("LOCAL_RANK", "0")))   # one process per GPU
-    if world != args.gpus and world > 1:
-        args.gpus = world
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-
+    if world != args.gpus:
+        if world > 1:
+            args.gpus = world
+        else:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is 1" % args.gpus)
     pkg = importlib.import_module("softgnss-python_amd")
     shard = importlib.import_module("softgnss-python_amd.shard")
-    if pkg._native.device_count() < 1:
-        raise SystemExit("bench.py needs an MI355X: libsgx has no CPU path")
 
     s = pkg.Settings()
     s.msToProcess = float(args.ms)
     s.numberOfChannels = args.channels
     n_code = s.samplesPerCode
+    scene = pkg.synth.Scene.default()
+    rec_len = pkg.synth.record_length(n_code, args.ms)
+
+    # The CPU baseline forks worker processes: it runs first, while this process has not loaded the GPU runtime.
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = leg("cpu_baseline", cpu_baseline, pkg, scene, n_code, args, float(rec_len), args.channels, args.ms)
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    if pkg._native.device_count() < max(1, local + 1):
+        raise SystemExit("bench.py needs an MI355X per rank (rank %d wants device %d): libsgx has no CPU path"
+                         % (rank, local))
     ctx = pkg.engine.get_context(s, local)
 
     # ---- peak gather transport ----------------------------------------------------------------
@@ -225,10 +297,12 @@ def main():
         except Exception as e:   # flagged, never silent
             sys.stderr.write("[bench] rank %d: RCCL gather unavailable (%s); using host gather\n" % (rank, e))
             gather = shard.HostGather(dist)
+        names = [None] * world
+        dist.all_gather_object(names, gather.name)
+        if len(set(names)) != 1:   # a mixed transport would deadlock: everybody falls back, and says so
+            gather = shard.HostGather(dist)
 
     # ---- synthetic record, generated in HBM (bit-identical to softgnss-python_amd/synth.py) --------
-    scene = pkg.synth.Scene.default()
-    rec_len = pkg.synth.record_length(n_code, args.ms)
     rec = ctx.synth(scene, rec_len)
     signal = pkg.DeviceSignal(rec, 0, 11 * n_code)
 
@@ -244,6 +318,14 @@ def main():
     def barrier():
         if dist is not None:
             dist.barrier()
+
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0])
 
     # result buffers live in pinned host memory (the kernel writes its per-millisecond records straight into
     # them); pinning is slow, so the two buffers the steady state alternates between are created during setup
@@ -280,12 +362,50 @@ def main():
         acq_ms.append(last["acquire_ms"])
     device_sync()
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+
+    # ---- BASELINE.json config 4: 32 PRNs x 10 ms non-coherent, PRNs sharded, RCCL gather included ----------
+    cfg4 = None
+    if not args.no_config4:
+        sig4 = pkg.DeviceSignal(rec, 0, 20 * n_code)
+        reps = 5
+
+        def acq4(r, w, g):
+            a = pkg.AcquisitionResult(s, device=local)
+            shard.acquire_sharded(a, sig4, r, w, g, n_blocks=10, noncoh=True)
+            return a
+
+        acq4(rank, world, gather)
+        barrier()
+        device_sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            a4 = acq4(rank, world, gather)
+        device_sync()
+        barrier()
+        t_sharded = max_over_ranks(time.perf_counter() - t0) / reps * 1e3
+        dev_sharded = max_over_ranks(ctx.timing()["acquire_ms"])
+        if rank == 0:
+            # the same search on ONE GPU, timed in the same process (the other ranks wait at the barrier below)
+            one = shard.LocalGather()
+            acq4(0, 1, one)
+            device_sync()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                a1 = acq4(0, 1, one)
+            device_sync()
+            t_one = (time.perf_counter() - t0) / reps * 1e3
+            dev_one = ctx.timing()["acquire_ms"]
+            same = bool(np.array_equal(a1.codePhase, a4.codePhase) and np.array_equal(a1.carrFreq, a4.carrFreq) and
+                        np.array_equal(a1.internals["freqBin"], a4.internals["freqBin"]))
+            cfg4 = {"workload": "configs[3]: 32 PRNs x 10 ms non-coherent, %d PRN/GPU, peaks all-gathered (%s)"
+                                % (len(shard.plan_shards(32, world)[0]), gather.name),
+                    "ms": t_sharded, "ms_n1": t_one, "speedup_vs_n1": t_one / t_sharded,
+                    "device_ms_slowest_rank": dev_sharded, "device_ms_n1": dev_one,
+                    "sharded_result_equals_single_gpu": same,
+                    "note": "wall time per search incl. host glue and the gather, max over ranks; ms_n1 = the whole "
+                            "search on rank 0's GPU in the same run"}
+        barrier()
 
     # ---- accounting ----------------------------------------------------------------------------
     series = last["series"]
@@ -300,7 +420,7 @@ def main():
     value = world * samples_per_step * args.steps / elapsed / 1e6
 
     if rank == 0:
-        traffic = pmc_traffic(args.channels, args.ms)
+        traffic = pmc_file("_pmc_trk_kernel.json", {"channels": args.channels, "ms": args.ms})
         read_gbs, copy_gbs = ctx.stream_rates(1 << 30, 5)
         out = {
             "metric": "IF Msamples/s through acquisition + tracking (x real-time = value / 38.192)",
@@ -318,43 +438,98 @@ def main():
             "us_per_code_period": k_ms * 1e3 / args.ms,
             "roofline": {"kernel": "trk_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic[0] if traffic else None,
+                         "traffic": traffic[0]["hbm_bytes_per_launch"] if traffic else None,
                          "traffic_source": (traffic[1] + " (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes of this "
                                             "command; FETCH_SIZE x2, gfx950 correction)") if traffic else None,
                          "algorithmic_bytes_per_launch": b_trk,
                          "measured_stream_read_gbs": read_gbs, "measured_stream_copy_gbs": copy_gbs,
                          "frac_of_measured_read": achieved / read_gbs,
                          "note": "37 000 dependent steps per channel; 8 channels x 10 cooperating CUs = 80 of 256 "
-                                 "CUs busy: latency-bound, not bandwidth-bound (DESIGN.md section 5)"},
+                                 "CUs busy: latency-bound, not bandwidth-bound (DESIGN.md section 4.1)"},
         }
+        if cfg4 is not None:
+            out["acq_config4"] = cfg4
+        out["roofline_acq"] = leg("roofline_acq", acq_roofline, pkg, ctx, s, signal, local, n_code)
         if world == 1 and args.many_channels > 0:
-            # the throughput-mode kernel, where bandwidth and not the 37 000-step dependency chain is the limit: one
-            # CU per channel (two channels per CU), replicas of the acquired channels, HIP-event kernel time
-            def many_leg():
-                chans = [(int(c.PRN), float(c.acquiredFreq), float(c.codePhase)) for c in acq.channels if c.PRN != 0]
-                many = [chans[i % len(chans)] for i in range(args.many_channels)]
-                ctx.track(rec, many, 20)
-                ser, dn = ctx.track(rec, many, args.many_ms)
-                t_ms = ctx.timing()["track_ms"]
-                b_many = float(np.sum(ser[:, 0, -1] - np.array([c[2] for c in many]))) + \
-                    len(many) * args.many_ms * 13 * 8.0
-                return {"kernel": "trk_kernel_tp", "bound": "hbm", "channels": len(many), "ms": args.many_ms,
-                        "achieved": b_many / (t_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": b_many / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": t_ms,
-                        "frac_of_measured_read": b_many / (t_ms * 1e-3) / 1e9 / read_gbs,
-                        "note": "throughput-mode kernel (one lane per prompt chip, split=1): channels x ms code "
-                                "periods of independent work; fp64 VALU-bound at >= 4 instructions per sample"}
-            out["roofline_many_channels"] = guarded("roofline_many_channels", 180, many_leg)
+            out["roofline_many_channels"] = leg("roofline_many_channels", many_channels_leg, pkg, ctx, rec, acq, args,
+                                                read_gbs, n_code)
         if world == 1 and args.concurrent > 1:
-            out["concurrent_records"] = guarded("concurrent_records", 180, concurrent_records, pkg, s, scene, rec_len,
-                                                n_code, local, args)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = guarded("cpu_baseline", 600, cpu_baseline, pkg, scene, n_code, args, samples_per_step,
-                                          args.channels, args.ms)
+            out["concurrent_records"] = leg("concurrent_records", concurrent_records, pkg, s, scene, rec_len, n_code,
+                                            local, args)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out))
+        sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    ctx.sync()
+
+
+def acq_roofline(pkg, ctx, s, signal, local, n_code):
+    """Roofline of the acquisition (configs[1]): SURVEY.md section 8(d) names FFT arithmetic and on-chip bandwidth,
+    not HBM, as its roof.  Algorithmic flops = the deduplicated transform count x 5 N log2 N + pointwise + fine
+    search; algorithmic bytes = the 2 ms searched + 10 ms per detection + the result rows."""
+    a = pkg.AcquisitionResult(s, device=local)
+    a.acquire(signal)
+    ts = []
+    for _ in range(5):
+        a.acquire(signal)
+        ts.append(ctx.timing())
+    t_ms = float(np.mean([t["acquire_ms"] for t in ts]))
+    n_det = int(np.sum(a.carrFreq > 0))
+    bins = int(round(s.acqSearchBand * 2)) + 1
+    fft_n = 5.0 * n_code * np.log2(n_code)
+    flops = (2 * bins + 32 + 32 * 2 * bins) * fft_n + 32 * 2 * bins * n_code * 10.0 + n_det * 5.0 * 2 ** 22 * 22
+    alg_bytes = 2.0 * n_code + n_det * 10.0 * n_code + 32 * 24
+    pm = pmc_file("_pmc_acq.json", {"prns": 32, "blocks": 2})
+    out = {"kernel": "acquisition (all kernels of one sgx_acquire call)", "bound": "fp64 valu", "acquire_ms": t_ms,
+           "coarse_ms": float(np.mean([t["acq_coarse_ms"] for t in ts])),
+           "fine_ms": float(np.mean([t["acq_fine_ms"] for t in ts])), "detections": n_det,
+           "achieved": flops / (t_ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "frac": flops / (t_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "algorithmic_flops_per_call": flops,
+           "algorithmic_bytes_per_call": alg_bytes,
+           "traffic": pm[0]["hbm_bytes_per_call"] if pm else None, "traffic_source": pm[1] if pm else None,
+           "hbm_gbs_at_counter_traffic": (pm[0]["hbm_bytes_per_call"] / (t_ms * 1e-3) / 1e9) if pm else None}
+    return out
+
+
+def many_channels_leg(pkg, ctx, rec, acq, args, read_gbs, n_code):
+    """The throughput-mode kernel, where the 37 000-step dependency chain is not the limit: one workgroup per channel,
+    two per CU.  The channels are replicas of the acquired ones whose start offsets are STAGGERED over the record
+    (whole code periods apart, so every replica stays locked), so that the launch's working set is far larger than
+    the 256 MiB Infinity Cache and its bytes really come from HBM."""
+    chans = [(int(c.PRN), float(c.acquiredFreq), float(c.codePhase)) for c in acq.channels if c.PRN != 0]
+    span_ms = args.ms - args.many_ms - 2
+    many = []
+    for i in range(args.many_channels):
+        prn, f, cp = chans[i % len(chans)]
+        shift_ms = (i // len(chans)) * max(1, span_ms // max(1, args.many_channels // len(chans))) if span_ms > 0 else 0
+        many.append((prn, f, cp + shift_ms * n_code))
+    ctx.track(rec, many, 20)
+    ser, dn = ctx.track(rec, many, args.many_ms)
+    t_ms = ctx.timing()["track_ms"]
+    first = np.array([c[2] for c in many])
+    b_many = float(np.sum(ser[:, 0, -1] - first)) + len(many) * args.many_ms * 13 * 8.0
+    lo, hi = float(np.min(first)), float(np.max(ser[:, 0, -1]))
+    pm = pmc_file("_pmc_trk_tp.json", {"channels": len(many), "ms": args.many_ms})
+    out = {"kernel": "trk_kernel_tp", "channels": len(many), "ms": args.many_ms,
+           "achieved": b_many / (t_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": b_many / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": t_ms,
+           "frac_of_measured_read": b_many / (t_ms * 1e-3) / 1e9 / read_gbs,
+           "working_set_bytes": hi - lo, "locked_channels": int(np.sum(dn == args.many_ms)),
+           "note": "throughput-mode kernel (one lane per prompt chip, split=1): channels x ms code periods of "
+                   "independent work on distinct windows of the record"}
+    if pm:
+        d = pm[0]
+        out["traffic"] = d.get("hbm_bytes_per_launch")
+        out["valu_busy_frac"] = d.get("valu_busy_frac")
+        out["valu_insts_per_sample"] = d.get("valu_insts_per_sample")
+        out["traffic_source"] = pm[1]
+        out["bound"] = d.get("bound", "valu")
+    else:
+        out["bound"] = "valu"
+    return out
 
 
 if __name__ == "__main__":

@@ -134,7 +134,7 @@ def freq_bins(s):
     return np.array([s.IF - s.acqSearchBand / 2 * 1000 + 500.0 * k for k in range(nb)])
 
 
-def acquire(s, long_signal, n_prn=None, n_blocks=2, noncoh=False, as_written=False):
+def acquire(s, long_signal, n_prn=None, n_blocks=2, noncoh=False, as_written=False, prn_indices=None):
     """Parallel code-phase search + fine carrier estimate.  Follows acquisition.py:49-203.
 
     n_prn      number of PRN indices searched (reference: len(acqSatelliteList), Q1).
@@ -145,6 +145,8 @@ def acquire(s, long_signal, n_prn=None, n_blocks=2, noncoh=False, as_written=Fal
     as_written True recomputes the PRN-independent carrier mix and forward FFTs for every
                PRN exactly as the reference does (same values; only used to time the
                reference's own cost).
+    prn_indices  search only these PRN indices (0-based) instead of range(n_prn); the other entries stay zero
+               (lets the timing harness spread the 32 independent searches over processes).
     Returns a dict with the three reference outputs plus the internal indices.
     """
     x = np.asarray(long_signal)
@@ -173,7 +175,7 @@ def acquire(s, long_signal, n_prn=None, n_blocks=2, noncoh=False, as_written=Fal
     fine = np.full(32, -1, dtype=np.int64)
     bsel = np.full((32, nb), -1, dtype=np.int64)
     spc = int(round(s.samplingFreq / s.codeFreqBasis))       # acquisition.py:145
-    for p in range(n_prn):
+    for p in (range(n_prn) if prn_indices is None else prn_indices):
         code_fd = np.fft.fft(table[p]).conj()               # acquisition.py:95
         res = np.zeros((nb, n))
         for k in range(nb):

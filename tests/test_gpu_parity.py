@@ -1122,3 +1122,49 @@ def test_tracking_channels_without_a_signal(default_record):
     err = np.max(np.abs(t.series[:, 3:9] - want[:, 3:9]), axis=(1, 2)) / scale
     assert err.max() < 1e-6, err
     assert np.max(np.abs(t.series[:, 1:3] - want[:, 1:3])) < 1e-5
+
+
+def test_rccl_communicator_single_rank_roundtrip():
+    """The acquisition peak gather's native transport (sgx_comm_*: dlopen of librccl, ncclCommInitRank,
+    ncclAllGather on the context stream) with one rank on device 0: what it gathers is what was sent."""
+    m, s, ctx = _ctx()
+    sh = pkg("shard")
+    comm = m._native.Comm(ctx, 1, 0, m._native.Comm.unique_id())
+    try:
+        g = load_golden("acq_default.npz")
+        mine = list(range(32))
+        res = dict(carrFreq=g["carrFreq"], codePhase=g["codePhase"], peakMetric=g["peakMetric"],
+                   freqBin=g["freqBin"], fineIdx=g["fineIdx"])
+        buf = sh.pack_peaks(mine, res, 32)
+        gather = sh.RcclGather(comm)
+        for _ in range(3):
+            out = gather.allgather(buf)
+            assert out.shape == (1, 32)
+            assert out.tobytes() == buf.tobytes()
+        merged = sh.merge_peaks(out)
+        assert np.array_equal(merged["codePhase"], g["codePhase"])
+        # the sharded acquisition entry point over this transport equals the plain call
+        a = m.AcquisitionResult(s, device=0)
+        rec = ctx.synth(m.synth.Scene.default(), 11 * s.samplesPerCode)
+        sig = m.DeviceSignal(rec, 0, 11 * s.samplesPerCode)
+        sh.acquire_sharded(a, sig, 0, 1, gather)
+        b = m.AcquisitionResult(s, device=0)
+        b.acquire(sig)
+        assert np.array_equal(a.codePhase, b.codePhase) and np.array_equal(a.carrFreq, b.carrFreq)
+        rec.free()
+    finally:
+        comm.close()
+
+
+def test_bench_refuses_more_gpus_than_the_box_has():
+    """`python bench.py --gpus N` starts its own ranks; with fewer than N devices it must fail, not report n_gpus 1."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    n = pkg()._native.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    assert r.returncode != 0
+    assert b"n_gpus" not in r.stdout
+    assert b"refusing" in r.stderr

@@ -104,3 +104,42 @@ def test_peak_gather_world_size_2_gloo():
         assert p.exitcode == 0
     got = dict(q.get(timeout=10) for _ in range(2))
     assert got == {0: True, 1: True}
+
+
+def test_bench_self_launch_refuses_without_enough_devices():
+    """bench.py --gpus 2 with WORLD_SIZE unset starts its own ranks; on a box with fewer devices (here: none) it
+    exits non-zero and prints no JSON line - it never degrades silently to a 1-GPU measurement."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    if pkg()._native.device_count() >= 2:
+        pytest.skip("this box has two GPUs")
+    assert r.returncode != 0
+    assert b"n_gpus" not in r.stdout
+    assert b"refusing" in r.stderr
+
+
+def test_bench_launcher_starts_one_child_per_rank(tmp_path, monkeypatch):
+    """launch_ranks: N children with RANK/LOCAL_RANK/WORLD_SIZE/SGX_DEVICE/MASTER_* set, rank 0's stdout relayed,
+    a failing rank makes the launcher fail."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    stub = tmp_path / "rank.py"
+    stub.write_text("import os, sys\n"
+                    "r = int(os.environ['RANK']); w = int(os.environ['WORLD_SIZE'])\n"
+                    "assert os.environ['SGX_DEVICE'] == os.environ['LOCAL_RANK'] == str(r)\n"
+                    "assert os.environ['MASTER_ADDR'] == '127.0.0.1' and int(os.environ['MASTER_PORT']) > 0\n"
+                    "open(os.path.join(%r, 'seen%%d' %% r), 'w').write(str(w))\n"
+                    "print('{\"n_gpus\": %%d}' %% w) if r == 0 else None\n"
+                    "sys.exit(int(os.environ.get('FAIL_RANK', '-1')) == r)\n" % str(tmp_path))
+    monkeypatch.setattr(bench, "count_devices_in_child", lambda: 4)
+    monkeypatch.setattr(bench, "__file__", str(stub))
+    monkeypatch.setattr(bench.os.path, "abspath", lambda p: p)
+    assert bench.launch_ranks(3, []) == 0
+    assert sorted(p.name for p in tmp_path.iterdir() if p.name.startswith("seen")) == ["seen0", "seen1", "seen2"]
+    monkeypatch.setenv("FAIL_RANK", "2")
+    assert bench.launch_ranks(3, []) == 1
+    assert bench.launch_ranks(5, []) == 3   # more ranks than devices
