@@ -114,6 +114,10 @@ int sgx_generate_ca_code(int32_t prn0, double* out);
 int sgx_make_ca_table(const sgx_settings* s, double* out);
 /* Settings.calcLoopCoef(LBW, zeta, k), initialize.py:304-328 */
 int sgx_calc_loop_coef(double lbw, double zeta, double k, double* tau1, double* tau2);
+/* Host evaluation of the short-chain arithmetic the tracking kernel's loop-filter waves use (csrc/sgx_trk_math.h; on the
+ * host the hardware reciprocal seeds are replaced by float-precision ones).  Diagnostics for the parity tests:
+ * fn 0: 1/a   1: a/b   2: sqrt(a)   3: atan(a/b)   4: out[0..1] = sin, cos of 2 pi a   5: ceil(a/b) */
+int sgx_trk_math_eval(int32_t fn, double a, double b, double* out);
 
 /* ---- device context and IF records --------------------------------------------------------- */
 int sgx_device_count(int* n);

@@ -64,6 +64,7 @@ _PROTOS = {
     "sgx_make_ca_table": (C.c_int, [C.POINTER(Settings), _P]),
     "sgx_calc_loop_coef": (C.c_int, [C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double),
                                      C.POINTER(C.c_double)]),
+    "sgx_trk_math_eval": (C.c_int, [C.c_int32, C.c_double, C.c_double, _P]),
     "sgx_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "sgx_ctx_create": (C.c_int, [C.POINTER(Settings), C.c_int, C.POINTER(_P)]),
     "sgx_ctx_create_prio": (C.c_int, [C.POINTER(Settings), C.c_int, C.c_int, C.POINTER(_P)]),

@@ -14,6 +14,7 @@
 #include <string>
 
 #include "sgx_internal.h"
+#include "sgx_trk_math.h"
 
 static thread_local char g_err[512] = "";
 
@@ -495,6 +496,35 @@ extern "C" int sgx_if_download(sgx_ctx* c, const sgx_if* r, size_t offset, size_
     SGX_HIP(hipMemcpyAsync(host, r->d + offset, n, hipMemcpyDeviceToHost, c->stream));
     SGX_HIP(hipStreamSynchronize(c->stream));
     return SGX_OK;
+}
+
+extern "C" int sgx_trk_math_eval(int32_t fn, double a, double b, double* out) {
+    SGX_CHECK_ARG(out && fn >= 0 && fn <= 5);
+    switch (fn) {
+        case 0: out[0] = sgx_fast_rcp(a); break;
+        case 1: out[0] = sgx_fast_div(a, b); break;
+        case 2: out[0] = sgx_fast_sqrt(a); break;
+        case 3: out[0] = sgx_atan_ratio(a, b); break;
+        case 4: sgx_sincos_turns_short(a, out[0], out[1]); break;
+        default: out[0] = (double)sgx_ceil_div(a, b); break;
+    }
+    return SGX_OK;
+}
+
+// ---- co-residency budget of cooperative tracking launches ---------------------------------------
+static std::atomic<int> g_cu_used[64];
+
+int sgx_cu_reserve(int device, int cus_total, int want) {
+    if (device < 0 || device >= 64 || want <= 0) return 0;
+    int cur = g_cu_used[device].load();
+    for (;;) {
+        if (cur + want > cus_total) return 0;
+        if (g_cu_used[device].compare_exchange_weak(cur, cur + want)) return want;
+    }
+}
+
+void sgx_cu_release(int device, int n) {
+    if (device >= 0 && device < 64 && n > 0) g_cu_used[device].fetch_sub(n);
 }
 
 extern "C" int sgx_if_length(const sgx_if* r, size_t* n) {

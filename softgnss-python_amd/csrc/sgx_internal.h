@@ -93,6 +93,10 @@ struct sgx_ctx {
 };
 
 // sgx_host.cpp
+// Compute units claimed by this process's cooperative tracking launches (all contexts of a device): `want` CUs are
+// granted (returned) only if they fit next to what is already running, else 0.
+int sgx_cu_reserve(int device, int cus_total, int want);
+void sgx_cu_release(int device, int n);
 int sgx_host_ca_code(int prn0, int8_t* out /*1023*/);
 int64_t sgx_host_samples_per_code(const sgx_settings* s);
 

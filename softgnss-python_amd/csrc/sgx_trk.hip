@@ -46,10 +46,11 @@
 void sgx_trk_tp_launch(int n_blocks, hipStream_t st, const int8_t* rec, const int8_t* codes, const void* chans,
                        double* out, int* done, const TrkConst& K, long long* prof, unsigned long long* xch, int* err);
 
-// sgx_trk_spec.hip
-void sgx_trk_spec_launch(int n_blocks, hipStream_t st, const int8_t* rec, const int8_t* codes, const void* chans,
-                         double* out, int* done, const TrkConst& K, long long* prof, unsigned long long* xch,
-                         int* err);
+// sgx_trk2.hip: the round-2 latency-mode kernel (one unit per member, integer-atomic exchange, dedicated filter waves)
+void sgx_trk2_launch(int n_blocks, hipStream_t st, const int8_t* rec, const int8_t* codes, const TrkChan* chans,
+                     double* out, int* done, const TrkConst& K, long long* prof, unsigned long long* xch, int* err);
+#define T2_MAXP 16
+#define T2_XCH_STRIDE 256
 
 // sgx_trk_stream.hip: the cooperative kernel with watermark checks, for a record that is still streaming in
 void sgx_trk_stream_launch(int n_blocks, hipStream_t st, const int8_t* rec, const int8_t* codes, const TrkChan* chans,
@@ -187,7 +188,8 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
     // device-side call state lives in one cached allocation: [channels | done | exchange | err | profile]
     const size_t sz_ch = ((sizeof(TrkChan) * (size_t)n_ch + 255) / 256) * 256;
     const size_t sz_done = ((sizeof(int) * (size_t)n_ch + 255) / 256) * 256;
-    const size_t xch_bytes = sizeof(unsigned long long) * (size_t)n_ch * (2 * TRK_MAX_SPLIT * 12 + 16);
+    const size_t xch_words = (2 * TRK_MAX_SPLIT * 12 + 16) > T2_XCH_STRIDE ? (2 * TRK_MAX_SPLIT * 12 + 16) : T2_XCH_STRIDE;
+    const size_t xch_bytes = sizeof(unsigned long long) * (size_t)n_ch * xch_words;
     const size_t sz_xch = ((xch_bytes + 255) / 256) * 256;
     const size_t sz_prof = sizeof(long long) * 64 * (size_t)n_ch;
     const size_t need = sz_ch + sz_done + sz_xch + 256 + sz_prof;
@@ -209,10 +211,17 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
     const char* pe = getenv("SGX_TRK_PROFILE");
     const bool want_prof = pe && pe[0] == '1';
     long long* d_prof = want_prof ? (long long*)(aux + sz_ch + sz_done + sz_xch + 256) : nullptr;
-    // SGX_TRK_SPEC=1 selects the experimental speculative pipeline (sgx_trk_spec.hip; needs exactly one unit
-    // per member).  It reproduces the cooperative kernel's results but measured slower.
-    const char* sp = getenv("SGX_TRK_SPEC");
-    bool use_spec = false;
+    // The round-2 kernel (sgx_trk2.hip) gives every member exactly one unit: it runs when the CUs allow one workgroup
+    // per (channel, unit).  SGX_TRK_V1=1 (or an explicit SGX_TRK_SPLIT) keeps the round-1 cooperative kernel.
+    const char* v1 = getenv("SGX_TRK_V1");
+    int cus_total = 0;
+    SGX_HIP(hipDeviceGetAttribute(&cus_total, hipDeviceAttributeMultiprocessorCount, c->device));
+    const int ch8 = ((n_ch + 7) / 8) * 8;
+    bool use_v2 = !(v1 && v1[0] == '1') && !getenv("SGX_TRK_SPLIT") && !K.multi && K.n_units >= 2 && K.n_units <= T2_MAXP &&
+                  ch8 * K.n_units <= cus_total;
+    const int split_v1 = K.split;
+    int reserved = 0;
+    bool used_v2 = false;
     hipError_t e = hipSuccess;
     int h_err = 0;
     // The cooperating workgroups of a channel wait for each other, so all of them must be resident at once.  If
@@ -222,13 +231,25 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
         SGX_HIP(hipMemcpyAsync(d_ch, hc.data(), sizeof(TrkChan) * (size_t)n_ch, hipMemcpyHostToDevice, st));
         SGX_HIP(hipMemsetAsync(aux + sz_ch, 0, sz_done + sz_xch + 256, st));   // done, every polled word, err
         if (!direct) trk_fill_kernel<<<(unsigned)((elems + 255) / 256), 256, 0, st>>>(d_out, ms, (long long)elems);
-        const int n_blocks = ((n_ch + 7) / 8) * 8 * K.split;
-        use_spec = (K.split > 1 && K.split == K.n_units) && (sp && sp[0] == '1') && !K.multi;
+        // a record that is still streaming in is followed by the round-1 kernel's watermark variant
+        const char* se2 = getenv("SGX_TRK_STREAM");
+        const bool want_stream = r->loader && !r->load_done.load() && attempt == 0 && !(se2 && se2[0] == '0') && !K.multi &&
+                                 !(split_v1 == 1 && n_ch > 128);
+        const bool v2 = use_v2 && attempt == 0 && !want_stream;
+        if (attempt == 0) K.split = v2 ? K.n_units : split_v1;
+        // Cooperating workgroups wait for each other, so all of a launch must be resident at once: one workgroup per CU
+        // out of a per-device budget shared by every context of this process (a launch that does not fit the CUs left
+        // by the others runs with one workgroup per channel, which needs no co-residency).
+        if (K.split > 1) {
+            reserved = sgx_cu_reserve(c->device, cus_total, ch8 * K.split);
+            if (reserved == 0) {
+                K.split = 1;
+            }
+        }
+        const int n_blocks = ch8 * K.split;
         // a record that is still streaming in: the cooperative kernel follows the device watermark; the other
         // kernels (and a repeated launch) first wait for the whole record
-        const char* se2 = getenv("SGX_TRK_STREAM");
-        const bool streaming = r->loader && !r->load_done.load() && !use_spec && !(K.split == 1 && n_ch > 128) &&
-                               attempt == 0 && !(se2 && se2[0] == '0') && !K.multi;
+        const bool streaming = want_stream;
         if (!streaming) {
             const int rq = sgx_if_require(r, r->n);
             if (rq != SGX_OK) return rq;
@@ -238,8 +259,12 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
         hipEventRecord(c->ev[3], st);
         if (streaming)
             sgx_trk_stream_launch(n_blocks, st, r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err);
-        else if (use_spec)
-            sgx_trk_spec_launch(n_blocks, st, r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err);
+        else if (v2 && K.split > 1) {
+            const char* wh = getenv("SGX_TRK_TEST_WITHHOLD");   // test hook: launch without each channel's last member
+            const int nb2 = (wh && wh[0] == '1') ? n_blocks - 8 : n_blocks;
+            sgx_trk2_launch(nb2, st, r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err);
+            used_v2 = true;
+        }
         else if (K.split == 1 && n_ch > 128)   // (general in the sampling rate: one lane per prompt chip)
             sgx_trk_tp_launch(n_blocks, st, r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err);
         else if (K.multi)
@@ -252,6 +277,8 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
         h_err = 0;
         if (e == hipSuccess) e = hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (reserved) sgx_cu_release(c->device, reserved);
+        reserved = 0;
         const char* th = getenv("SGX_TRK_TEST_TIMEOUT");   // test hook: treat the first attempt as timed out
         if (e == hipSuccess && th && th[0] == '1' && attempt == 0 && K.split > 1) h_err = 1;
         if (e == hipSuccess && (h_err & TRK_ERR_STREAM) && attempt == 0) {
@@ -262,6 +289,12 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
             continue;
         }
         h_err &= ~TRK_ERR_STREAM;
+        if (e == hipSuccess && (h_err & TRK_ERR_RANGE)) {
+            sgx_set_error("tracking: channel %d reached a block longer than the %d units of %d samples the kernel "
+                          "provides (the code NCO left its plausible range; dllNoiseBandwidth %g)",
+                          (h_err & 0xFFFF) - 1, K.n_units, TRK_UNIT, S.dllNoiseBandwidth);
+            return SGX_E_RANGE;
+        }
         if (e != hipSuccess || h_err == 0 || K.split == 1) break;
         fprintf(stderr, "[sgx] tracking: channel %d timed out waiting for a cooperating workgroup (split %d, are the "
                         "CUs shared?); repeating the launch with one workgroup per channel\n", h_err - 1, K.split);
@@ -273,21 +306,12 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
     if (want_prof && e == hipSuccess) {
         std::vector<long long> hp(64 * (size_t)n_ch);
         hipMemcpy(hp.data(), d_prof, sizeof(long long) * hp.size(), hipMemcpyDeviceToHost);
-        if (use_spec) {
-            for (int i = 0; i < n_ch && i < 1; ++i) {
-                const long long* q = &hp[64 * i];
-                const double d = (double)ms;
-                fprintf(stderr, "[sgx trk profile] ch %d spec: exact %lld/%lld wave-blocks\n", i, q[63], 4ll * ms);
-                for (int mm = 0; mm < 2; ++mm) {
-                    const long long* c2 = q + 8 * mm;
-                    fprintf(stderr, "   CAR member %d: bookkeeping %.0f | wait-partials %.0f | rowsum+publish %.0f | poll %.0f | totals %.0f | PLL %.0f | tables+stores %.0f  (sum %.0f)\n",
-                            mm * 5, c2[0] / d, c2[1] / d, c2[4] / d, c2[5] / d, c2[2] / d, c2[6] / d, c2[3] / d,
-                            (c2[0] + c2[1] + c2[2] + c2[3] + c2[4] + c2[5] + c2[6]) / d);
-                }
-                fprintf(stderr, "   COD: wait-totals %.0f | DLL+params %.0f | prediction+stores %.0f\n", q[16] / d, q[18] / d, q[17] / d);
-                fprintf(stderr, "   MAP w2: wait-params %.0f finalize %.0f fold %.0f wait-pred %.0f shadow %.0f | w4: wait-params %.0f finalize %.0f fold %.0f wait-pred %.0f shadow %.0f\n",
-                        q[24] / d, q[25] / d, q[26] / d, q[27] / d, q[28] / d, q[32] / d, q[33] / d, q[34] / d, q[35] / d, q[36] / d);
-            }
+        if (used_v2) {
+            for (int i = 0; i < n_ch && i < 8; ++i)
+                for (int mm = 0; mm < K.split; mm += (i == 0 ? 1 : K.split - 1))
+                    fprintf(stderr, "[sgx trk2 profile] ch %d member %2d cycles/block: release->publish %.0f  publish->sums %.0f  "
+                                    "sums->release %.0f\n", i, mm, (double)hp[64 * i + mm] / ms,
+                            (double)hp[64 * i + 16 + mm] / ms, (double)hp[64 * i + 32 + mm] / ms);
         } else
         for (int i = 0; i < n_ch && i < 4; ++i)
             fprintf(stderr, "[sgx trk profile] ch %d cycles/block: map %.0f wait %.0f reduce %.0f filter %.0f\n", i,

@@ -390,3 +390,72 @@ def test_plot_methods_run_headless():
     import matplotlib.pyplot as plt
     assert len(plt.get_fignums()) >= 4
     plt.close('all')
+
+
+def _math_eval(fn, a, b=0.0):
+    import ctypes as C
+    L = pkg()._native.lib()
+    out = (C.c_double * 2)()
+    assert L.sgx_trk_math_eval(fn, float(a), float(b), out) == 0
+    return out[0], out[1]
+
+
+def test_short_chain_loop_filter_arithmetic_ulp_bounds(built):
+    """csrc/sgx_trk_math.h (the loop-filter waves' reciprocal-based division and square root, short atan, Estrin
+    sincos, division-free ceil) against 50-digit arithmetic.  The host build starts its Newton iterations from a
+    float-precision seed (worse than v_rcp_f64 / v_rsq_f64), so these bounds hold on the device too."""
+    import math
+    import mpmath as mp
+    mp.mp.dps = 50
+    rng = np.random.default_rng(20260102)
+
+    def ulps(got, exact):
+        if exact == 0:
+            return abs(got)
+        e = abs(mp.mpf(got) - exact)
+        return float(e / (mp.mpf(2) ** (math.frexp(float(exact))[1] - 53)))
+
+    worst = dict(rcp=0.0, div=0.0, sqrt=0.0, atan=0.0, sin=0.0, cos=0.0)
+    for _ in range(4000):
+        a = float(rng.uniform(-1, 1) * 10.0 ** rng.uniform(-3, 7))
+        b = float(rng.choice([-1, 1]) * 10.0 ** rng.uniform(-3, 7))
+        worst["rcp"] = max(worst["rcp"], ulps(_math_eval(0, b)[0], 1 / mp.mpf(b)))
+        worst["div"] = max(worst["div"], ulps(_math_eval(1, a, b)[0], mp.mpf(a) / mp.mpf(b)))
+        x = abs(a) ** 2
+        worst["sqrt"] = max(worst["sqrt"], ulps(_math_eval(2, x)[0], mp.sqrt(mp.mpf(x))))
+        # atan(q / i): both the short path (|q/i| <= 0.25) and the libm path; the argument itself is within 1 ulp
+        q = float(rng.uniform(-1, 1) * 10.0 ** rng.uniform(-2, 5))
+        i = float(rng.choice([-1, 1]) * abs(q) * 10.0 ** rng.uniform(-1, 3))
+        worst["atan"] = max(worst["atan"], ulps(_math_eval(3, q, i)[0], mp.atan(mp.mpf(q) / mp.mpf(i))))
+        u = float(rng.uniform(0, 2))
+        sn, cs = _math_eval(4, u)
+        ex_s, ex_c = mp.sin(2 * mp.pi * mp.mpf(u)), mp.cos(2 * mp.pi * mp.mpf(u))
+        # absolute error in units of 2^-53 (the phasors have modulus 1; what matters is the phase error)
+        worst["sin"] = max(worst["sin"], float(abs(mp.mpf(sn) - ex_s) * 2 ** 53))
+        worst["cos"] = max(worst["cos"], float(abs(mp.mpf(cs) - ex_c) * 2 ** 53))
+    assert worst["rcp"] <= 1.0 and worst["div"] <= 1.5 and worst["sqrt"] <= 1.0, worst
+    assert worst["atan"] <= 2.5, worst
+    assert worst["sin"] <= 4.0 and worst["cos"] <= 4.0, worst
+    assert _math_eval(2, 0.0)[0] == 0.0
+    assert _math_eval(3, 1.0, 0.0)[0] == math.atan(math.inf) and _math_eval(3, -1.0, 0.0)[0] == -math.atan(math.inf)
+    assert math.isnan(_math_eval(3, 0.0, 0.0)[0])
+
+
+def test_division_free_ceil_equals_ieee_ceil(built):
+    """sgx_ceil_div(a, b) == ceil(a / b) for the block-length computation blksize = ceil((1023 - rem) / step)
+    (tracking.py:148-151), including quotients that are exact integers or within a few ulp of one."""
+    import math
+    rng = np.random.default_rng(7)
+    fs = 38.192e6
+    for k in range(20000):
+        step = (1.023e6 + rng.normal(0, 5)) / fs
+        if k % 4 == 0:
+            # quotient at (or a few ulp next to) an integer
+            n = int(rng.integers(38000, 38400))
+            a = n * step
+            a = float(np.nextafter(a, a + rng.choice([-1.0, 1.0]) * 1.0)) if k % 8 else a
+            for _ in range(int(rng.integers(0, 4))):
+                a = float(np.nextafter(a, a + 1.0))
+        else:
+            a = 1023.0 - rng.uniform(-0.05, 0.05)
+        assert int(_math_eval(5, a, step)[0]) == math.ceil(a / step), (a, step)

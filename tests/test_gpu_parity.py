@@ -320,24 +320,44 @@ def test_many_channels_throughput_mode(full_run):
     assert _trk_err(s2[:8], series[:, :, :ms]) < 1e-9
 
 
-def test_speculative_pipeline_agrees_with_cooperative_kernel(full_run):
-    """SGX_TRK_SPEC=1 (shadow map + exact correction, sgx_trk_spec.hip) must reproduce the default kernel:
-    identical block boundaries, sums equal to rounding, over a long run including the pull-in transient."""
+def test_round1_and_round2_kernels_agree_on_a_long_run(full_run):
+    """SGX_TRK_V1=1 (the round-1 cooperative kernel: fp64 granule exchange, libm loop filter) against the default
+    round-2 kernel (prepared switch candidates, integer-atomic exchange, short-chain loop filter): identical block
+    boundaries and sums equal to rounding over a long run including the pull-in transient."""
     m, s, ctx, sc, rec, a, chans, series, done = full_run
-    old = os.environ.get("SGX_TRK_SPEC")
+    old = os.environ.get("SGX_TRK_V1")
     try:
-        os.environ["SGX_TRK_SPEC"] = "1"
+        os.environ["SGX_TRK_V1"] = "1"
         ms = 12000
         s2, d2 = ctx.track(rec, chans, ms)
     finally:
         if old is None:
-            os.environ.pop("SGX_TRK_SPEC", None)
+            os.environ.pop("SGX_TRK_V1", None)
         else:
-            os.environ["SGX_TRK_SPEC"] = old
+            os.environ["SGX_TRK_V1"] = old
     assert np.all(d2 == ms)
     assert np.array_equal(s2[:, 0], series[:, 0, :ms])
     assert _trk_err(s2, series[:, :, :ms]) < 1e-9
     assert np.max(np.abs(s2[:, 1:3] - series[:, 1:3, :ms])) < 1e-6
+
+
+def test_a_withheld_member_aborts_the_channel_quickly(full_run, capfd):
+    """The launch really lacks one member per channel (SGX_TRK_TEST_WITHHOLD=1): the others must give the channel up
+    within one poll budget - not spin block after block - and the host's repeat with one workgroup per channel must
+    deliver the usual results."""
+    import time
+    m, s, ctx, sc, rec, a, chans, series, done = full_run
+    os.environ["SGX_TRK_TEST_WITHHOLD"] = "1"
+    try:
+        t0 = time.perf_counter()
+        s2, d2 = ctx.track(rec, chans, 500)
+        dt = time.perf_counter() - t0
+    finally:
+        os.environ.pop("SGX_TRK_TEST_WITHHOLD", None)
+    assert "repeating the launch with one workgroup per channel" in capfd.readouterr().err
+    assert dt < 20.0, dt
+    assert np.all(d2 == 500) and np.array_equal(s2[:, 0], series[:, 0, :500])
+    assert _trk_err(s2, series[:, :, :500]) < 1e-9
 
 
 def test_second_front_end_golden():
@@ -361,7 +381,7 @@ def test_second_front_end_golden():
     assert np.allclose(a.peakMetric, g["peakMetric"], rtol=1e-9, atol=0)
     a.preRun()
     assert np.array_equal(a.channels.PRN, g["ch_PRN"])
-    for env in ({}, {"SGX_TRK_SPLIT": "1"}, {"SGX_TRK_SPEC": "1"}):
+    for env in ({}, {"SGX_TRK_SPLIT": "1"}, {"SGX_TRK_V1": "1"}):
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:

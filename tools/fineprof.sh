@@ -3,7 +3,7 @@
 # Usage (GPU box): bash tools/fineprof.sh     -- restores the normal build afterwards
 set -e
 cd "$(dirname "$0")/.."
-SGX_EXTRA_FLAGS=-DTRK_FINEPROF python softgnss-python_amd/build.py --force >/dev/null 2>&1
+SGX_EXTRA_FLAGS=-DTRK_FINEPROF=${FINEPROF_LEVEL:-1} python softgnss-python_amd/build.py --force >/dev/null 2>&1
 SGX_TRK_PROFILE=1 python - <<'PY'
 import importlib, sys
 sys.path.insert(0, '.')

@@ -128,14 +128,16 @@ __device__ __forceinline__ unsigned xcc_id() {
 // MODE 1: integer atomics, workgroup scope (L2 of the XCD), sc1 polls
 // MODE 2: integer atomics, agent scope
 // MODE 3: as 1, the six words spread over two 64-byte lines (I/Q of P | E and L)
+// MODE 4: as 1, polled with returning atomic ORs of zero at workgroup scope (always served by the XCD's L2)
+// MODE 5: as 1, polled with nt loads
 template <int MODE>
 __global__ __launch_bounds__(256) void xch_kernel(unsigned long long* xch, long long* cyc, int P, int rounds, int work,
-                                                  double* sink, int* bad) {
+                                                  double* sink, int* bad, long long stride_words) {
     const int bq = blockIdx.x >> 3, br = blockIdx.x & 7;
     const int ch = br + 8 * (bq / P);
     const int member = bq % P;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    unsigned long long* base = xch + (size_t)ch * 1024;
+    unsigned long long* base = xch + (size_t)ch * stride_words;
     __shared__ double s_v[8];
     double acc = 1.0 + member;
     long long t_total = 0;
@@ -198,7 +200,11 @@ __global__ __launch_bounds__(256) void xch_kernel(unsigned long long* xch, long 
                 int budget = 1 << 20;
                 const unsigned long long pv = prev[it & 1];
                 for (;;) {
-                    if (lane < 6) x = __hip_atomic_load(lp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane < 6) {
+                        if (MODE == 4) x = __hip_atomic_fetch_or(lp, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        else if (MODE == 5) x = __builtin_nontemporal_load(lp);
+                        else x = __hip_atomic_load(lp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                     const bool ok = lane >= 6 || (((x - pv) & 31ull) == (unsigned long long)P);
                     if (__all(ok)) break;
                     if (--budget == 0) {
@@ -226,13 +232,13 @@ __global__ __launch_bounds__(256) void xch_kernel(unsigned long long* xch, long 
 }
 
 template <int MODE>
-static void run_xch(const char* name, int P, int work) {
+static void run_xch(const char* name, int P, int work, long long stride_words = 1024) {
     const int n_ch = 8, rounds = 4000;
     unsigned long long* x;
     long long* c;
     double* sink;
     int* bad;
-    (void)hipMalloc(&x, 8 * 1024 * n_ch);
+    (void)hipMalloc(&x, 8 * stride_words * n_ch + 4096);
     (void)hipMalloc(&c, 8 * 256);
     (void)hipMalloc(&sink, 8 * 256 * 256);
     (void)hipMalloc(&bad, 4);
@@ -240,13 +246,13 @@ static void run_xch(const char* name, int P, int work) {
     long long hc[256];
     int hb = 0;
     for (int rep = 0; rep < 3; ++rep) {
-        (void)hipMemset(x, 0, 8 * 1024 * n_ch);
+        (void)hipMemset(x, 0, 8 * stride_words * n_ch + 4096);
         (void)hipMemset(bad, 0, 4);
         hipEvent_t e0, e1;
         hipEventCreate(&e0);
         hipEventCreate(&e1);
         hipEventRecord(e0);
-        xch_kernel<MODE><<<n_ch * P, 256>>>(x, c, P, rounds, work, sink, bad);
+        xch_kernel<MODE><<<n_ch * P, 256>>>(x, c, P, rounds, work, sink, bad, stride_words);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms = 0;
@@ -258,8 +264,17 @@ static void run_xch(const char* name, int P, int work) {
     double mean = 0;
     for (int i = 0; i < n_ch * P; ++i) mean += (double)hc[i] / rounds;
     mean /= n_ch * P;
-    printf("B  %-34s P %2d work %4d : %7.3f us per round, exchange segment %7.1f cycles (mean over members)%s\n", name, P,
-           work, best * 1e3 / rounds, mean, hb ? "  ** CHECK FAILED **" : "");
+    printf("B  %-34s P %2d work %4d stride %8lld B: %7.3f us per round, exchange segment %7.1f cycles (mean)%s | per channel:", name, P,
+           work, stride_words * 8, best * 1e3 / rounds, mean, hb ? "  ** CHECK FAILED **" : "");
+    for (int chn = 0; chn < n_ch; ++chn) {
+        double m2 = 0;
+        for (int mm = 0; mm < P; ++mm) {
+            // block index of (channel, member): bq = (chn / 8) * P + mm, br = chn % 8
+            m2 += (double)hc[((chn / 8) * P + mm) * 8 + (chn % 8)] / rounds;
+        }
+        printf(" %5.0f", m2 / P);
+    }
+    printf("\n");
     (void)hipFree(x);
     (void)hipFree(c);
     (void)hipFree(sink);
@@ -284,13 +299,12 @@ int main() {
     run_chain<14>("2 readlane + add", 1.3, 0.7);
     run_chain<11>("LDS store -> load (same wave) + add", 1.3, 0.7);
     run_chain<12>("LDS store -> __syncthreads -> load + add", 1.3, 0.7);
-    for (int P : {10, 16}) {
-        for (int work : {0, 300}) {
-            run_xch<0>("granules (plain store, sc1 poll)", P, work);
-            run_xch<1>("int64 atomics, workgroup scope", P, work);
-            run_xch<3>("int64 atomics, wg scope, 2 lines", P, work);
-            run_xch<2>("int64 atomics, agent scope", P, work);
-        }
+    for (long long stride : {64ll, 512ll, 8192ll, 131072ll, 1048576ll + 24}) {
+        run_xch<0>("granules (plain store, sc1 poll)", 10, 300, stride);
+        run_xch<1>("int64 atomics wg, sc1 poll", 10, 300, stride);
+        run_xch<4>("int64 atomics wg, atomic-or poll", 10, 300, stride);
+        run_xch<5>("int64 atomics wg, nt poll", 10, 300, stride);
+        run_xch<2>("int64 atomics agent, sc1 poll", 10, 300, stride);
     }
     return 0;
 }
