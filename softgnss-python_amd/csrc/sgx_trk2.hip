@@ -77,19 +77,24 @@
 #define T2PROBE(role, k) do { } while (0)
 #endif
 
-struct T2Code {   // code side of a block's parameters (DLL wave -> everybody), double-buffered by block parity
-    long long pos;          // record index of the block's first sample
-    long long pos_next;     // ... and of the next block's
+struct __attribute__((aligned(256))) T2Code {   // code side of a block's parameters (DLL wave -> everybody), by block parity
+    // chain part: written right before the barrier that starts the block
     int blk;
     int stop;               // 1: the record ends inside this block (tracking.py:159-163); 2: a member gave up waiting;
                             // 3: the block does not fit the units of the launch
     int fast_ok;            // the prepared switch candidates are within one sample of the true ones
-    int pad;
-    double inv_step;        // ~ 1 / codePhaseStep (estimates only)
-    double pad2;
-    double start[4];        // ramp starts E, P, L (tracking.py:166-188; [3] unused)
-    double step[4];         // ramp steps
-    double start_n[4];      // ramp starts of the NEXT block (its rates are not known yet)
+    int pad0;
+    double step[4];         // ramp steps E, P, L (tracking.py:166-188; [3] unused)
+    // early part: known one block earlier (written while the previous block is processed)
+    long long pos;          // record index of the block's first sample
+    long long pad1;
+    double start[4];        // ramp starts E, P, L
+    // late part, about the NEXT block, written while this block is processed; valid once ready == block index + 1
+    double start_n[4];      // ramp starts of the next block (its rates are not known yet)
+    double inv_step;        // ~ 1 / codePhaseStep of this block (estimates only)
+    long long pos_next;
+    int ready;
+    int pad2[3];
 };
 
 struct T2Carr {   // carrier side (PLL wave -> map waves), double-buffered: (cos, sin)(2 pi r m), r = turns per sample
@@ -155,9 +160,9 @@ __device__ __forceinline__ void ramp_resolve(const T2Ramp& R, double start, doub
     const double Tc = R.cd * step + start;
     const double Tm = R.cm1d * step + start;
     const double T0 = ilod * step + start;
-    const bool abv_m = Tm > R.Kd, abv_c = Tc > R.Kd;
-    const int cp = abv_m ? R.c - 1 : (abv_c ? R.c : R.c + 1);
-    const bool caseB = T0 > R.Kd;          // first sample already in chip K + 1
+    // t() is monotonic: Tm > K implies Tc > K, so the switch sample is c + 1 - [Tc > K] - [Tm > K]
+    const int cp = R.c + 1 - (int)(Tc > R.Kd) - (int)(Tm > R.Kd);
+    const bool caseB = T0 > R.Kd;          // first sample already in chip K + 1 (then cp <= ilo)
     const bool caseC = T0 <= R.Km1d;       // first sample still in chip K - 1
     isw = caseB ? 0x3FFFFFFF : (caseC ? ilo + 1 : cp);
     const unsigned sh = caseB ? 2u : (caseC ? 0u : 1u);   // position of chip k1 among the four prepared ones
@@ -186,10 +191,8 @@ __device__ __forceinline__ void t2_carr_tables(double inv_2pifs_hi, double inv_2
     CN.T[lane < 48 ? lane : 48] = make_double2(cs, sn);
 }
 
-// Block size and ramps (T1, T3, T4) of the block that starts at pos_cur with code phase remCode and rate codeFreq, the
-// starts of the block after it, and whether candidates prepared with `prev`'s rates stay within one sample of the truth.
-// Advances remCode / pos_cur to the block after.  Lanes work in parallel on the three ramps: lane & 3 = 0 early,
-// 1 prompt, 2 late (3 repeats prompt); uniform results come from lane 1.
+// DLL-wave constants and the loop state it carries in registers.  Lanes work in parallel on the three ramps:
+// lane & 3 = 0 early, 1 prompt, 2 late (3 repeats prompt); uniform results come from lane 1 / lane 0.
 struct T2DllConst {
     double fs, inv_fs, code_len, spacing;
     double inv_nb_lane;     // RN(1 / (nb_base + (lane & 7))): reciprocals of the plausible block lengths, one per lane
@@ -197,13 +200,23 @@ struct T2DllConst {
     long long rec_len;
 };
 
-__device__ __forceinline__ void t2_code_params(const T2DllConst& D, double codeFreq, double& remCode, long long& pos_cur,
-                                               const T2Code* prev, bool gave_up, int P, T2Code& N, int lane) {
+struct T2DllState {      // everything about the block being processed that the DLL wave needs again
+    double rem;          // remCodePhase at the block's start
+    long long pos;       // its first sample
+    double step;         // codePhaseStep = codeFreq / fs (T1)
+    double stp;          // the lane's ramp step (lane & 3: E, P, L, P)
+    int blk;
+};
+
+// Chain part of the next block's parameters (T1, T3): block size and ramp steps from the new code frequency; the
+// block starts at pos_n with code phase rem_n.  `prev_stp` = the lane's ramp step of the block the candidates were
+// prepared with (0 = none: block 0).  Writes N's chain part; returns the new state.
+__device__ __forceinline__ T2DllState t2_code_chain(const T2DllConst& D, double codeFreq, double rem_n, long long pos_n,
+                                                    double prev_stp, bool have_prev, bool gave_up, int P, T2Code& N, int lane) {
     const int l4 = lane & 3;
     const double off = (l4 == 0) ? -D.spacing : ((l4 == 2) ? D.spacing : 0.0);   // rem - spc == rem + (-spc) exactly
-    const double rem = remCode;
     const double step = div_rn(codeFreq, D.fs, D.inv_fs);                       // codeFreq / fs
-    const int blk = sgx_ceil_div(D.code_len - rem, step);
+    const int blk = sgx_ceil_div(D.code_len - rem_n, step);
     const double nb = (double)blk;
     const double span = nb * step;                                              // blksize * codePhaseStep
     const int ki = blk - D.nb_base;
@@ -212,37 +225,51 @@ __device__ __forceinline__ void t2_code_params(const T2DllConst& D, double codeF
     const double ynb = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(D.inv_nb_lane), kq),
                                         __builtin_amdgcn_readlane(__double2loint(D.inv_nb_lane), kq));
     // np.linspace(start, stop, blk, endpoint=False): delta = stop - start; step = delta / blk
-    const double start = rem + off;
-    const double d = ((span + rem) + off) - start;
+    const double start = rem_n + off;
+    const double d = ((span + rem_n) + off) - start;
     double stp;
     if (__builtin_expect(known, 1)) stp = div_rn(d, nb, ynb);
     else stp = d / nb;
-    const double t_last = ramp_at(blk - 1, stp, start);
-    const double rn_lane = (t_last + step) - 1023.0;                            // T4 (meaningful in the prompt lane)
-    const double rem_next = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rn_lane), 1),
-                                             __builtin_amdgcn_readlane(__double2loint(rn_lane), 1));
     bool ok_fast = true;
-    if (prev) {
-        const double reach = nb + 80.0;
-        const double lim = 0.45 * step;
-        ok_fast = __all(fabs(stp - prev->step[l4]) * reach < lim);
+    if (have_prev) ok_fast = __all(fabs(stp - prev_stp) * (nb + 80.0) < 0.45 * step);
+    if (lane < 3) N.step[lane] = stp;
+    if (lane == 0) {
+        const int stop = gave_up ? 2 : ((blk <= 0 || pos_n + blk > D.rec_len) ? 1 : ((blk + 15 > P * TRK_UNIT) ? 3 : 0));
+        *reinterpret_cast<int4*>(&N.blk) = make_int4(blk, stop, ok_fast ? 1 : 0, 0);
     }
+    T2DllState st;
+    st.rem = rem_n;
+    st.pos = pos_n;
+    st.step = step;
+    st.stp = stp;
+    st.blk = blk;
+    return st;
+}
+
+// Late part of block `st` (T4) and early part of the block after it: code phase and first sample of the next block, its
+// ramp starts, the reciprocal step for estimates; then `ready`.  Returns (rem_next, pos_next).
+__device__ __forceinline__ void t2_code_late(const T2DllConst& D, const T2DllState& st, int it, T2Code& C, T2Code& N, int lane,
+                                             double& rem_next, long long& pos_next) {
+    const int l4 = lane & 3;
+    const double off = (l4 == 0) ? -D.spacing : ((l4 == 2) ? D.spacing : 0.0);
+    const double start = st.rem + off;
+    const double t_last = ramp_at(st.blk - 1, st.stp, start);
+    const double rn_lane = (t_last + st.step) - 1023.0;                         // T4 (meaningful in the prompt lane)
+    rem_next = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rn_lane), 1),
+                                __builtin_amdgcn_readlane(__double2loint(rn_lane), 1));
+    pos_next = st.pos + st.blk;
     if (lane < 3) {
-        N.start[lane] = start;
-        N.step[lane] = stp;
-        N.start_n[lane] = rem_next + off;
+        C.start_n[lane] = rem_next + off;
+        N.start[lane] = rem_next + off;
     }
     if (lane == 0) {
-        N.pos = pos_cur;
-        N.pos_next = pos_cur + blk;
-        N.blk = blk;
-        N.stop = gave_up ? 2 : ((blk <= 0 || pos_cur + blk > D.rec_len) ? 1 : ((blk + 15 > P * TRK_UNIT) ? 3 : 0));
-        N.fast_ok = ok_fast ? 1 : 0;
-        const double r0 = __builtin_amdgcn_rcp(step);
-        N.inv_step = __builtin_fma(r0, __builtin_fma(-step, r0, 1.0), r0);
+        const double r0 = __builtin_amdgcn_rcp(st.step);
+        C.inv_step = __builtin_fma(r0, __builtin_fma(-st.step, r0, 1.0), r0);
+        C.pos_next = pos_next;
+        N.pos = pos_next;
     }
-    remCode = rem_next;
-    pos_cur = pos_cur + blk;
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the stores above are in LDS before the flag
+    if (lane == 0) *(volatile int*)&C.ready = it + 1;
 }
 
 #define T2_PIN(x) asm volatile("" : "+v"(x))
@@ -256,6 +283,7 @@ struct T2Shared {
     unsigned ticket[2][2];          // arrival ticket of the map waves, by block parity
     double rec[2][16];              // a block's 13 series values (member 0), stored one block later
     int flag[4];                    // [0] same-XCD placement, [1] abort seen by this workgroup
+    int rflag[4];                   // [0] PLL wave, [1] DLL wave: number of blocks whose record values are in rec[]
     long long tpub[2];              // (profiling) time stamp of the member's publish, by block parity
 };
 
@@ -320,33 +348,43 @@ __device__ __forceinline__ int t2_map_role(T2Shared& S, const int8_t* __restrict
         // block 0: prepared with its own (true) parameters
         raw = load_group(rec, (pos0 & ~15ll) + lane_off, limit);
         const T2Code& C0 = S.code[0];
-        T2_PREPARE(C0.pos, C0.start, C0.step[0], C0.step[1], C0.step[2], C0.inv_step);
+        const double s0 = C0.step[1];
+        const double r0 = __builtin_amdgcn_rcp(s0);
+        const double inv0 = __builtin_fma(r0, __builtin_fma(-s0, r0, 1.0), r0);
+        T2_PREPARE(C0.pos, C0.start, C0.step[0], C0.step[1], C0.step[2], inv0);
     }
     int it = 0;
     for (; it < ms; ++it) {
         const int par = it & 1;
         const T2Code& C = S.code[par];
-        if (C.stop) break;
+        // one batch of LDS reads: chain part, early part, the lane's carrier phasors
+        const int4 hd = *reinterpret_cast<const int4*>(&C.blk);      // blk, stop, fast_ok
+        const double stepE = C.step[0], stepP = C.step[1], stepL = C.step[2];
+        const double startE = C.start[0], startP = C.start[1], startL = C.start[2];
+        const long long pos = C.pos;
+        const T2Carr& CR = S.carr[par];
+        const double2 w1 = CR.T[T2_W1 + (tid & 15)], w2 = CR.T[T2_W2 + ((tid >> 4) & 15)], w3 = CR.T[T2_W3];
+        if (hd.y) break;
         T2_FP_TOP
         __builtin_amdgcn_s_setprio(2);
-        const int blk = C.blk;
-        const double startE = C.start[0], startP = C.start[1], startL = C.start[2];
-        const double stepE = C.step[0], stepP = C.step[1], stepL = C.step[2];
-        const uint4 nraw = load_group(rec, (C.pos_next & ~15ll) + lane_off, limit);   // next block's bytes
-        const T2Carr& CR = S.carr[par];
+        const int blk = hd.x;
+        const long long pos_next = pos + blk;
+        const uint4 nraw = load_group(rec, (pos_next & ~15ll) + lane_off, limit);   // next block's bytes
         T2PROBE(prof_on, 0);   // parameters read, next block's load issued
         double cE1, cE2, cP1, cP2, cL1, cL2;
         int swE, swP, swL;
-        if (__builtin_expect(C.fast_ok, 1)) {
+        if (__builtin_expect(hd.z, 1)) {
             ramp_resolve(RE, startE, stepE, ilod, ilo, cE1, cE2, swE);
             ramp_resolve(RP, startP, stepP, ilod, ilo, cP1, cP2, swP);
             ramp_resolve(RL, startL, stepL, ilod, ilo, cL1, cL2, swL);
         } else {
             // the rate moved too far for the prepared candidates: exact search (round-1 path)
+            const double r0 = __builtin_amdgcn_rcp(stepP);
+            const double inv_step = __builtin_fma(r0, __builtin_fma(-stepP, r0, 1.0), r0);
             int kE, kP, kL;
-            ramp_setup(startE, stepE, C.inv_step, ilo, kE, swE);
-            ramp_setup(startP, stepP, C.inv_step, ilo, kP, swP);
-            ramp_setup(startL, stepL, C.inv_step, ilo, kL, swL);
+            ramp_setup(startE, stepE, inv_step, ilo, kE, swE);
+            ramp_setup(startP, stepP, inv_step, ilo, kP, swP);
+            ramp_setup(startL, stepL, inv_step, ilo, kL, swL);
             kE = kE < 0 ? 0 : (kE > 1024 ? 1024 : kE);
             kP = kP < 0 ? 0 : (kP > 1024 ? 1024 : kP);
             kL = kL < 0 ? 0 : (kL > 1024 ? 1024 : kL);
@@ -357,21 +395,24 @@ __device__ __forceinline__ int t2_map_role(T2Shared& S, const int8_t* __restrict
             cL1 = __hiloint2double((int)chip_hi(S.chip, kL), 0);
             cL2 = __hiloint2double((int)chip_hi(S.chip, kL + 1), 0);
         }
-        if (__builtin_expect(i0 + 16 > blk, 0)) {
-            // the block ends inside (or before) this group: samples from blk on belong to the next block
+        // group-start phasor G = W1[tid & 15] * W2[(tid >> 4) & 15] * W3; a group that lies entirely beyond the block
+        // (its samples belong to the next one) gets a zero phasor, i.e. adds nothing
+        double gc, gs;
+        {
+            const double lc = __builtin_fma(w1.x, w2.x, -(w1.y * w2.y));
+            const double ls = __builtin_fma(w1.x, w2.y, w1.y * w2.x);
+            gc = __builtin_fma(lc, w3.x, -(ls * w3.y));
+            gs = __builtin_fma(lc, w3.y, ls * w3.x);
+            const bool beyond = i0 >= blk;
+            gc = beyond ? 0.0 : gc;
+            gs = beyond ? 0.0 : gs;
+        }
+        if (__builtin_expect(i0 < blk && i0 + 16 > blk, 0)) {
+            // the block ends inside this group (one lane per block): samples from blk on belong to the next block
 #pragma unroll
             for (int b = 0; b < 16; ++b) xd[b] = (i0 + b < blk) ? xd[b] : 0.0;
         }
         T2PROBE(prof_on, 1);   // switch samples and chips resolved
-        // group-start phasor G = W1[tid & 15] * W2[(tid >> 4) & 15] * W3
-        double gc, gs;
-        {
-            const double2 a = CR.T[T2_W1 + (tid & 15)], c2 = CR.T[T2_W2 + ((tid >> 4) & 15)], w3 = CR.T[T2_W3];
-            const double lc = __builtin_fma(a.x, c2.x, -(a.y * c2.y));
-            const double ls = __builtin_fma(a.x, c2.y, a.y * c2.x);
-            gc = __builtin_fma(lc, w3.x, -(ls * w3.y));
-            gs = __builtin_fma(lc, w3.y, ls * w3.x);
-        }
         double aIE, aQE, aIP, aQP, aIL, aQL;
         const int iend = i0 + 16;
         int swmin = swE < swP ? swE : swP;
@@ -399,14 +440,19 @@ __device__ __forceinline__ int t2_map_role(T2Shared& S, const int8_t* __restrict
                 aQL = __builtin_fma(cL, xc, aQL);
             }
         } else {
-            const int bsw = swmin - i0;           // samples b >= bsw come after the switch
+            // samples b >= bsw come after the switch.  The samples are small integers, so their fp64 low dword is zero
+            // and masking the HIGH dword alone zeroes one: xt_hi = xd_hi & ((b - bsw) >> 31 ? 0 : ~0) - plain integer
+            // VALU, no compare/select round trip through VCC per sample
+            int bsw = swmin - i0;
+            bsw = bsw > 16 ? 16 : bsw;
             double Ac = 0.0, As = 0.0, Tc = 0.0, Ts = 0.0;
 #pragma unroll
             for (int b = 0; b < 16; ++b) {
                 const double2 Bb = CR.T[T2_B + b];
                 Ac = __builtin_fma(xd[b], Bb.x, Ac);
                 As = __builtin_fma(xd[b], Bb.y, As);
-                const double xt = (b >= bsw) ? xd[b] : 0.0;
+                const int keep = ~((b - bsw) >> 31);                  // all ones iff b >= bsw
+                const double xt = __hiloint2double(__double2hiint(xd[b]) & keep, 0);
                 Tc = __builtin_fma(xt, Bb.x, Tc);
                 Ts = __builtin_fma(xt, Bb.y, Ts);
             }
@@ -427,7 +473,7 @@ __device__ __forceinline__ int t2_map_role(T2Shared& S, const int8_t* __restrict
             aQL = __builtin_fma(dL, tlQ, cL1 * allQ);
         }
         T2PROBE(prof_on, 3);   // group finalisation
-        // ---- transposing reduction inside each row of 16 lanes; exchange-line order I_P Q_P I_E Q_E I_L Q_L ----
+        // ---- transposing reduction inside each row of 16 lanes; exchange order I_P Q_P I_E Q_E I_L Q_L ----
         const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
         // xor 1: pairs (I_P, Q_P), (I_E, Q_E), (I_L, Q_L) -> a lane keeps the member selected by its bit 0
         double p = (b0 ? aQP : aIP) + dpp_mov<0xB1>(b0 ? aIP : aQP);
@@ -456,7 +502,7 @@ __device__ __forceinline__ int t2_map_role(T2Shared& S, const int8_t* __restrict
         if ((ticket & 3u) == 3u) {
             // last of the four map waves: all 16 row sums of every word are in LDS.  Lane j adds slots 2p, 2p+1 of word
             // j >> 3 (p = j & 7), three DPP steps add the eight lanes of a word, lane 8 w converts the member's sum to
-            // 2^-32 fixed point and adds it (with the arrival tag) to the channel's exchange line.
+            // fixed point and publishes it as one granule.
             const int word = lane >> 3, pp = lane & 7;
             double v = 0.0;
             if (word < 6) v = S.part[par][2 * pp][word] + S.part[par][2 * pp + 1][word];
@@ -464,7 +510,7 @@ __device__ __forceinline__ int t2_map_role(T2Shared& S, const int8_t* __restrict
             v = v + dpp_mov<0x4E>(v);
             v = v + dpp_mov<0x141>(v);   // row_half_mirror: the other quad of the eight
             if (pp == 0 && word < 6) {
-                // one granule per sum: {16-bit epoch tag | 48-bit two's-complement fixed point}, ONE aligned 8-byte store
+                // {16-bit epoch tag | 48-bit two's-complement fixed point}, ONE aligned 8-byte store
                 const double t = __builtin_fma(v, T2_FIX, T2_MAGIC);
                 const unsigned long long q = (unsigned long long)(__double_as_longlong(t) - __double_as_longlong(T2_MAGIC));
                 const unsigned long long gran = ((unsigned long long)((unsigned)(it + 1) & 0xFFFFu) << 48) | (q & 0xFFFFFFFFFFFFull);
@@ -476,7 +522,8 @@ __device__ __forceinline__ int t2_map_role(T2Shared& S, const int8_t* __restrict
         // ---- shadow: prepare the next block with this block's rates ----
         __builtin_amdgcn_s_setprio(0);
         raw = nraw;
-        T2_PREPARE(C.pos_next, C.start_n, stepE, stepP, stepL, C.inv_step);
+        while (*(volatile int*)&C.ready != it + 1) __builtin_amdgcn_s_sleep(1);   // (the late part was posted long ago)
+        T2_PREPARE(pos_next, C.start_n, stepE, stepP, stepL, C.inv_step);
         T2STAMP(prof_on, 6);   // next block prepared
         wg_barrier();
         T2STAMP(prof_on, 7);   // waiting for the loop filter
@@ -496,12 +543,15 @@ __device__ __forceinline__ int t2_pll_role(T2Shared& S, const TrkConst& K, const
     const double two_pi = 2 * M_PI;
     // constants of the call in registers (kernel arguments would be re-fetched through the scalar cache on the chain)
     double k_a = K.k_carr_a, k_b = K.k_carr_b, inv_pi = K.inv_pi, inv_2pi = K.inv_2pi, c_hi = K.inv_2pifs_hi,
-           c_lo = K.inv_2pifs_lo, inv_fs = K.inv_fs;
+           c_lo = K.inv_2pifs_lo, inv_fs = K.inv_fs, fs = K.fs;
     T2_PIN(k_a); T2_PIN(k_b); T2_PIN(inv_pi); T2_PIN(inv_2pi); T2_PIN(c_hi); T2_PIN(c_lo); T2_PIN(inv_fs); T2_PIN(carrBasis);
+    T2_PIN(fs);
     const int ms = K.ms;
     // lane = 16 word + member polls that member's granule of I_P (word 0, row 0) / Q_P (word 1, row 1)
     const bool mine = (lane < 32) && ((lane & 15) < P);
     unsigned long long* const xabort = xbase + T2_XABORT;
+    // record values of the block just finished (member 0), posted after the barrier: carrFreq I_P Q_P pllDiscr pllDiscrFilt
+    double r_cf = 0.0, r_ip = 0.0, r_qp = 0.0, r_err = 0.0, r_nco = 0.0;
     T2_FP_DECL
     (void)prof_on;
     __builtin_amdgcn_s_setprio(3);
@@ -509,21 +559,36 @@ __device__ __forceinline__ int t2_pll_role(T2Shared& S, const TrkConst& K, const
     for (; it < ms; ++it) {
         const int par = it & 1;
         const T2Code& C = S.code[par];
-        if (C.stop) break;
+        const int4 hd = *reinterpret_cast<const int4*>(&C.blk);
+        const long long pos = C.pos;
+        if (member == 0 && it > 0) {
+            if (lane == 0) {
+                double* R = S.rec[par ^ 1];      // T9 record (tracking.py:255-275) of block it - 1, stored by the record wave
+                R[2] = r_cf;
+                R[3] = r_ip;
+                R[7] = r_qp;
+                R[11] = r_err;
+                R[12] = r_nco;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            if (lane == 0) *(volatile int*)&S.rflag[0] = it;
+        }
+        if (hd.y) break;
         T2_FP_TOP
         if (prof) t_top = (long long)__builtin_amdgcn_s_memtime();
         // before the sums arrive: carrier phase at the end of this block (T5), exact remainder by FMA
-        const int blk = C.blk;
-        const int head_next = (int)(C.pos_next & 15);
+        const int blk = hd.x;
+        const int head_next = (int)((pos + blk) & 15);
         double rc;
         {
-            const double arg_end = w_cur * div_rn((double)blk, K.fs, inv_fs) + remCarr;   // blk / fs, correctly rounded
+            const double arg_end = w_cur * div_rn((double)blk, fs, inv_fs) + remCarr;   // blk / fs, correctly rounded
             const double kq = floor(arg_end * inv_2pi);
             rc = __builtin_fma(-kq, two_pi, arg_end);
             if (rc < 0.0) rc += two_pi;
             if (rc >= two_pi) rc -= two_pi;
         }
         T2_PIN(rc);   // (keeps the block-end phase computation ahead of the wait)
+        __builtin_amdgcn_s_setprio(3);
         const unsigned long long* gp = xbase + T2_XG + par * 96 + (lane & 31);
         const unsigned long long tag = (unsigned long long)((unsigned)(it + 1) & 0xFFFFu);
         unsigned long long x = 0;
@@ -569,14 +634,11 @@ __device__ __forceinline__ int t2_pll_role(T2Shared& S, const TrkConst& K, const
         if (it + 1 < ms) t2_carr_tables(c_hi, c_lo, inv_2pi, w_new, rc, head_next, member, S.carr[par ^ 1], lane);
         w_cur = w_new;
         remCarr = rc;
-        if (member == 0 && lane == 0) {
-            double* R = S.rec[par];      // T9 record (tracking.py:255-275), stored by the record wave
-            R[2] = carrFreq;
-            R[3] = I_P;
-            R[7] = Q_P;
-            R[11] = carrError;
-            R[12] = carrNco;
-        }
+        r_cf = carrFreq;
+        r_ip = I_P;
+        r_qp = Q_P;
+        r_err = carrError;
+        r_nco = carrNco;
         if (gave_up && lane == 0) {
             S.flag[1] = 1;
             atomicExch(err, 1 + ch);
@@ -584,8 +646,22 @@ __device__ __forceinline__ int t2_pll_role(T2Shared& S, const TrkConst& K, const
         }
         T2STAMP(prof_on, 10);  // carrier tables
         wg_barrier();
+        __builtin_amdgcn_s_setprio(0);   // what follows until the next wait is off the chain: let the map waves issue first
         if (prof) acc_flt += (long long)__builtin_amdgcn_s_memtime() - t_arr;   // sums visible -> barrier released (both filter waves done)
         T2STAMP(prof_on, 11);
+    }
+    if (member == 0 && it > 0 && it == ms) {
+        // (when the loop ran out of blocks, the last block's record values are still in registers)
+        if (lane == 0) {
+            double* R = S.rec[(it - 1) & 1];
+            R[2] = r_cf;
+            R[3] = r_ip;
+            R[7] = r_qp;
+            R[11] = r_err;
+            R[12] = r_nco;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        if (lane == 0) *(volatile int*)&S.rflag[0] = it;
     }
     if (prof && lane == 0) {
         prof[ch * 64 + member] = acc_map;
@@ -597,10 +673,10 @@ __device__ __forceinline__ int t2_pll_role(T2Shared& S, const TrkConst& K, const
 }
 
 // ================================ DLL (wave 5) ================================
-__device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const T2DllConst& D, int member, int lane, int P,
-                                           int ch, double remCode, long long pos_cur,
-                                           unsigned long long* __restrict__ xbase, int* __restrict__ err, bool prof_on) {
-    // tracking.py:114-121; remCode / pos_cur already describe block 1 (block 0's parameters are posted)
+__device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const T2DllConst& D, T2DllState st, int member,
+                                           int lane, int P, int ch, unsigned long long* __restrict__ xbase,
+                                           int* __restrict__ err, bool prof_on) {
+    // tracking.py:114-121; `st` describes block 0 (its chain and early parts are posted)
     double oldCodeNco = 0.0, oldCodeErr = 0.0;
     double k_a = K.k_code_a, k_b = K.k_code_b, basis = K.code_basis;
     T2_PIN(k_a); T2_PIN(k_b); T2_PIN(basis);
@@ -610,15 +686,36 @@ __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const
     const int l4 = lane & 3;
     const bool mine = (lane & 15) < P;
     unsigned long long* const xabort = xbase + T2_XABORT;
+    // record values of the block just finished (member 0), posted after the barrier
+    double r_v = 0.0, r_cf = 0.0, r_err = 0.0, r_nco = 0.0;
     T2_FP_DECL
     (void)prof_on;
     __builtin_amdgcn_s_setprio(3);
     int it = 0;
     for (; it < ms; ++it) {
         const int par = it & 1;
-        const T2Code& C = S.code[par];
-        if (C.stop) break;
+        T2Code& C = S.code[par];
+        const int stop = C.stop;
+        if (member == 0 && it > 0) {
+            double* R = S.rec[par ^ 1];
+            // I_E -> 4, Q_E -> 6, I_L -> 5, Q_L -> 8 (series order of _native.SERIES)
+            if (lane < 4) R[lane == 0 ? 4 : (lane == 1 ? 6 : (lane == 2 ? 5 : 8))] = r_v;
+            if (lane == 0) {
+                R[0] = (double)(st.pos + file_off);   // position after block it - 1 = first sample of block it
+                R[1] = r_cf;
+                R[9] = r_err;
+                R[10] = r_nco;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            if (lane == 0) *(volatile int*)&S.rflag[1] = it;
+        }
+        if (stop) break;
         T2_FP_TOP
+        // late part of this block and early part of the next (nothing here needs the sums)
+        double rem_next;
+        long long pos_next;
+        t2_code_late(D, st, it, C, S.code[par ^ 1], lane, rem_next, pos_next);
+        __builtin_amdgcn_s_setprio(3);
         const unsigned long long* gp = xbase + T2_XG + par * 96 + 32 + lane;
         const unsigned long long tag = (unsigned long long)((unsigned)(it + 1) & 0xFFFFu);
         unsigned long long x = 0, xa = 0;
@@ -663,20 +760,14 @@ __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const
         oldCodeNco = codeNco;
         oldCodeErr = codeError;
         T2PROBE(prof_on, 13);  // discriminator + NCO
-        if (member == 0) {
-            double* R = S.rec[par];
-            // I_E -> 4, Q_E -> 6, I_L -> 5, Q_L -> 8 (series order of _native.SERIES)
-            if (lane < 4) R[lane == 0 ? 4 : (lane == 1 ? 6 : (lane == 2 ? 5 : 8))] = v;
-            if (lane == 0) {
-                R[0] = (double)(pos_cur + file_off);   // position after this block
-                R[1] = cf_new;
-                R[9] = codeError;
-                R[10] = codeNco;
-            }
-        }
-        // T1, T3, T4: block size and ramps of the next block; starts of the one after
-        t2_code_params(D, cf_new, remCode, pos_cur, &C, gave_up, P, S.code[par ^ 1], lane);
-        if (lane == 0 && S.code[par ^ 1].stop == 3) atomicExch(err, TRK_ERR_RANGE | (1 + ch));
+        // T1, T3: block size and ramp steps of the next block
+        const T2DllState nx = t2_code_chain(D, cf_new, rem_next, pos_next, st.stp, true, gave_up, P, S.code[par ^ 1], lane);
+        if (lane == 0 && nx.blk + 15 > P * TRK_UNIT && !gave_up) atomicExch(err, TRK_ERR_RANGE | (1 + ch));
+        st = nx;
+        r_v = v;
+        r_cf = cf_new;
+        r_err = codeError;
+        r_nco = codeNco;
         if (gave_up && lane == 0) {
             S.flag[1] = 1;
             if (xa == 0) {
@@ -686,20 +777,40 @@ __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const
         }
         T2STAMP(prof_on, 14);  // next block's code parameters
         wg_barrier();
+        __builtin_amdgcn_s_setprio(0);
         T2STAMP(prof_on, 15);
+    }
+    if (member == 0 && it > 0 && it == ms) {
+        double* R = S.rec[(it - 1) & 1];
+        if (lane < 4) R[lane == 0 ? 4 : (lane == 1 ? 6 : (lane == 2 ? 5 : 8))] = r_v;
+        if (lane == 0) {
+            R[0] = (double)(st.pos + file_off);
+            R[1] = r_cf;
+            R[9] = r_err;
+            R[10] = r_nco;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        if (lane == 0) *(volatile int*)&S.rflag[1] = it;
     }
     T2_FP_PRINT(prof_on && lane == 0, 12, 16)
     return it;
 }
 
 // ================================ RECORD (wave 6) ================================
+// Stores block k's 13 series values once both filter waves have posted them (rflag >= k + 1): one block behind.
+__device__ __forceinline__ void t2_rec_store(T2Shared& S, int k, long long m, int lane, double* __restrict__ o) {
+    int budget = 1 << 16;
+    while ((*(volatile int*)&S.rflag[0] < k + 1 || *(volatile int*)&S.rflag[1] < k + 1) && --budget) __builtin_amdgcn_s_sleep(2);
+    if (lane < SGX_NUM_SERIES) o[lane * m + k] = S.rec[k & 1][lane];
+}
+
 __device__ __forceinline__ int t2_rec_role(T2Shared& S, int ms, int member, int lane, double* __restrict__ o) {
     const long long m = ms;
     int it = 0;
     for (; it < ms; ++it) {
         const int par = it & 1;
         if (S.code[par].stop) break;
-        if (member == 0 && it > 0 && lane < SGX_NUM_SERIES) o[lane * m + (it - 1)] = S.rec[par ^ 1][lane];
+        if (member == 0 && it > 0) t2_rec_store(S, it - 1, m, lane, o);
         wg_barrier();
     }
     return it;
@@ -730,8 +841,10 @@ __global__ __launch_bounds__(T2_THREADS) void trk2_kernel(const int8_t* __restri
     // ---- placement: are all members of the channel on one XCD (one L2)?  Then the exchange may stay in that L2.
     if (tid < 4) {
         S.flag[tid] = 0;
+        S.rflag[tid] = 0;
         S.ticket[tid >> 1][tid & 1] = 0;
     }
+    if (tid < 2) S.code[tid].ready = 0;
     __syncthreads();
     if (wave == 4) {
         unsigned long long* pl = xbase + T2_XPLACE;
@@ -769,10 +882,14 @@ __global__ __launch_bounds__(T2_THREADS) void trk2_kernel(const int8_t* __restri
     const bool fast = S.flag[0] != 0;
     const bool dead = S.flag[1] != 0;
 
-    // block 0 parameters (tracking.py:114-130)
-    double remCode = 0.0;
-    long long pos_cur = cc.pos0;
+    // block 0 parameters (tracking.py:114-130): chain part and early part
     T2DllConst D;
+    T2DllState st0;
+    st0.rem = 0.0;
+    st0.pos = cc.pos0;
+    st0.step = 0.0;
+    st0.stp = 0.0;
+    st0.blk = 0;
     if (wave == 5) {
         D.fs = K.fs;
         D.inv_fs = K.inv_fs;
@@ -781,9 +898,14 @@ __global__ __launch_bounds__(T2_THREADS) void trk2_kernel(const int8_t* __restri
         D.inv_nb_lane = 1.0 / (double)(K.nb_base + (lane & 7));
         D.nb_base = K.nb_base;
         D.rec_len = K.rec_len;
-        t2_code_params(D, K.code_basis, remCode, pos_cur, nullptr, false, P, S.code[0], lane);
+        st0 = t2_code_chain(D, K.code_basis, 0.0, cc.pos0, 0.0, false, false, P, S.code[0], lane);
+        const double off = ((lane & 3) == 0) ? -K.spacing : (((lane & 3) == 2) ? K.spacing : 0.0);
+        if (lane < 3) S.code[0].start[lane] = 0.0 + off;
+        if (lane == 0) {
+            S.code[0].pos = cc.pos0;
+            if (st0.blk + 15 > P * TRK_UNIT) atomicExch(err, TRK_ERR_RANGE | (1 + ch));
+        }
         __builtin_amdgcn_s_waitcnt(0xc07f);
-        if (lane == 0 && S.code[0].stop == 3) atomicExch(err, TRK_ERR_RANGE | (1 + ch));
         if (lane == 0 && dead) S.code[0].stop = 2;
     }
     if (wave == 4)
@@ -795,12 +917,13 @@ __global__ __launch_bounds__(T2_THREADS) void trk2_kernel(const int8_t* __restri
     int done;
     if (wave < 4) done = t2_map_role(S, rec, K.rec_alloc, K.ms, cc.pos0, member, tid, xbase, fast, prof_on, prof != nullptr);
     else if (wave == 4) done = t2_pll_role(S, K, cc, member, lane, P, ch, xbase, err, prof_on, prof);
-    else if (wave == 5) done = t2_dll_role(S, K, D, member, lane, P, ch, remCode, pos_cur, xbase, err, prof_on);
+    else if (wave == 5) done = t2_dll_role(S, K, D, st0, member, lane, P, ch, xbase, err, prof_on);
     else done = t2_rec_role(S, K.ms, member, lane, o);
 
     // a channel that was given up reports the blocks completed before the abort
-    if (S.code[done & 1].stop == 2 && done > 0) done -= 1;
-    if (wave == 6 && member == 0 && done > 0 && lane < SGX_NUM_SERIES) o[lane * (long long)K.ms + (done - 1)] = S.rec[(done - 1) & 1][lane];
+    const bool aborted = S.code[done & 1].stop == 2;
+    if (wave == 6 && member == 0 && done > 0 && !aborted) t2_rec_store(S, done - 1, (long long)K.ms, lane, o);
+    if (aborted && done > 0) done -= 1;
     if (tid == 0 && member == 0) ms_done[ch] = done;
 }
 
