@@ -456,3 +456,335 @@ int sgx_fft_forward_fused(const FftPlan* p, cplx* a, cplx* b, int64_t rows, hipS
     *result = src;
     return SGX_OK;
 }
+
+// =====================================================================================================================
+// Four-step transform with LDS-resident sub-transforms (the acquisition's hot transforms).
+//
+// n = N1 * N2, input index N2 n1 + n2, output index k1 + N1 k2:
+//   X[k1 + N1 k2] = sum_n2 W_N2^(n2 k2) [ W_n^(n2 k1) sum_n1 x[N2 n1 + n2] W_N1^(n1 k1) ]
+//   columns kernel   a workgroup takes C adjacent columns n2 (C * 16 bytes contiguous per n1), runs their N1-point
+//                    transforms in LDS (Stockham radix passes, outputs staged in registers across a barrier), multiplies
+//                    by W_n^(n2 k1) and stores element (k1, n2) where it came from;
+//   rows kernel      a workgroup takes CB adjacent rows k1 (CB * N2 contiguous elements), runs their N2-point transforms
+//                    in LDS and either stores X[k1 + N1 k2] or - last step of the correlation - squares, scales and
+//                    max-reduces the outputs without storing anything (optionally summing the powers of several 1-ms
+//                    blocks first: the non-coherent extension).
+// A row therefore crosses HBM twice (write after the columns, read before the rows) instead of once per radix pass.
+// The first kernel can form the correlation product conj(X_b[(i + shift) mod n]) * F_prn[i] on load; the circular
+// shift is how one forward spectrum serves every Doppler bin that differs from it by whole output bins.
+
+struct F4Args {
+    const cplx* in;
+    cplx* out;
+    const cplx* tw_hi;
+    const cplx* tw_lo;
+    const cplx* wr[3];      // root tables of the (up to three) radices of this kernel's sub-transform
+    long long n;
+    long long nonzero_len;  // input elements >= this index are zero
+    int lo_bits;
+    // product on load (columns kernel, MODE 1)
+    const cplx* mul_x;      // forward spectra [block * n_phi + phi][n]
+    const cplx* mul_f;      // code spectra [prn][n]
+    const int2* bin_map;    // per Doppler bin: (phi index, circular shift)
+    const int2* row_map;    // optional: (block * n_bins + bin, prn) per row
+    int n_bins, n_phi, rows_per_prn, prn_base;
+    // rows kernel, MODE 2 / 3
+    double* pmax;           // [rows][gridDim.x] per-workgroup maxima (MODE 2)
+    int* parg;
+    double* pout;           // [rows][n] powers (MODE 3)
+    double inv_n;
+    int sum_blocks;         // > 1: powers of this many consecutive input rows are added first (input row = row * sum_blocks + b)
+};
+
+__device__ __forceinline__ cplx f4_twiddle(const F4Args& a, long long t) {
+    const cplx h = a.tw_hi[t >> a.lo_bits];
+    const cplx l = a.tw_lo[t & ((1ll << a.lo_bits) - 1)];
+    return cmul(h, l);
+}
+
+// One Stockham radix-R pass over C sequences of length L in LDS; element n of sequence c lives at buf[n * SN + c * SC].
+// CFAST: consecutive threads take consecutive sequences (use when SC == 1), else consecutive butterflies.
+template <int L, int R, int C, int SN, int SC, int TPB, bool CFAST>
+__device__ __forceinline__ void lds_radix_pass(cplx* __restrict__ buf, int ns, const F4Args& a, const cplx* __restrict__ wr,
+                                               int tid) {
+    constexpr int M = L / R;
+    constexpr int TOTAL = M * C;
+    constexpr int ROUNDS = (TOTAL + TPB - 1) / TPB;
+    cplx v[ROUNDS][R];
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+        const int w = tid + rd * TPB;
+        if (w < TOTAL) {
+            const int c = CFAST ? w % C : w / M, j = CFAST ? w / C : w % M;
+#pragma unroll
+            for (int q = 0; q < R; ++q) v[rd][q] = buf[(j + q * M) * SN + c * SC];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+        const int w = tid + rd * TPB;
+        if (w < TOTAL) {
+            const int c = CFAST ? w % C : w / M, j = CFAST ? w / C : w % M;
+            const int k = j % ns;
+            if (ns > 1) {
+                // W_L^(q k L / (ns R)) = W_n^(q k (L / (ns R)) (n / L))
+                const long long tstep = (long long)k * (L / (ns * R)) * (a.n / L);
+                long long t = 0;
+#pragma unroll
+                for (int q = 1; q < R; ++q) {
+                    t += tstep;
+                    if (t >= a.n) t -= a.n;
+                    v[rd][q] = cmul(v[rd][q], f4_twiddle(a, t));
+                }
+            }
+            dft_small<R>(v[rd], wr);
+            const int j0 = (j / ns) * ns * R + k;
+#pragma unroll
+            for (int q = 0; q < R; ++q) buf[(j0 + q * ns) * SN + c * SC] = v[rd][q];
+        }
+    }
+    __syncthreads();
+}
+
+template <int L, int C, int SN, int SC, int TPB, bool CFAST, int R1, int R2, int R3>
+__device__ __forceinline__ void lds_fft(cplx* __restrict__ buf, const F4Args& a, int tid) {
+    lds_radix_pass<L, R1, C, SN, SC, TPB, CFAST>(buf, 1, a, a.wr[0], tid);
+    if constexpr (R2 > 1) lds_radix_pass<L, R2, C, SN, SC, TPB, CFAST>(buf, R1, a, a.wr[1], tid);
+    if constexpr (R3 > 1) lds_radix_pass<L, R3, C, SN, SC, TPB, CFAST>(buf, R1 * R2, a, a.wr[2], tid);
+}
+
+// MODE 0: plain.  MODE 1: input = conj(X[(i + shift) mod n]) * F[i] (correlation product, acquisition.py:120-123).
+template <int N1, int N2, int C, int TPB, int R1, int R2, int R3, int MODE>
+__global__ __launch_bounds__(TPB) void fft4_cols_kernel(F4Args a) {
+    extern __shared__ __attribute__((aligned(16))) char f4_smem[];
+    cplx* __restrict__ buf = reinterpret_cast<cplx*>(f4_smem);   // [N1][C]
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * C;
+    const long long row = blockIdx.y;
+    const cplx* __restrict__ in = a.in + row * a.n;
+    const cplx* __restrict__ px = nullptr;
+    const cplx* __restrict__ pf = nullptr;
+    int shift = 0;
+    if (MODE == 1) {
+        int bk, prn;
+        if (a.row_map) {
+            const int2 rm = a.row_map[row];
+            bk = rm.x;
+            prn = rm.y;
+        } else {
+            bk = (int)(row % a.rows_per_prn);
+            prn = a.prn_base + (int)(row / a.rows_per_prn);
+        }
+        const int b = bk / a.n_bins, kb = bk % a.n_bins;
+        const int2 bm = a.bin_map[kb];
+        px = a.mul_x + (long long)(b * a.n_phi + bm.x) * a.n;
+        pf = a.mul_f + (long long)prn * a.n;
+        shift = bm.y;
+    }
+    for (int e = tid; e < N1 * C; e += TPB) {
+        const int n1 = e / C, c = e % C;
+        const long long idx = (long long)n1 * N2 + c0 + c;
+        cplx val;
+        if (MODE == 1) {
+            long long ix = idx + shift;
+            if (ix >= a.n) ix -= a.n;
+            const cplx xv = px[ix], fv = pf[idx];
+            val = make_double2(__builtin_fma(xv.x, fv.x, xv.y * fv.y), __builtin_fma(xv.x, fv.y, -(xv.y * fv.x)));
+        } else {
+            val = (idx < a.nonzero_len) ? in[idx] : make_double2(0.0, 0.0);
+        }
+        buf[e] = val;
+    }
+    __syncthreads();
+    lds_fft<N1, C, C, 1, TPB, true, R1, R2, R3>(buf, a, tid);
+    cplx* __restrict__ out = a.out + row * a.n;
+    for (int e = tid; e < N1 * C; e += TPB) {
+        const int k1 = e / C, c = e % C;
+        const long long t = (long long)(c0 + c) * k1;   // < n
+        out[(long long)k1 * N2 + c0 + c] = cmul(buf[e], f4_twiddle(a, t));
+    }
+}
+
+// MODE 0: store X.  MODE 2: |X|^2 inv_n^2 (summed over sum_blocks input rows), per-workgroup (max, first index).
+// MODE 3: the same powers stored to pout (the rows the second-peak search reads).
+template <int N1, int N2, int CB, int TPB, int R1, int R2, int R3, int MODE>
+__global__ __launch_bounds__(TPB) void fft4_rows_kernel(F4Args a) {
+    extern __shared__ __attribute__((aligned(16))) char f4_smem[];
+    cplx* __restrict__ buf = reinterpret_cast<cplx*>(f4_smem);   // [CB][N2]
+    const int tid = threadIdx.x;
+    const int k10 = blockIdx.x * CB;
+    const long long row = blockIdx.y;
+    constexpr int E = CB * N2;
+    constexpr int PER = (E + TPB - 1) / TPB;
+    double acc[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) acc[i] = 0.0;
+    const int nb = (MODE == 0 || a.sum_blocks < 1) ? 1 : a.sum_blocks;
+    for (int b = 0; b < nb; ++b) {
+        const cplx* __restrict__ in = a.in + (row * nb + b) * a.n + (long long)k10 * N2;
+        if (b > 0) __syncthreads();
+        for (int e = tid; e < E; e += TPB) buf[e] = in[e];
+        __syncthreads();
+        lds_fft<N2, CB, 1, N2, TPB, false, R1, R2, R3>(buf, a, tid);
+        if (MODE == 0) {
+            cplx* __restrict__ out = a.out + row * a.n;
+            for (int e = tid; e < E; e += TPB) {
+                const int cb = e / N2, k2 = e % N2;
+                out[(long long)(k10 + cb) + (long long)N1 * k2] = buf[e];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int e = tid + i * TPB;
+                if (e < E) {
+                    const cplx V = buf[e];
+                    const double re = V.x * a.inv_n, im = V.y * a.inv_n;
+                    const double pw = re * re + im * im;
+                    acc[i] = (b == 0) ? pw : acc[i] + pw;
+                }
+            }
+        }
+    }
+    if (MODE == 0) return;
+    if (MODE == 3) {
+        double* __restrict__ po = a.pout + row * a.n;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = tid + i * TPB;
+            if (e < E) po[(long long)(k10 + e / N2) + (long long)N1 * (e % N2)] = acc[i];
+        }
+        return;
+    }
+    double best = -1.0;
+    int arg = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int e = tid + i * TPB;
+        if (e < E) {
+            const int idx = (k10 + e / N2) + N1 * (e % N2);
+            if (acc[i] > best || (acc[i] == best && idx < arg)) {
+                best = acc[i];
+                arg = idx;
+            }
+        }
+    }
+    __syncthreads();
+    double* s_v = reinterpret_cast<double*>(f4_smem);
+    int* s_i = reinterpret_cast<int*>(f4_smem + sizeof(double) * TPB);
+    s_v[tid] = best;
+    s_i[tid] = arg;
+    __syncthreads();
+    for (int st = TPB / 2; st > 0; st >>= 1) {
+        if (tid < st) {
+            const double ov = s_v[tid + st];
+            const int oi = s_i[tid + st];
+            if (ov > s_v[tid] || (ov == s_v[tid] && oi < s_i[tid])) {
+                s_v[tid] = ov;
+                s_i[tid] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        a.pmax[row * gridDim.x + blockIdx.x] = s_v[0];
+        a.parg[row * gridDim.x + blockIdx.x] = s_i[0];
+    }
+}
+
+// ---- the plan the acquisition uses: n = 38192 = 176 x 217 (16*11, 7*31); other lengths keep the pass-per-radix path ----
+#define F4_N1 176
+#define F4_N2 217
+#define F4_C 31
+#define F4_CB 16
+#define F4_TPB 512
+
+bool sgx_fft4_supported(int64_t n) { return n == (int64_t)F4_N1 * F4_N2; }
+int sgx_fft4_row_blocks(void) { return F4_N1 / F4_CB; }
+
+template <int MODE>
+static void f4_launch_cols(const F4Args& a, int64_t rows, hipStream_t st) {
+    auto kern = fft4_cols_kernel<F4_N1, F4_N2, F4_C, F4_TPB, 16, 11, 1, MODE>;
+    const size_t lds = sizeof(cplx) * F4_N1 * F4_C;
+    static bool once = false;
+    if (!once) {
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        once = true;
+    }
+    dim3 grid(F4_N2 / F4_C, (unsigned)rows);
+    kern<<<grid, F4_TPB, lds, st>>>(a);
+}
+
+template <int MODE>
+static void f4_launch_rows(const F4Args& a, int64_t rows, hipStream_t st) {
+    auto kern = fft4_rows_kernel<F4_N1, F4_N2, F4_CB, F4_TPB, 7, 31, 1, MODE>;
+    const size_t lds = sizeof(cplx) * F4_CB * F4_N2;
+    static bool once = false;
+    if (!once) {
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        once = true;
+    }
+    dim3 grid(F4_N1 / F4_CB, (unsigned)rows);
+    kern<<<grid, F4_TPB, lds, st>>>(a);
+}
+
+// Forward transform of `rows` rows through the four-step kernels.  `work` holds the intermediate; the result (natural
+// order) lands in `out`.  fuse (optional): product on load / reductions instead of a stored result, as FftFuse.
+int sgx_fft4_forward(const FftPlan* p, const cplx* in, cplx* work, cplx* out, int64_t rows, hipStream_t st,
+                     const Fft4Fuse* fuse) {
+    if (!p->tw_hi || !sgx_fft4_supported(p->n) || rows < 1 || rows > 65535) {
+        sgx_set_error("sgx_fft4_forward: length %lld / %lld rows not supported", (long long)p->n, (long long)rows);
+        return SGX_E_ARG;
+    }
+    int dev = 0;
+    SGX_HIP(hipGetDevice(&dev));
+    for (int r : {16, 11, 7, 31}) {
+        const int rc = ensure_roots(r);
+        if (rc != SGX_OK) return rc;
+    }
+    F4Args a;
+    memset(&a, 0, sizeof(a));
+    a.tw_hi = p->tw_hi;
+    a.tw_lo = p->tw_lo;
+    a.lo_bits = p->lo_bits;
+    a.n = p->n;
+    a.nonzero_len = p->n;
+    a.in = in;
+    a.out = work;
+    a.wr[0] = g_wr[dev][16];
+    a.wr[1] = g_wr[dev][11];
+    const int sum_blocks = (fuse && fuse->sum_blocks > 1) ? fuse->sum_blocks : 1;
+    if (fuse && fuse->mul_x) {
+        a.mul_x = fuse->mul_x;
+        a.mul_f = fuse->mul_f;
+        a.bin_map = fuse->bin_map;
+        a.row_map = fuse->row_map;
+        a.n_bins = fuse->n_bins;
+        a.n_phi = fuse->n_phi;
+        a.rows_per_prn = fuse->rows_per_prn;
+        a.prn_base = fuse->prn_base;
+        f4_launch_cols<1>(a, rows, st);
+    } else {
+        f4_launch_cols<0>(a, rows, st);
+    }
+    a.in = work;
+    a.out = out;
+    a.wr[0] = g_wr[dev][7];
+    a.wr[1] = g_wr[dev][31];
+    if (fuse && fuse->pmax) {
+        a.pmax = fuse->pmax;
+        a.parg = fuse->parg;
+        a.inv_n = fuse->inv_n;
+        a.sum_blocks = sum_blocks;
+        f4_launch_rows<2>(a, rows / sum_blocks, st);
+    } else if (fuse && fuse->pout) {
+        a.pout = fuse->pout;
+        a.inv_n = fuse->inv_n;
+        a.sum_blocks = sum_blocks;
+        f4_launch_rows<3>(a, rows / sum_blocks, st);
+    } else {
+        f4_launch_rows<0>(a, rows, st);
+    }
+    SGX_HIP(hipGetLastError());
+    return SGX_OK;
+}

@@ -122,4 +122,22 @@ int sgx_fft_forward_fused(const FftPlan* p, cplx* a, cplx* b, int64_t rows, hipS
                           int64_t nonzero_len, const FftFuse* fuse);
 int sgx_fft_last_pass_blocks(const FftPlan* p);
 
+// Four-step transform with LDS-resident sub-transforms (sgx_fft.hip), for the lengths it is instantiated for.
+struct Fft4Fuse {
+    const cplx* mul_x = nullptr;   // columns kernel input = conj(mul_x[b * n_phi + phi][(i + shift) mod n]) * mul_f[prn][i]
+    const cplx* mul_f = nullptr;
+    const int2* bin_map = nullptr; // device, per Doppler bin: (phi index, circular shift)
+    const int2* row_map = nullptr; // device (block * n_bins + bin, prn) per row, or null for the regular batch layout
+    int n_bins = 1, n_phi = 1, rows_per_prn = 1, prn_base = 0;
+    double* pmax = nullptr;        // rows kernel: per-workgroup (max, first index) of |.|^2 * inv_n^2 ...
+    int* parg = nullptr;
+    double* pout = nullptr;        // ... or the powers themselves, [rows / sum_blocks][n]
+    double inv_n = 0.0;
+    int sum_blocks = 1;            // powers of this many consecutive rows are added before the reduction / store
+};
+bool sgx_fft4_supported(int64_t n);
+int sgx_fft4_row_blocks(void);
+int sgx_fft4_forward(const FftPlan* p, const cplx* in, cplx* work, cplx* out, int64_t rows, hipStream_t st,
+                     const Fft4Fuse* fuse);
+
 // sgx_synth.hip / sgx_acq.hip / sgx_trk.hip provide the C-ABI entry points directly.

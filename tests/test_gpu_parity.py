@@ -881,10 +881,13 @@ def test_streaming_record_overlaps_tracking_with_identical_results(full_run, tmp
             r = ctx.open_file(path, 0, n_bytes)
             s2, d2 = ctx.track(r, chans, 6000)           # starts while the file is still being read
             assert np.all(d2 == 6000) and np.array_equal(s2[:, 0], series[:, 0, :6000])
-            if "SGX_TRK_SPLIT" in env:       # another reduction order: equal to rounding
-                assert _trk_err(s2, series[:, :, :6000]) < 1e-9
-            else:                            # the same arithmetic as the resident run: bit-identical
+            if env.get("SGX_TRK_STREAM") == "0":
+                # waits for the whole record, then the resident run's kernel: bit-identical
                 assert np.array_equal(s2, series[:, :, :6000])
+            else:
+                # the watermark-following kernel (round-1 body) and one workgroup per channel: other arithmetic /
+                # reduction order than the resident run's round-2 kernel, equal to rounding
+                assert _trk_err(s2, series[:, :, :6000]) < 1e-9
             assert np.array_equal(r.download(n_bytes - 5000, 5000), rec.download(n_bytes - 5000, 5000))
             r.free()
         finally:
@@ -1000,7 +1003,8 @@ def test_streaming_record_with_many_live_streams(full_run, tmp_path, capfd):
     """HIP maps streams onto a few hardware queues.  The copy stream of a streaming record has the highest
     priority (its own queue pool), so it runs beside the tracking kernel however many streams are alive; with a
     normal-priority copy stream (test hook) the watermark can stall behind the kernel - then the kernel gives up
-    after about a second and the launch is repeated on the resident record.  Results identical in every case."""
+    after about a second and the launch is repeated on the resident record.  Same block boundaries, sums equal to
+    rounding in every case."""
     m, s, ctx, sc, rec, a, chans, series, done = full_run
     path = str(tmp_path / "stream.bin")
     ms = 3000
@@ -1016,7 +1020,9 @@ def test_streaming_record_with_many_live_streams(full_run, tmp_path, capfd):
             r = ctx.open_file(path, 0, n_bytes)
             s2_, d2 = ctx.track(r, chans, ms)
             r.free()
-            assert np.all(d2 == ms) and np.array_equal(s2_, series[:, :, :ms])
+            # (the watermark-following kernel is the round-1 body: equal to the resident run up to rounding)
+            assert np.all(d2 == ms) and np.array_equal(s2_[:, 0], series[:, 0, :ms])
+            assert _trk_err(s2_, series[:, :, :ms]) < 1e-9
         assert "did not stream in" not in capfd.readouterr().err
         os.environ["SGX_STREAM_PRIO"] = "0"
         try:
@@ -1024,7 +1030,8 @@ def test_streaming_record_with_many_live_streams(full_run, tmp_path, capfd):
                 r = ctx.open_file(path, 0, n_bytes)
                 s3, d3 = ctx.track(r, chans, ms)
                 r.free()
-                assert np.all(d3 == ms) and np.array_equal(s3, series[:, :, :ms])
+                assert np.all(d3 == ms) and np.array_equal(s3[:, 0], series[:, 0, :ms])
+                assert _trk_err(s3, series[:, :, :ms]) < 1e-9
         finally:
             os.environ.pop("SGX_STREAM_PRIO", None)
     finally:
