@@ -276,6 +276,27 @@ __global__ __launch_bounds__(256) void acq_fine_argmax_kernel(const cplx* __rest
     }
 }
 
+// Forward rows of the shifted-spectrum search.  The reference transforms
+// x (sin th + j cos th) = j x e^(-j th), th = 2 pi f n / fs, for every Doppler bin f (acquisition.py:103-117).  With
+// f N / fs = s + phi (s integer, 0 <= phi < 1) that transform is j X_phi[(m + s) mod N], X_phi = fft(x e^(-j 2 pi phi n / N)):
+// bins that share phi share ONE forward spectrum, read with a circular shift (|j| = 1 drops out of |.|^2).  For the
+// default front end (fs / N = 1 kHz, 500 Hz grid) phi is 0 or 1/2: two forward transforms per 1-ms block instead of 29.
+struct PhiArgs {
+    double phi[4];
+    int n_phi;
+};
+__global__ __launch_bounds__(256) void acq_mixphi_kernel(const int8_t* __restrict__ x, cplx* __restrict__ out,
+                                                         long long n, PhiArgs a) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int j = blockIdx.y % a.n_phi;
+    const int b = blockIdx.y / a.n_phi;
+    const double xv = (double)x[(long long)b * n + i];
+    double s = 0.0, c = 1.0;
+    if (a.phi[j] != 0.0) sincospi((2.0 * a.phi[j]) * ((double)i / (double)n), &s, &c);
+    out[(long long)blockIdx.y * n + i] = make_double2(c * xv, -(s * xv));
+}
+
 static int ensure_buf(void** p, size_t* cap_bytes, size_t need) {
     if (*p && *cap_bytes >= need) return SGX_OK;
     if (*p) hipFree(*p);
@@ -289,6 +310,13 @@ static int ensure_buf(void** p, size_t* cap_bytes, size_t need) {
     *cap_bytes = need;
     return SGX_OK;
 }
+
+static int acquire_four_step(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n_samples, const int32_t* prn0,
+                             int32_t n_prn, int32_t n_blocks, int32_t noncoh, double* carrFreq, double* codePhase,
+                             double* peakMetric, int32_t* freqBin, int32_t* fineIdx, bool* handled);
+static int acquire_fine(sgx_ctx* c, const int8_t* x, size_t n_samples, const std::vector<int>& det_prn,
+                        const std::vector<int>& det_phase, const std::vector<int>& det_slot, long long* d_sum,
+                        double* carrFreq, double* codePhase, int32_t* fineIdx);
 
 extern "C" int sgx_acquire(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n_samples, const int32_t* prn0,
                            int32_t n_prn, int32_t n_blocks, int32_t noncoh, double* carrFreq, double* codePhase,
@@ -308,6 +336,13 @@ extern "C" int sgx_acquire(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n_
         if (rq != SGX_OK) return rq;
     }
     SGX_HIP(hipSetDevice(c->device));
+    {
+        // the four-step path (LDS-resident sub-transforms, shifted forward spectra) where it applies
+        bool handled = false;
+        const int rc4 = acquire_four_step(c, r, offset, n_samples, prn0, n_prn, n_blocks, noncoh, carrFreq, codePhase,
+                                          peakMetric, freqBin, fineIdx, &handled);
+        if (handled) return rc4;
+    }
     hipStream_t st = c->stream;
     const int8_t* x = r->d + offset;
 
@@ -540,6 +575,31 @@ extern "C" int sgx_acquire(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n_
     }
 
     // ---- fine frequency search (acquisition.py:167-193) -----------------------------------------------
+    {
+        const int rcf = acquire_fine(c, x, n_samples, det_prn, det_phase, det_slot, d_sum, carrFreq, codePhase, fineIdx);
+        if (rcf != SGX_OK) return rcf;
+    }
+    hipEventElapsedTime(&c->timing.acq_coarse_ms, c->ev[0], c->ev[1]);
+    hipEventElapsedTime(&c->timing.acq_fine_ms, c->ev[1], c->ev[2]);
+    hipEventElapsedTime(&c->timing.acquire_ms, c->ev[0], c->ev[2]);
+    return SGX_OK;
+}
+
+// Fine frequency search (acquisition.py:167-193) for the detected PRNs; records event ev[2] and synchronises.
+static int acquire_fine(sgx_ctx* c, const int8_t* x, size_t n_samples, const std::vector<int>& det_prn,
+                        const std::vector<int>& det_phase, const std::vector<int>& det_slot, long long* d_sum,
+                        double* carrFreq, double* codePhase, int32_t* fineIdx) {
+    hipStream_t st = c->stream;
+    const sgx_settings& S = c->s;
+    const long long N = c->n_code;
+    const double ts = 1.0 / S.samplingFreq;
+    char* dsm = (char*)c->d_small;
+    char* hsm = (char*)c->h_small;
+    int* d_detprn = (int*)(dsm + 1024 + 12 * 4096 + 512);
+    int* d_detph = d_detprn + 32;
+    double* d_pv = (double*)(dsm + 65536);
+    long long* d_pi = (long long*)(dsm + 65536 + 8 * 32 * 256);
+    int rc = SGX_OK;
     const int n_det = (int)det_prn.size();
     if (n_det > 0) {
         const long long len = 10 * N;
@@ -603,6 +663,294 @@ extern "C" int sgx_acquire(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n_
         hipEventRecord(c->ev[2], st);
         SGX_HIP(hipStreamSynchronize(st));
     }
+    return SGX_OK;
+}
+
+// Host part of the peak logic for one PRN (acquisition.py:129-162): block choice per bin (A7), global peak, first
+// row / first column attaining it (A8), exclusion list (A8b).  rowmax / rowarg: per (block, bin) row of this PRN, or per
+// bin (non-coherent).  Returns SGX_E_INDEX where the reference raises IndexError (Q5).
+static int acq_peak_logic(const double* rowmax, const int* rowarg, int n_bins, int n_blocks, bool noncoh, long long N,
+                          int spc, int prn_for_msg, double* peak, int* cph, int* fbi, int* best_block, int* lo0, int* hi0,
+                          int* lo1, int* hi1) {
+    double gmax = -1.0;
+    int gk = 0, gc = 0, gb = 0;
+    bool have = false;
+    for (int k = 0; k < n_bins; ++k) {
+        int row, bsel = 0;
+        if (noncoh) {
+            row = k;
+        } else {
+            int best = 0;   // acquisition.py:129-133 generalised left to right, later block wins ties
+            for (int b = 1; b < n_blocks; ++b) {
+                const double vb = rowmax[best * n_bins + k];
+                const double vn = rowmax[b * n_bins + k];
+                if (!(vb > vn)) best = b;
+            }
+            row = best * n_bins + k;
+            bsel = best;
+        }
+        const double v = rowmax[row];
+        const int a = rowarg[row];
+        if (!have || v > gmax) {
+            gmax = v;
+            gk = k;          // first row attaining the maximum (results.max(1).argmax())
+            gc = a;
+            gb = bsel;
+            have = true;
+        } else if (v == gmax && a < gc) {
+            gc = a;          // results.max(0).argmax(): first column attaining the maximum
+        }
+    }
+    *peak = gmax;
+    *cph = gc;
+    *fbi = gk;
+    *best_block = gb;
+    *lo0 = *hi0 = *lo1 = *hi1 = 0;
+    const int e1 = gc - spc, e2 = gc + spc;
+    if (e1 <= 0) {
+        if ((long long)N + e1 + 1 > N) {   // index N would be read: the reference's IndexError (Q5)
+            sgx_set_error("IndexError: index %lld is out of bounds for axis 1 with size %lld "
+                          "(PRN index %d, codePhase %d; reference acquisition.py:152-162)",
+                          N, N, prn_for_msg, gc);
+            return SGX_E_INDEX;
+        }
+        *lo0 = e2;
+        *hi0 = (int)(N + e1 + 1);
+    } else if (e2 >= N - 1) {
+        const int lo = (int)(e2 - N);
+        if (lo < 0) {   // arange starts at -1: numpy wraps it to N-1
+            *lo0 = 0;
+            *hi0 = e1;
+            *lo1 = (int)N - 1;
+            *hi1 = (int)N;
+        } else {
+            *lo0 = lo;
+            *hi0 = e1;
+        }
+    } else {
+        *lo0 = 0;
+        *hi0 = e1 + 1;
+        *lo1 = e2;
+        *hi1 = (int)N;
+    }
+    return SGX_OK;
+}
+
+// The acquisition on the four-step transform (sgx_fft.hip): every 38192-point transform is two kernels with LDS-resident
+// sub-transforms, the mixed-signal spectra are computed once per (block, phi) and read with a circular shift, results
+// land where they are needed (no device-to-device copies) and the host looks at the device twice before the fine search
+// (row maxima of ALL PRNs, then the second peaks) whatever the number of PRN chunks.
+static int acquire_four_step(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n_samples, const int32_t* prn0,
+                             int32_t n_prn, int32_t n_blocks, int32_t noncoh, double* carrFreq, double* codePhase,
+                             double* peakMetric, int32_t* freqBin, int32_t* fineIdx, bool* handled) {
+    *handled = false;
+    const long long N = c->n_code;
+    const sgx_settings& S = c->s;
+    const char* v1 = getenv("SGX_ACQ_V1");
+    if ((v1 && v1[0] == '1') || !sgx_fft4_supported(N)) return SGX_OK;
+    const int n_bins = (int)(nearbyint(S.acqSearchBand * 2) + 1);
+    if (n_bins < 1 || n_bins > ACQ_MAX_BINS) return SGX_OK;
+    // f N / fs = shift + phi for every bin; the path needs few distinct phi
+    PhiArgs pa;
+    pa.n_phi = 0;
+    std::vector<int2> bin_map((size_t)n_bins);
+    for (int k = 0; k < n_bins; ++k) {
+        const double f = S.IF - S.acqSearchBand / 2 * 1000 + 500.0 * k;   // A4 (acquisition.py:68,99-101)
+        const double ratio = f * (double)N / S.samplingFreq;
+        double sh = floor(ratio + 1e-9);
+        double phi = ratio - sh;
+        if (phi < 1e-9) phi = 0.0;
+        int j = -1;
+        for (int q = 0; q < pa.n_phi; ++q)
+            if (fabs(pa.phi[q] - phi) < 1e-9) j = q;
+        if (j < 0) {
+            if (pa.n_phi == 4) return SGX_OK;   // too many distinct fractions: the direct path mixes every bin
+            j = pa.n_phi;
+            pa.phi[pa.n_phi++] = phi;
+        }
+        long long shm = (long long)sh % N;
+        if (shm < 0) shm += N;
+        bin_map[(size_t)k] = make_int2(j, (int)shm);
+    }
+    if (pa.n_phi >= n_bins && n_bins > 1) return SGX_OK;
+    *handled = true;
+
+    hipStream_t st = c->stream;
+    const int8_t* x = r->d + offset;
+    const double ts = 1.0 / S.samplingFreq;
+    const double tc = 1.0 / S.codeFreqBasis;
+    const int spc = (int)llround(S.samplingFreq / S.codeFreqBasis);   // acquisition.py:145
+    int rc = sgx_fft_plan_create(&c->plan_code, N);
+    if (rc != SGX_OK) return rc;
+
+    // ---- scratch ------------------------------------------------------------------------------
+    const int n_phi = pa.n_phi;
+    const int rows_fwd = n_blocks * n_phi;
+    const int rows_per_prn = n_blocks * n_bins;
+    SGX_CHECK_ARG(rows_per_prn <= ACQ_MAX_ROWS);
+    // PRN chunks small enough for the intermediate (written by the columns kernel, read back by the rows kernel) to
+    // stay in the 256 MiB Infinity Cache: ~230 rows of 611 KB
+    int chunk_rows = 232;
+    {
+        const char* ce = getenv("SGX_ACQ_CHUNK_ROWS");
+        if (ce && atoi(ce) > 0) chunk_rows = atoi(ce);
+        if (chunk_rows > ACQ_MAX_ROWS) chunk_rows = ACQ_MAX_ROWS;
+    }
+    int prn_chunk = chunk_rows / rows_per_prn;
+    if (prn_chunk < 1) prn_chunk = 1;
+    if (prn_chunk > n_prn) prn_chunk = n_prn;
+    const size_t row_bytes = sizeof(cplx) * (size_t)N;
+    size_t work_rows = (size_t)prn_chunk * rows_per_prn;
+    if (work_rows < (size_t)rows_fwd) work_rows = rows_fwd;
+    if (work_rows < (size_t)n_prn * (noncoh ? n_blocks : 1)) work_rows = (size_t)n_prn * (noncoh ? n_blocks : 1);
+    if ((rc = ensure_buf((void**)&c->d_work[0], &c->cap_w0, work_rows * row_bytes)) != SGX_OK) return rc;
+    if ((rc = ensure_buf((void**)&c->d_work[1], &c->cap_w1, work_rows * row_bytes)) != SGX_OK) return rc;
+    if ((rc = ensure_buf((void**)&c->d_fwd, &c->cap_fwd, (size_t)rows_fwd * row_bytes)) != SGX_OK) return rc;
+    if ((rc = ensure_buf((void**)&c->d_codefd, &c->cap_code, (size_t)n_prn * row_bytes)) != SGX_OK) return rc;
+    const int nblk = sgx_fft4_row_blocks();
+    const int rows_out_all = n_prn * (noncoh ? n_bins : rows_per_prn);
+    size_t pow_need = (size_t)rows_out_all * nblk * 12 + 4096;
+    if (noncoh && pow_need < (size_t)n_prn * sizeof(double) * (size_t)N) pow_need = (size_t)n_prn * sizeof(double) * (size_t)N;
+    // [per-workgroup maxima | their indices | row maxima | row indices], then (non-coherent) the second-peak power rows
+    const size_t red_bytes = ((size_t)rows_out_all * nblk * 12 + (size_t)rows_out_all * 12 + 1023) / 256 * 256;
+    if ((rc = ensure_buf((void**)&c->d_pow, &c->cap_pow, red_bytes + pow_need)) != SGX_OK) return rc;
+    char* red = (char*)c->d_pow;
+    double* d_pmax = (double*)red;
+    int* d_parg = (int*)(red + (size_t)rows_out_all * nblk * 8);
+    double* d_rowmax = (double*)(red + (size_t)rows_out_all * nblk * 12);
+    int* d_rowarg = (int*)(red + (size_t)rows_out_all * nblk * 12 + (size_t)rows_out_all * 8);
+    double* d_power = (double*)(red + red_bytes);
+
+    char* dsm = (char*)c->d_small;
+    char* hsm = (char*)c->h_small;
+    long long* d_sum = (long long*)dsm;
+    int* d_prn = (int*)(dsm + 64);
+    double* d_second = (double*)(dsm + 1024 + 12 * 4096);
+    int2* d_binmap = (int2*)(dsm + 1024);              // [n_bins <= 128]
+    int2* d_map = (int2*)(dsm + 200000);
+
+    hipEventRecord(c->ev[0], st);
+    SGX_HIP(hipMemsetAsync(d_sum, 0, 8, st));
+    SGX_HIP(hipMemcpyAsync(d_prn, prn0, sizeof(int) * (size_t)n_prn, hipMemcpyHostToDevice, st));
+    SGX_HIP(hipMemcpyAsync(d_binmap, bin_map.data(), sizeof(int2) * (size_t)n_bins, hipMemcpyHostToDevice, st));
+    acq_sum_kernel<<<256, 256, 0, st>>>(x, (long long)n_samples, d_sum);
+
+    // ---- PRN-independent part: n_blocks x n_phi forward spectra, straight into d_fwd --------------------------
+    {
+        dim3 grid((unsigned)((N + 255) / 256), (unsigned)rows_fwd);
+        acq_mixphi_kernel<<<grid, 256, 0, st>>>(x, c->d_work[1], N, pa);
+        rc = sgx_fft4_forward(&c->plan_code, c->d_work[1], c->d_work[0], c->d_fwd, rows_fwd, st, nullptr);
+        if (rc != SGX_OK) return rc;
+    }
+    // ---- code spectra, straight into d_codefd -------------------------------------------------------------------
+    {
+        dim3 grid((unsigned)((N + 255) / 256), (unsigned)n_prn);
+        acq_code_kernel<<<grid, 256, 0, st>>>(c->d_codes, d_prn, c->d_work[1], N, ts, tc);
+        rc = sgx_fft4_forward(&c->plan_code, c->d_work[1], c->d_work[0], c->d_codefd, n_prn, st, nullptr);
+        if (rc != SGX_OK) return rc;
+    }
+    for (int i = 0; i < n_prn; ++i) {
+        carrFreq[i] = 0.0;
+        codePhase[i] = 0.0;
+        peakMetric[i] = 0.0;
+        freqBin[i] = -1;
+        fineIdx[i] = -1;
+    }
+    // ---- correlation, all PRN chunks queued back to back; row maxima of every PRN collected on the device -----------
+    const double inv_n = 1.0 / (double)N;
+    const int out_per_prn = noncoh ? n_bins : rows_per_prn;
+    for (int p0 = 0; p0 < n_prn; p0 += prn_chunk) {
+        const int np = (p0 + prn_chunk <= n_prn) ? prn_chunk : (n_prn - p0);
+        Fft4Fuse fu;
+        fu.mul_x = c->d_fwd;
+        fu.mul_f = c->d_codefd;
+        fu.bin_map = d_binmap;
+        fu.n_bins = n_bins;
+        fu.n_phi = n_phi;
+        fu.rows_per_prn = rows_per_prn;
+        fu.prn_base = p0;
+        fu.n_blocks = n_blocks;
+        fu.blocks_fast = noncoh ? 1 : 0;
+        fu.pmax = d_pmax + (size_t)p0 * out_per_prn * nblk;
+        fu.parg = d_parg + (size_t)p0 * out_per_prn * nblk;
+        fu.inv_n = inv_n;
+        fu.sum_blocks = noncoh ? n_blocks : 1;
+        rc = sgx_fft4_forward(&c->plan_code, nullptr, c->d_work[0], nullptr, (int64_t)np * rows_per_prn, st, &fu);
+        if (rc != SGX_OK) return rc;
+    }
+    acq_rowmax_finish_kernel<<<rows_out_all, 64, 0, st>>>(d_pmax, d_parg, nblk, d_rowmax, d_rowarg);
+    std::vector<double> h_rowmax((size_t)rows_out_all);
+    std::vector<int> h_rowarg((size_t)rows_out_all);
+    SGX_HIP(hipMemcpyAsync(h_rowmax.data(), d_rowmax, sizeof(double) * (size_t)rows_out_all, hipMemcpyDeviceToHost, st));
+    SGX_HIP(hipMemcpyAsync(h_rowarg.data(), d_rowarg, sizeof(int) * (size_t)rows_out_all, hipMemcpyDeviceToHost, st));
+    SGX_HIP(hipStreamSynchronize(st));
+
+    // ---- host: block choice, global peak, exclusion list of every PRN; the rows the second-peak search reads -------
+    SecondArgs sa;
+    double peak[32];
+    int cph[32], fbi[32];
+    int2* h_map = (int2*)(hsm + 200000);
+    int status = SGX_OK;
+    for (int pi = 0; pi < 32; ++pi) sa.row[pi] = -1, sa.lo0[pi] = sa.hi0[pi] = sa.lo1[pi] = sa.hi1[pi] = 0;
+    for (int pi = 0; pi < n_prn; ++pi) {
+        int bb = 0;
+        status = acq_peak_logic(h_rowmax.data() + (size_t)pi * out_per_prn, h_rowarg.data() + (size_t)pi * out_per_prn, n_bins,
+                                n_blocks, noncoh != 0, N, spc, prn0[pi], &peak[pi], &cph[pi], &fbi[pi], &bb, &sa.lo0[pi],
+                                &sa.hi0[pi], &sa.lo1[pi], &sa.hi1[pi]);
+        if (status != SGX_OK) break;
+        sa.row[pi] = pi;
+        if (noncoh) {
+            for (int b = 0; b < n_blocks; ++b) h_map[pi * n_blocks + b] = make_int2(b * n_bins + fbi[pi], pi);
+        } else {
+            h_map[pi] = make_int2(bb * n_bins + fbi[pi], pi);
+        }
+    }
+    if (status != SGX_OK) {
+        hipEventRecord(c->ev[1], st);
+        hipStreamSynchronize(st);
+        return status;
+    }
+    {
+        const int rows2 = n_prn * (noncoh ? n_blocks : 1);
+        SGX_HIP(hipMemcpyAsync(d_map, h_map, sizeof(int2) * (size_t)rows2, hipMemcpyHostToDevice, st));
+        Fft4Fuse fu;
+        fu.mul_x = c->d_fwd;
+        fu.mul_f = c->d_codefd;
+        fu.bin_map = d_binmap;
+        fu.row_map = d_map;
+        fu.n_bins = n_bins;
+        fu.n_phi = n_phi;
+        fu.n_blocks = n_blocks;
+        if (noncoh) {
+            fu.pout = d_power;
+            fu.inv_n = inv_n;
+            fu.sum_blocks = n_blocks;
+            rc = sgx_fft4_forward(&c->plan_code, nullptr, c->d_work[0], nullptr, rows2, st, &fu);
+            if (rc != SGX_OK) return rc;
+            acq_second_kernel<<<n_prn, 256, 0, st>>>(d_power, d_second, N, sa);
+        } else {
+            rc = sgx_fft4_forward(&c->plan_code, nullptr, c->d_work[0], c->d_work[1], rows2, st, &fu);
+            if (rc != SGX_OK) return rc;
+            acq_second_cplx_kernel<<<n_prn, 256, 0, st>>>(c->d_work[1], d_second, N, inv_n, sa);
+        }
+    }
+    double h_second[32];
+    SGX_HIP(hipMemcpyAsync(h_second, d_second, sizeof(double) * (size_t)n_prn, hipMemcpyDeviceToHost, st));
+    hipEventRecord(c->ev[1], st);
+    SGX_HIP(hipStreamSynchronize(st));
+    std::vector<int> det_prn, det_phase, det_slot;
+    for (int pi = 0; pi < n_prn; ++pi) {
+        const double ratio = peak[pi] / h_second[pi];
+        peakMetric[pi] = ratio;
+        freqBin[pi] = fbi[pi];
+        if (ratio > S.acqThreshold) {
+            det_prn.push_back(prn0[pi]);
+            det_phase.push_back(cph[pi]);
+            det_slot.push_back(pi);
+        }
+    }
+    rc = acquire_fine(c, x, n_samples, det_prn, det_phase, det_slot, d_sum, carrFreq, codePhase, fineIdx);
+    if (rc != SGX_OK) return rc;
     hipEventElapsedTime(&c->timing.acq_coarse_ms, c->ev[0], c->ev[1]);
     hipEventElapsedTime(&c->timing.acq_fine_ms, c->ev[1], c->ev[2]);
     hipEventElapsedTime(&c->timing.acquire_ms, c->ev[0], c->ev[2]);

@@ -479,6 +479,7 @@ struct F4Args {
     const cplx* tw_hi;
     const cplx* tw_lo;
     const cplx* wr[3];      // root tables of the (up to three) radices of this kernel's sub-transform
+    const cplx* tw_sub;     // W_L^t, t < L, of this kernel's sub-transform length L
     long long n;
     long long nonzero_len;  // input elements >= this index are zero
     int lo_bits;
@@ -488,6 +489,7 @@ struct F4Args {
     const int2* bin_map;    // per Doppler bin: (phi index, circular shift)
     const int2* row_map;    // optional: (block * n_bins + bin, prn) per row
     int n_bins, n_phi, rows_per_prn, prn_base;
+    int n_blocks, blocks_fast;   // batch rows ordered (prn, bin, block) instead of (prn, block, bin)
     // rows kernel, MODE 2 / 3
     double* pmax;           // [rows][gridDim.x] per-workgroup maxima (MODE 2)
     int* parg;
@@ -504,20 +506,26 @@ __device__ __forceinline__ cplx f4_twiddle(const F4Args& a, long long t) {
 
 // One Stockham radix-R pass over C sequences of length L in LDS; element n of sequence c lives at buf[n * SN + c * SC].
 // CFAST: consecutive threads take consecutive sequences (use when SC == 1), else consecutive butterflies.
-template <int L, int R, int C, int SN, int SC, int TPB, bool CFAST>
-__device__ __forceinline__ void lds_radix_pass(cplx* __restrict__ buf, int ns, const F4Args& a, const cplx* __restrict__ wr,
-                                               int tid) {
+// twl = W_L^t, t < L, in LDS (needed when NS > 1).
+template <int L, int R, int NS, int C, int SN, int SC, int TPB, bool CFAST>
+__device__ __forceinline__ void lds_radix_pass(cplx* __restrict__ buf, const cplx* __restrict__ twl,
+                                               const cplx* __restrict__ wr, int tid) {
     constexpr int M = L / R;
     constexpr int TOTAL = M * C;
     constexpr int ROUNDS = (TOTAL + TPB - 1) / TPB;
+    constexpr int TS = L / (NS * R);
     cplx v[ROUNDS][R];
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; ++rd) {
         const int w = tid + rd * TPB;
         if (w < TOTAL) {
             const int c = CFAST ? w % C : w / M, j = CFAST ? w / C : w % M;
+            const int k = j % NS;
 #pragma unroll
-            for (int q = 0; q < R; ++q) v[rd][q] = buf[(j + q * M) * SN + c * SC];
+            for (int q = 0; q < R; ++q) {
+                v[rd][q] = buf[(j + q * M) * SN + c * SC];
+                if (NS > 1 && q > 0) v[rd][q] = cmul(v[rd][q], twl[q * k * TS]);   // q k TS < L
+            }
         }
     }
     __syncthreads();
@@ -526,32 +534,107 @@ __device__ __forceinline__ void lds_radix_pass(cplx* __restrict__ buf, int ns, c
         const int w = tid + rd * TPB;
         if (w < TOTAL) {
             const int c = CFAST ? w % C : w / M, j = CFAST ? w / C : w % M;
-            const int k = j % ns;
-            if (ns > 1) {
-                // W_L^(q k L / (ns R)) = W_n^(q k (L / (ns R)) (n / L))
-                const long long tstep = (long long)k * (L / (ns * R)) * (a.n / L);
-                long long t = 0;
+            const int k = j % NS;
+            const int j0 = (j / NS) * NS * R + k;
+            if constexpr ((R % 2 == 1) && (R >= 11)) {
+                // large odd radix: outputs go to LDS as they are produced (half the live registers)
+                dft_odd_emit<R>(v[rd], wr, [&](int q, cplx V) { buf[(j0 + q * NS) * SN + c * SC] = V; });
+            } else {
+                dft_small<R>(v[rd], wr);
 #pragma unroll
-                for (int q = 1; q < R; ++q) {
-                    t += tstep;
-                    if (t >= a.n) t -= a.n;
-                    v[rd][q] = cmul(v[rd][q], f4_twiddle(a, t));
-                }
+                for (int q = 0; q < R; ++q) buf[(j0 + q * NS) * SN + c * SC] = v[rd][q];
             }
-            dft_small<R>(v[rd], wr);
-            const int j0 = (j / ns) * ns * R + k;
-#pragma unroll
-            for (int q = 0; q < R; ++q) buf[(j0 + q * ns) * SN + c * SC] = v[rd][q];
         }
     }
     __syncthreads();
 }
 
-template <int L, int C, int SN, int SC, int TPB, bool CFAST, int R1, int R2, int R3>
-__device__ __forceinline__ void lds_fft(cplx* __restrict__ buf, const F4Args& a, int tid) {
-    lds_radix_pass<L, R1, C, SN, SC, TPB, CFAST>(buf, 1, a, a.wr[0], tid);
-    if constexpr (R2 > 1) lds_radix_pass<L, R2, C, SN, SC, TPB, CFAST>(buf, R1, a, a.wr[1], tid);
-    if constexpr (R3 > 1) lds_radix_pass<L, R3, C, SN, SC, TPB, CFAST>(buf, R1 * R2, a, a.wr[2], tid);
+// A large odd radix with few butterflies per workgroup (radix 31: 7 per 217-point row): PARTS waves share a
+// butterfly, each producing a compile-time subset of the output pairs (k, R - k), so every wave keeps the roots in
+// scalar registers and the pass runs PARTS times wider.  The a = v[q] + v[R-q], b = v[q] - v[R-q] halves are what
+// is staged in registers across the barrier.  Wave w takes part w % PARTS and butterflies (w / PARTS) * 64 + lane.
+template <int R, int PART, int PARTS, class Emit>
+__device__ __forceinline__ void dft_odd_part(const cplx (&a)[(R - 1) / 2], const cplx (&b)[(R - 1) / 2], cplx v0,
+                                             const cplx* __restrict__ wr, Emit&& emit) {
+    constexpr int H = (R - 1) / 2;
+    double wc[H], ws[H];
+#pragma unroll
+    for (int m = 1; m <= H; ++m) {
+        wc[m - 1] = wr[m].x;
+        ws[m - 1] = wr[m].y;
+    }
+    if (PART == 0) {
+        cplx s0 = v0;
+#pragma unroll
+        for (int q = 0; q < H; ++q) s0 = cadd(s0, a[q]);
+        emit(0, s0);
+    }
+#pragma unroll
+    for (int k = 1 + PART; k <= H; k += PARTS) {
+        double pr = v0.x, pi = v0.y, qr = 0.0, qi = 0.0;
+#pragma unroll
+        for (int q = 1; q <= H; ++q) {
+            const int m0 = (q * k) % R;
+            const bool lowhalf = m0 <= H;
+            const int m = lowhalf ? m0 : R - m0;
+            const double c = wc[m - 1];
+            const double sy = lowhalf ? ws[m - 1] : -ws[m - 1];
+            pr = __builtin_fma(a[q - 1].x, c, pr);
+            pi = __builtin_fma(a[q - 1].y, c, pi);
+            qr = __builtin_fma(b[q - 1].y, -sy, qr);
+            qi = __builtin_fma(b[q - 1].x, sy, qi);
+        }
+        emit(k, make_double2(pr + qr, pi + qi));
+        emit(R - k, make_double2(pr - qr, pi - qi));
+    }
+}
+
+template <int L, int R, int NS, int C, int SN, int SC, int TPB, bool CFAST, int PARTS>
+__device__ __forceinline__ void lds_odd_pass_split(cplx* __restrict__ buf, const cplx* __restrict__ twl,
+                                                   const cplx* __restrict__ wr, int tid) {
+    static_assert(PARTS == 4, "instantiated for four parts");
+    constexpr int M = L / R, H = (R - 1) / 2;
+    constexpr int TOTAL = M * C;
+    constexpr int TS = L / (NS * R);
+    static_assert((TPB / 64 / PARTS) * 64 >= TOTAL, "one round must cover every butterfly");
+    const int wv = tid >> 6, lane = tid & 63;
+    const int part = __builtin_amdgcn_readfirstlane(wv % PARTS);
+    const int w = (wv / PARTS) * 64 + lane;
+    const bool act = w < TOTAL;
+    const int c = CFAST ? w % C : w / M, j = CFAST ? w / C : w % M;
+    const int k = j % NS;
+    cplx a[H], b[H];
+    cplx v0 = make_double2(0.0, 0.0);
+    if (act) {
+        v0 = buf[j * SN + c * SC];
+#pragma unroll
+        for (int q = 1; q <= H; ++q) {
+            cplx x = buf[(j + q * M) * SN + c * SC];
+            cplx y = buf[(j + (R - q) * M) * SN + c * SC];
+            if (NS > 1) {
+                x = cmul(x, twl[q * k * TS]);
+                y = cmul(y, twl[(R - q) * k * TS]);
+            }
+            a[q - 1] = cadd(x, y);
+            b[q - 1] = csub(x, y);
+        }
+    }
+    __syncthreads();
+    if (act) {
+        const int j0 = (j / NS) * NS * R + k;
+        auto put = [&](int q, cplx V) { buf[(j0 + q * NS) * SN + c * SC] = V; };
+        if (part == 0) dft_odd_part<R, 0, PARTS>(a, b, v0, wr, put);
+        else if (part == 1) dft_odd_part<R, 1, PARTS>(a, b, v0, wr, put);
+        else if (part == 2) dft_odd_part<R, 2, PARTS>(a, b, v0, wr, put);
+        else dft_odd_part<R, 3, PARTS>(a, b, v0, wr, put);
+    }
+    __syncthreads();
+}
+
+// W_L^t, t < L, into LDS (from the plan's table of the sub-transform's roots)
+template <int L, int TPB>
+__device__ __forceinline__ void lds_fill_twiddles(cplx* __restrict__ twl, const cplx* __restrict__ tab, int tid) {
+    for (int t = tid; t < L; t += TPB) twl[t] = tab[t];
 }
 
 // MODE 0: plain.  MODE 1: input = conj(X[(i + shift) mod n]) * F[i] (correlation product, acquisition.py:120-123).
@@ -559,7 +642,9 @@ template <int N1, int N2, int C, int TPB, int R1, int R2, int R3, int MODE>
 __global__ __launch_bounds__(TPB) void fft4_cols_kernel(F4Args a) {
     extern __shared__ __attribute__((aligned(16))) char f4_smem[];
     cplx* __restrict__ buf = reinterpret_cast<cplx*>(f4_smem);   // [N1][C]
+    cplx* __restrict__ twl = buf + N1 * C;                       // [N1]: W_N1^t
     const int tid = threadIdx.x;
+    lds_fill_twiddles<N1, TPB>(twl, a.tw_sub, tid);
     const int c0 = blockIdx.x * C;
     const long long row = blockIdx.y;
     const cplx* __restrict__ in = a.in + row * a.n;
@@ -576,7 +661,8 @@ __global__ __launch_bounds__(TPB) void fft4_cols_kernel(F4Args a) {
             bk = (int)(row % a.rows_per_prn);
             prn = a.prn_base + (int)(row / a.rows_per_prn);
         }
-        const int b = bk / a.n_bins, kb = bk % a.n_bins;
+        const bool bf = a.blocks_fast && !a.row_map;
+        const int b = bf ? bk % a.n_blocks : bk / a.n_bins, kb = bf ? bk / a.n_blocks : bk % a.n_bins;
         const int2 bm = a.bin_map[kb];
         px = a.mul_x + (long long)(b * a.n_phi + bm.x) * a.n;
         pf = a.mul_f + (long long)prn * a.n;
@@ -597,7 +683,10 @@ __global__ __launch_bounds__(TPB) void fft4_cols_kernel(F4Args a) {
         buf[e] = val;
     }
     __syncthreads();
-    lds_fft<N1, C, C, 1, TPB, true, R1, R2, R3>(buf, a, tid);
+    // R3 = 4: the second radix is a large odd one whose butterflies are split over four waves each
+    lds_radix_pass<N1, R1, 1, C, C, 1, TPB, true>(buf, twl, a.wr[0], tid);
+    if constexpr (R3 == 4) lds_odd_pass_split<N1, R2, R1, C, C, 1, TPB, true, 4>(buf, twl, a.wr[1], tid);
+    else lds_radix_pass<N1, R2, R1, C, C, 1, TPB, true>(buf, twl, a.wr[1], tid);
     cplx* __restrict__ out = a.out + row * a.n;
     for (int e = tid; e < N1 * C; e += TPB) {
         const int k1 = e / C, c = e % C;
@@ -612,7 +701,9 @@ template <int N1, int N2, int CB, int TPB, int R1, int R2, int R3, int MODE>
 __global__ __launch_bounds__(TPB) void fft4_rows_kernel(F4Args a) {
     extern __shared__ __attribute__((aligned(16))) char f4_smem[];
     cplx* __restrict__ buf = reinterpret_cast<cplx*>(f4_smem);   // [CB][N2]
+    cplx* __restrict__ twl = buf + CB * N2;                      // [N2]: W_N2^t
     const int tid = threadIdx.x;
+    lds_fill_twiddles<N2, TPB>(twl, a.tw_sub, tid);
     const int k10 = blockIdx.x * CB;
     const long long row = blockIdx.y;
     constexpr int E = CB * N2;
@@ -626,7 +717,9 @@ __global__ __launch_bounds__(TPB) void fft4_rows_kernel(F4Args a) {
         if (b > 0) __syncthreads();
         for (int e = tid; e < E; e += TPB) buf[e] = in[e];
         __syncthreads();
-        lds_fft<N2, CB, 1, N2, TPB, false, R1, R2, R3>(buf, a, tid);
+        lds_radix_pass<N2, R1, 1, CB, 1, N2, TPB, false>(buf, twl, a.wr[0], tid);
+        if constexpr (R3 == 4) lds_odd_pass_split<N2, R2, R1, CB, 1, N2, TPB, false, 4>(buf, twl, a.wr[1], tid);
+        else lds_radix_pass<N2, R2, R1, CB, 1, N2, TPB, false>(buf, twl, a.wr[1], tid);
         if (MODE == 0) {
             cplx* __restrict__ out = a.out + row * a.n;
             for (int e = tid; e < E; e += TPB) {
@@ -693,19 +786,38 @@ __global__ __launch_bounds__(TPB) void fft4_rows_kernel(F4Args a) {
 }
 
 // ---- the plan the acquisition uses: n = 38192 = 176 x 217 (16*11, 7*31); other lengths keep the pass-per-radix path ----
-#define F4_N1 176
-#define F4_N2 217
-#define F4_C 31
-#define F4_CB 16
-#define F4_TPB 512
+#define F4_N1 217          // columns: 7 x 31 (the radix-31 butterflies split over four waves each)
+#define F4_N2 176          // rows: 16 x 11
+#define F4_C 16            // 256 contiguous bytes per column-tile row; 59 KB of LDS: two workgroups per CU
+#define F4_CB 7            // 217 = 31 x 7 rows; 22 KB of LDS: seven workgroups per CU
+#define F4_TPB 512         // columns kernel: 496 radix-7 butterflies, 112 radix-31 butterflies x 4 waves
+#define F4_TPB_ROWS 128    // rows kernel: 77 radix-16 / 112 radix-11 butterflies
 
 bool sgx_fft4_supported(int64_t n) { return n == (int64_t)F4_N1 * F4_N2; }
+
+static cplx* g_f4_sub[SGX_MAX_DEVICES][2] = {{nullptr, nullptr}};   // W_N1^t and W_N2^t per device
+static int f4_ensure_sub_tables(int dev) {
+    std::lock_guard<std::mutex> hold(g_wr_lock);
+    if (g_f4_sub[dev][0]) return SGX_OK;
+    const long double twopi = 2.0L * 3.14159265358979323846264338327950288L;
+    const int len[2] = {F4_N1, F4_N2};
+    for (int i = 0; i < 2; ++i) {
+        std::vector<cplx> w((size_t)len[i]);
+        for (int t = 0; t < len[i]; ++t) {
+            const long double ang = -twopi * (long double)t / (long double)len[i];
+            w[(size_t)t] = make_double2((double)cosl(ang), (double)sinl(ang));
+        }
+        SGX_HIP(hipMalloc((void**)&g_f4_sub[dev][i], sizeof(cplx) * w.size()));
+        SGX_HIP(hipMemcpy(g_f4_sub[dev][i], w.data(), sizeof(cplx) * w.size(), hipMemcpyHostToDevice));
+    }
+    return SGX_OK;
+}
 int sgx_fft4_row_blocks(void) { return F4_N1 / F4_CB; }
 
 template <int MODE>
 static void f4_launch_cols(const F4Args& a, int64_t rows, hipStream_t st) {
-    auto kern = fft4_cols_kernel<F4_N1, F4_N2, F4_C, F4_TPB, 16, 11, 1, MODE>;
-    const size_t lds = sizeof(cplx) * F4_N1 * F4_C;
+    auto kern = fft4_cols_kernel<F4_N1, F4_N2, F4_C, F4_TPB, 7, 31, 4, MODE>;
+    const size_t lds = sizeof(cplx) * (F4_N1 * F4_C + F4_N1);
     static bool once = false;
     if (!once) {
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -717,15 +829,15 @@ static void f4_launch_cols(const F4Args& a, int64_t rows, hipStream_t st) {
 
 template <int MODE>
 static void f4_launch_rows(const F4Args& a, int64_t rows, hipStream_t st) {
-    auto kern = fft4_rows_kernel<F4_N1, F4_N2, F4_CB, F4_TPB, 7, 31, 1, MODE>;
-    const size_t lds = sizeof(cplx) * F4_CB * F4_N2;
+    auto kern = fft4_rows_kernel<F4_N1, F4_N2, F4_CB, F4_TPB_ROWS, 16, 11, 1, MODE>;
+    const size_t lds = sizeof(cplx) * (F4_CB * F4_N2 + F4_N2);
     static bool once = false;
     if (!once) {
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         once = true;
     }
     dim3 grid(F4_N1 / F4_CB, (unsigned)rows);
-    kern<<<grid, F4_TPB, lds, st>>>(a);
+    kern<<<grid, F4_TPB_ROWS, lds, st>>>(a);
 }
 
 // Forward transform of `rows` rows through the four-step kernels.  `work` holds the intermediate; the result (natural
@@ -742,8 +854,14 @@ int sgx_fft4_forward(const FftPlan* p, const cplx* in, cplx* work, cplx* out, in
         const int rc = ensure_roots(r);
         if (rc != SGX_OK) return rc;
     }
+    if (dev < 0 || dev >= SGX_MAX_DEVICES) return SGX_E_ARG;
+    {
+        const int rc = f4_ensure_sub_tables(dev);
+        if (rc != SGX_OK) return rc;
+    }
     F4Args a;
     memset(&a, 0, sizeof(a));
+    a.tw_sub = g_f4_sub[dev][0];
     a.tw_hi = p->tw_hi;
     a.tw_lo = p->tw_lo;
     a.lo_bits = p->lo_bits;
@@ -751,8 +869,8 @@ int sgx_fft4_forward(const FftPlan* p, const cplx* in, cplx* work, cplx* out, in
     a.nonzero_len = p->n;
     a.in = in;
     a.out = work;
-    a.wr[0] = g_wr[dev][16];
-    a.wr[1] = g_wr[dev][11];
+    a.wr[0] = g_wr[dev][7];
+    a.wr[1] = g_wr[dev][31];
     const int sum_blocks = (fuse && fuse->sum_blocks > 1) ? fuse->sum_blocks : 1;
     if (fuse && fuse->mul_x) {
         a.mul_x = fuse->mul_x;
@@ -763,14 +881,17 @@ int sgx_fft4_forward(const FftPlan* p, const cplx* in, cplx* work, cplx* out, in
         a.n_phi = fuse->n_phi;
         a.rows_per_prn = fuse->rows_per_prn;
         a.prn_base = fuse->prn_base;
+        a.n_blocks = fuse->n_blocks;
+        a.blocks_fast = fuse->blocks_fast;
         f4_launch_cols<1>(a, rows, st);
     } else {
         f4_launch_cols<0>(a, rows, st);
     }
     a.in = work;
     a.out = out;
-    a.wr[0] = g_wr[dev][7];
-    a.wr[1] = g_wr[dev][31];
+    a.tw_sub = g_f4_sub[dev][1];
+    a.wr[0] = g_wr[dev][16];
+    a.wr[1] = g_wr[dev][11];
     if (fuse && fuse->pmax) {
         a.pmax = fuse->pmax;
         a.parg = fuse->parg;

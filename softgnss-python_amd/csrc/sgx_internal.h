@@ -129,6 +129,7 @@ struct Fft4Fuse {
     const int2* bin_map = nullptr; // device, per Doppler bin: (phi index, circular shift)
     const int2* row_map = nullptr; // device (block * n_bins + bin, prn) per row, or null for the regular batch layout
     int n_bins = 1, n_phi = 1, rows_per_prn = 1, prn_base = 0;
+    int n_blocks = 1, blocks_fast = 0;   // regular batch rows ordered (prn, bin, block) instead of (prn, block, bin)
     double* pmax = nullptr;        // rows kernel: per-workgroup (max, first index) of |.|^2 * inv_n^2 ...
     int* parg = nullptr;
     double* pout = nullptr;        // ... or the powers themselves, [rows / sum_blocks][n]
