@@ -5,6 +5,8 @@ without a GPU, an exception is raised - there is no CPU implementation behind th
 """
 import ctypes as C
 import os
+import threading
+import weakref
 
 import numpy as np
 
@@ -170,12 +172,14 @@ def scene_struct(scene):
 
 
 class _Pinned(object):
-    """Owner of one pinned host allocation; numpy arrays built on it keep it alive through .base."""
+    """Owner of one pinned host allocation.  `busy` is set while a numpy array handed out by pinned_empty() is alive
+    (cleared by a weakref finalizer on the ctypes buffer the array is built on)."""
 
     def __init__(self, nbytes):
         self.ptr = _P()
         check(lib().sgx_host_alloc(int(nbytes), C.byref(self.ptr)))
         self.nbytes = int(nbytes)
+        self.busy = False
 
     def __del__(self):
         try:
@@ -186,27 +190,40 @@ class _Pinned(object):
 
 
 _pinned_pool = []   # pinning is slow (ms per 30 MB): allocations whose arrays have died are reused
+_pinned_lock = threading.Lock()
+
+
+def _pinned_release(own):
+    with _pinned_lock:
+        own.busy = False
 
 
 def pinned_empty(shape, dtype=np.float64):
     """numpy array in pinned host memory (falls back to a pageable array if pinning fails)."""
-    import sys
     n = int(np.prod(shape)) * np.dtype(dtype).itemsize
     own = None
-    for cand in _pinned_pool:
-        if cand.nbytes >= n and sys.getrefcount(cand) <= 3:   # pool + loop variable + getrefcount argument
-            own = cand
-            break
+    with _pinned_lock:
+        for cand in _pinned_pool:
+            if cand.nbytes >= n and not cand.busy:
+                own = cand
+                break
+        if own is not None:
+            own.busy = True
     if own is None:
         try:
             own = _Pinned(max(n, 1))
         except Exception:
             return np.empty(shape, dtype=dtype)
-        _pinned_pool.append(own)
-        if len(_pinned_pool) > 8:
-            _pinned_pool.pop(0)
+        own.busy = True
+        with _pinned_lock:
+            _pinned_pool.append(own)
+            while len(_pinned_pool) > 8:
+                # drop an idle allocation (a busy one stays alive through its array even when it leaves the pool)
+                idle = [c for c in _pinned_pool if not c.busy and c is not own]
+                _pinned_pool.remove(idle[0] if idle else _pinned_pool[0])
     buf = (C.c_char * own.nbytes).from_address(own.ptr.value)
     buf._owner = own                       # ctypes object keeps the owner, numpy keeps the ctypes object
+    weakref.finalize(buf, _pinned_release, own)   # every view of the array holds `buf` through .base
     return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
 
@@ -242,9 +259,12 @@ class Context(object):
         self._s = settings_struct(settings)
         check(lib().sgx_ctx_create_prio(C.byref(self._s), int(device), int(priority), C.byref(self._h)))
         self.device = int(device)
+        self._records = weakref.WeakSet()   # live records of this context: freed (loader threads joined) before it
 
     def close(self):
         if self._h:
+            for rec in list(self._records):
+                rec.free()
             lib().sgx_ctx_destroy(self._h)
             self._h = _P()
 
@@ -356,6 +376,7 @@ class Record(object):
         self.ctx = ctx
         self._h = handle
         self.n = n
+        ctx._records.add(self)
 
     def __len__(self):
         return self.n
@@ -371,8 +392,9 @@ class Record(object):
         return out
 
     def free(self):
-        if self._h and self.ctx._h:
-            lib().sgx_if_free(self.ctx._h, self._h)
+        if self._h:
+            # (a context that is already gone: sgx_if_free(NULL, h) still joins the loader thread and frees the HBM)
+            lib().sgx_if_free(self.ctx._h if self.ctx._h else None, self._h)
         self._h = _P()
 
     def __del__(self):

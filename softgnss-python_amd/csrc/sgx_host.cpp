@@ -142,16 +142,7 @@ extern "C" int sgx_ctx_create(const sgx_settings* s, int device, sgx_ctx** out) 
     return sgx_ctx_create_prio(s, device, 0, out);
 }
 
-extern "C" int sgx_ctx_create_prio(const sgx_settings* s, int device, int priority, sgx_ctx** out) {
-    SGX_CHECK_ARG(s && out && priority >= -1 && priority <= 1);
-    SGX_CHECK_ARG(s->codeLength == 1023 && s->samplingFreq > 0 && s->codeFreqBasis > 0);
-    SGX_HIP(hipSetDevice(device));
-    sgx_ctx* c = new sgx_ctx();
-    c->s = *s;
-    c->device = device;
-    c->n_code = sgx_host_samples_per_code(s);
-    memset(&c->timing, 0, sizeof(c->timing));
-    c->priority = priority;
+static int ctx_build(sgx_ctx* c, int priority) {
     if (priority == 0) {
         SGX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     } else {
@@ -166,6 +157,31 @@ extern "C" int sgx_ctx_create_prio(const sgx_settings* s, int device, int priori
     SGX_HIP(hipMemcpy(c->d_codes, codes.data(), codes.size(), hipMemcpyHostToDevice));
     SGX_HIP(hipMalloc(&c->d_small, 1 << 20));
     SGX_HIP(hipHostMalloc(&c->h_small, 1 << 20, hipHostMallocDefault));
+    return SGX_OK;
+}
+
+extern "C" int sgx_ctx_create_prio(const sgx_settings* s, int device, int priority, sgx_ctx** out) {
+    SGX_CHECK_ARG(s && out && priority >= -1 && priority <= 1);
+    SGX_CHECK_ARG(s->codeLength == 1023 && s->samplingFreq > 0 && s->codeFreqBasis > 0);
+    SGX_HIP(hipSetDevice(device));
+    sgx_ctx* c = new sgx_ctx();
+    c->s = *s;
+    c->device = device;
+    c->n_code = sgx_host_samples_per_code(s);
+    memset(&c->timing, 0, sizeof(c->timing));
+    c->priority = priority;
+    const int rc = ctx_build(c, priority);
+    if (rc != SGX_OK) {
+        // a partially built context: release what exists (the message of the failing call is kept)
+        if (c->stream) hipStreamDestroy(c->stream);
+        for (int i = 0; i < 6; ++i)
+            if (c->ev[i]) hipEventDestroy(c->ev[i]);
+        if (c->d_codes) hipFree(c->d_codes);
+        if (c->d_small) hipFree(c->d_small);
+        if (c->h_small) hipHostFree(c->h_small);
+        delete c;
+        return rc;
+    }
     *out = c;
     return SGX_OK;
 }

@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""rocprofv3 (rocpd sqlite) outputs of tools/profile_round.sh -> the small summaries kept under profiles/ (written to
+<out>/summary/, copied into profiles/ by hand).
+
+    python tools/profile_summary.py <tag> <out dir>
+"""
+import glob
+import json
+import os
+import sqlite3
+import sys
+
+
+def db_of(d):
+    g = glob.glob(os.path.join(d, "*", "*_results.db"))
+    return g[0] if g else None
+
+
+def top_kernels(db):
+    return list(sqlite3.connect(db).execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
+
+
+def per_dispatch(db, counter):
+    """[(kernel, dispatch id, value)] of one counter (summed over its dimensions)."""
+    q = ("select kernel_name, dispatch_id, sum(value) from counters_collection where counter_name = ? "
+         "group by kernel_name, dispatch_id")
+    return list(sqlite3.connect(db).execute(q, (counter,)))
+
+
+def by_kernel(rows):
+    out = {}
+    for k, _, v in rows:
+        out.setdefault(k, []).append(v)
+    return out
+
+
+def main():
+    tag, out = sys.argv[1], sys.argv[2]
+    dst = os.path.join(out, "summary")
+    os.makedirs(dst, exist_ok=True)
+    # ---- kernel trace ----
+    rows = top_kernels(db_of(os.path.join(out, "trace")))
+    with open(os.path.join(dst, "%s_kernel_trace_stats.csv" % tag), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "
+                "(the bench command; the CPU leg forks and is left out under the profiler)\n")
+        f.write("kernel,calls,total_us,average_us,percent\n")
+        for n, calls, tot, avg, pct in rows:
+            f.write('"%s",%d,%.3f,%.3f,%.3f\n' % (n, calls, tot, avg, pct))
+    # ---- HBM traffic of the bench command ----
+    fetch = by_kernel(per_dispatch(db_of(os.path.join(out, "fetch")), "FETCH_SIZE"))
+    write = by_kernel(per_dispatch(db_of(os.path.join(out, "write")), "WRITE_SIZE"))
+    with open(os.path.join(dst, "%s_pmc_hbm.csv" % tag), "w") as f:
+        f.write("# separate passes: rocprofv3 --pmc FETCH_SIZE --kernel-trace / --pmc WRITE_SIZE --kernel-trace -- python3 bench.py "
+                "--steps 1 --warmup 0 --no-cpu-baseline --concurrent 0 --no-config4; raw counter unit = KiB, per kernel: dispatches, sum, largest dispatch\n")
+        f.write("counter,kernel,dispatches,raw_sum_KiB,raw_max_KiB\n")
+        for name, d in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
+            for k, v in sorted(d.items(), key=lambda t: -sum(t[1])):
+                f.write('%s,"%s",%d,%.3f,%.3f\n' % (name, k, len(v), sum(v), max(v)))
+    corr = ("gfx950 FETCH_SIZE reports half of the bytes of wide (16 B per lane) coalesced reads (MI355X_MICROARCH.md, "
+            "HBM section): x2; WRITE_SIZE used as reported")
+
+    def big(d, prefix):
+        ks = [k for k in d if k.startswith(prefix)]
+        return max(max(d[k]) for k in ks) * 1024.0 if ks else None
+
+    f_trk, w_trk = big(fetch, "trk2_kernel"), big(write, "trk2_kernel")
+    if f_trk is not None:
+        with open(os.path.join(dst, "%s_pmc_trk_kernel.json" % tag), "w") as f:
+            json.dump({"kernel": "trk2_kernel", "fetch_size_raw_bytes_per_launch": f_trk,
+                       "write_size_raw_bytes_per_launch": w_trk, "correction": corr,
+                       "hbm_bytes_per_launch": 2.0 * f_trk + w_trk,
+                       "note": "the 13 series per block go straight to pinned host memory and are not HBM writes",
+                       "workload": {"channels": 8, "ms": 37000}}, f, indent=1)
+    # ---- many-channel (throughput-mode) kernel: traffic + VALU ----
+    f_tp, w_tp = big(fetch, "trk_kernel_tp"), big(write, "trk_kernel_tp")
+    valu_db = db_of(os.path.join(out, "valu"))
+    grbm_db = db_of(os.path.join(out, "grbm"))
+    if f_tp is not None and valu_db and grbm_db:
+        def biggest(db, counter, prefix):
+            d = by_kernel(per_dispatch(db, counter))
+            ks = [k for k in d if k.startswith(prefix)]
+            return max(max(d[k]) for k in ks)
+        act = biggest(valu_db, "SQ_ACTIVE_INST_VALU", "trk_kernel_tp")
+        insts = biggest(valu_db, "SQ_INSTS_VALU", "trk_kernel_tp")
+        gui = biggest(grbm_db, "GRBM_GUI_ACTIVE", "trk_kernel_tp")
+        hbm = 2.0 * f_tp + w_tp
+        samples = 2048 * 500 * 38192.0
+        # SQ_ACTIVE_INST_VALU counts quad-cycles summed over SIMDs; GRBM_GUI_ACTIVE cycles summed over the 8 XCDs
+        valu_busy = act * 4.0 / 1024.0 / (gui / 8.0)
+        json.dump({"kernel": "trk_kernel_tp", "workload": {"channels": 2048, "ms": 500},
+                   "fetch_size_raw_bytes_per_launch": f_tp, "write_size_raw_bytes_per_launch": w_tp, "correction": corr,
+                   "hbm_bytes_per_launch": hbm, "valu_busy_frac": valu_busy,
+                   "valu_insts_per_sample": insts * 64.0 / samples,
+                   "valu_formula": "SQ_ACTIVE_INST_VALU * 4 / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs); "
+                                   "SQ_INSTS_VALU * 64 lanes / (2048 channels * 500 ms * 38192 samples)",
+                   "bound": "valu"},
+                  open(os.path.join(dst, "%s_pmc_trk_tp.json" % tag), "w"), indent=1)
+    # ---- acquisition: all kernels of one call ----
+    fa = per_dispatch(db_of(os.path.join(out, "acq_fetch")), "FETCH_SIZE")
+    wa = per_dispatch(db_of(os.path.join(out, "acq_write")), "WRITE_SIZE")
+    skip = ("synth_kernel",)
+    fsum = sum(v for k, _, v in fa if not k.startswith(skip)) * 1024.0 / 3.0
+    wsum = sum(v for k, _, v in wa if not k.startswith(skip)) * 1024.0 / 3.0
+    fk = by_kernel([r for r in fa if not r[0].startswith(skip)])
+    wk = by_kernel([r for r in wa if not r[0].startswith(skip)])
+    json.dump({"workload": {"prns": 32, "blocks": 2}, "calls_profiled": 3,
+               "fetch_size_raw_bytes_per_call": fsum, "write_size_raw_bytes_per_call": wsum, "correction": corr,
+               "hbm_bytes_per_call": 2.0 * fsum + wsum,
+               "per_kernel_raw_KiB_per_call": {k.split("(")[0][:70]: {"fetch": sum(fk.get(k, [0])) / 3.0, "write": sum(wk.get(k, [0])) / 3.0}
+                                               for k in sorted(set(fk) | set(wk))}},
+              open(os.path.join(dst, "%s_pmc_acq.json" % tag), "w"), indent=1)
+    for n in sorted(os.listdir(dst)):
+        print("wrote", os.path.join(dst, n))
+
+
+if __name__ == "__main__":
+    main()
