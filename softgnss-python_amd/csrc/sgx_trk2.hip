@@ -6,16 +6,17 @@
 //
 //   roles     a workgroup has 7 waves: 4 MAP waves (256 lanes, one 16-sample group each), a PLL wave, a DLL wave and a
 //             RECORD wave.  One workgroup barrier per block hands the next block's parameters to the map waves.
-//   map       everything that needs only the block's START (its first sample and code phase, both known one block
-//             earlier) is prepared in the shadow of the previous block's exchange and loop filter: the 16 bytes are
-//             loaded and converted to fp64, and for each of the three code ramps the chip index K at the group's first
-//             sample and the switch sample c are computed exactly for the PREVIOUS block's NCO rate, with the four
-//             candidate chips read from LDS.  When the true rate arrives, three exact evaluations of the reference's
-//             ramp t(i) = fl(fl(i*step)+start) per ramp (at c-1, c and the first sample) decide between the cases
-//             "switch at c-1 / c / c+1", "first sample already in chip K+1" and "first sample still in chip K-1" -
-//             provably the only possibilities while the rate moved by less than half a sample over the block (checked
-//             per block by the DLL wave; otherwise the exact search of round 1 runs).  Chip indices are therefore still
-//             bit-identical to code[int64(ceil(linspace(...)))] (tracking.py:166-188).
+//   map       the 16 bytes of a lane are loaded and converted to fp64 one block ahead (the next block's first sample
+//             is known when the current block starts).  For each of the three code ramps the chip index at the group's
+//             first sample and the switch sample follow from ONE fused evaluation t0 = ilo*step + start and the distance
+//             to the next chip boundary in samples, u = (ceil(t0) - t0) / step: the reference's ramp
+//             t(i) = fl(fl(i*step)+start) differs from the real one by < 2.3e-13 chips, so ceil(t(i)) equals the real
+//             ramp's for every sample of the group unless a boundary lies within that distance of a sample - excluded
+//             when frac(u) is outside [1e-7, 1 - 1e-7] samples (2.7e-9 chips).  A wave in which any lane fails the test
+//             (probability ~1e-5 per block; all of block 0, whose prompt ramp starts ON a boundary) takes the exact
+//             search of round 1 (ramp_setup).  Chip indices are therefore still bit-identical to
+//             code[int64(ceil(linspace(...)))] (tracking.py:166-188); the chips themselves are two bits of a packed
+//             sign table in LDS, read while the samples are accumulated.
 //   reduce    six fp64 partials per lane -> transposing DPP reduction inside each row of 16 lanes (no LDS) -> 2^-32
 //             fixed point -> integer LDS atomics (order-independent, hence deterministic) -> the wave that arrives last
 //             publishes the member's six sums with ONE 64-bit integer atomic per sum into the channel's exchange line
@@ -77,24 +78,18 @@
 #define T2PROBE(role, k) do { } while (0)
 #endif
 
-struct __attribute__((aligned(256))) T2Code {   // code side of a block's parameters (DLL wave -> everybody), by block parity
+struct __attribute__((aligned(128))) T2Code {   // code side of a block's parameters (DLL wave -> everybody), by block parity
     // chain part: written right before the barrier that starts the block
     int blk;
     int stop;               // 1: the record ends inside this block (tracking.py:159-163); 2: a member gave up waiting;
                             // 3: the block does not fit the units of the launch
-    int fast_ok;            // the prepared switch candidates are within one sample of the true ones
-    int pad0;
-    double step[4];         // ramp steps E, P, L (tracking.py:166-188; [3] unused)
+    int pad0[2];
+    double step[3];         // ramp steps E, P, L (tracking.py:166-188)
+    double inv_step;        // 1 / codePhaseStep (distances to chip boundaries in samples)
     // early part: known one block earlier (written while the previous block is processed)
     long long pos;          // record index of the block's first sample
     long long pad1;
     double start[4];        // ramp starts E, P, L
-    // late part, about the NEXT block, written while this block is processed; valid once ready == block index + 1
-    double start_n[4];      // ramp starts of the next block (its rates are not known yet)
-    double inv_step;        // ~ 1 / codePhaseStep of this block (estimates only)
-    long long pos_next;
-    int ready;
-    int pad2[3];
 };
 
 struct T2Carr {   // carrier side (PLL wave -> map waves), double-buffered: (cos, sin)(2 pi r m), r = turns per sample
@@ -131,44 +126,31 @@ __device__ __forceinline__ long long dpp_movl(long long v) {
 // chip (as the high dword of +-1.0) of extended-code index k, k in [-1, 1026]
 __device__ __forceinline__ unsigned chip_hi(const unsigned* s_chip, int k) { return s_chip[k + 1]; }
 
-// One ramp's prepared search: exact for the rate it was prepared with.
-struct T2Ramp {
-    double Kd, Km1d;     // K and K - 1, K = chip index at the group's first sample
-    double cd, cm1d;     // c and c - 1, c = first sample whose chip index exceeds K
-    int c;
-    unsigned signs;      // bit j: chip K - 1 + j is -1 (j = 0..3)
-};
-
-__device__ __forceinline__ void ramp_prepare(const unsigned* s_chip, double start, double step, double inv_step, int ilo,
-                                             T2Ramp& R) {
-    int k1, isw;
-    ramp_setup(start, step, inv_step, ilo, k1, isw);
-    R.Kd = (double)k1;
-    R.Km1d = R.Kd - 1.0;
-    R.c = isw;
-    R.cd = (double)isw;
-    R.cm1d = R.cd - 1.0;
-    int kk = k1 < 0 ? 0 : (k1 > 1024 ? 1024 : k1);   // lanes beyond the block hold zeros: any chip will do
-    R.signs = (chip_hi(s_chip, kk - 1) >> 31) | ((chip_hi(s_chip, kk) >> 31) << 1) | ((chip_hi(s_chip, kk + 1) >> 31) << 2) |
-              ((chip_hi(s_chip, kk + 2) >> 31) << 3);
+// Sign bits of the extended code in LDS: bit k + 1 of the packed table is set where chip k is -1 (k in [-1, 1054]).
+// Two adjacent chips (k, k + 1) from one 8-byte read.
+__device__ __forceinline__ unsigned chip_bits2(const unsigned* cbits, int k) {
+    const int kk = (k < 0 ? 0 : (k > 1024 ? 1024 : k)) + 1;   // lanes beyond the block hold zeros: any chip will do
+    const unsigned lo = cbits[kk >> 5], hi = cbits[(kk >> 5) + 1];
+    const unsigned long long ww = ((unsigned long long)hi << 32) | lo;
+    return (unsigned)(ww >> (kk & 31)) & 3u;
 }
 
-// The true ramp against the prepared search: chip at the group's first sample (c1), chip after the switch (c2) and
-// the switch sample (isw, INT_MAX/2 when the group's first sample is already past it).
-__device__ __forceinline__ void ramp_resolve(const T2Ramp& R, double start, double step, double ilod, int ilo, double& c1,
-                                             double& c2, int& isw) {
-    const double Tc = R.cd * step + start;
-    const double Tm = R.cm1d * step + start;
-    const double T0 = ilod * step + start;
-    // t() is monotonic: Tm > K implies Tc > K, so the switch sample is c + 1 - [Tc > K] - [Tm > K]
-    const int cp = R.c + 1 - (int)(Tc > R.Kd) - (int)(Tm > R.Kd);
-    const bool caseB = T0 > R.Kd;          // first sample already in chip K + 1 (then cp <= ilo)
-    const bool caseC = T0 <= R.Km1d;       // first sample still in chip K - 1
-    isw = caseB ? 0x3FFFFFFF : (caseC ? ilo + 1 : cp);
-    const unsigned sh = caseB ? 2u : (caseC ? 0u : 1u);   // position of chip k1 among the four prepared ones
-    const unsigned sg = R.signs >> sh;
-    c1 = __hiloint2double((int)(0x3FF00000u | (sg << 31)), 0);
-    c2 = __hiloint2double((int)(0x3FF00000u | ((sg >> 1) << 31)), 0);
+// chip index at sample ilo (k1) and the first sample with a larger index (isw) of the ramp t(i) = i*step + start, from
+// one fused evaluation; `bad` is raised when a chip boundary lies within 1e-7 samples of a sample (then the exact
+// search decides).
+__device__ __forceinline__ void ramp_locate(double start, double step, double inv_step, double ilod, int ilo, int& k1,
+                                            int& isw, bool& bad) {
+    const double t0 = __builtin_fma(ilod, step, start);
+    const double kd = ceil(t0);
+    const double dist = kd - t0;                    // chips to the next boundary, in [0, 1)
+    const double u = dist * inv_step;               // the same in samples (real arithmetic, ~1e-12)
+    const double fu = floor(u);
+    const double fr = u - fu;
+    // no sample of the group within 1e-7 samples (2.7e-9 chips) of a boundary: the one ahead (fr) and, for the first
+    // sample, the one just behind it (dist close to 1)
+    bad = bad || !(fr > 1e-7 && fr < 1.0 - 1e-7 && dist < 1.0 - 3e-9);
+    k1 = (int)kd;
+    isw = ilo + (int)fu + 1;
 }
 
 // Carrier phasor tables of a block with rate w (rad/s), start phase rc and `head` bytes between the 16-byte boundary and
@@ -209,10 +191,9 @@ struct T2DllState {      // everything about the block being processed that the 
 };
 
 // Chain part of the next block's parameters (T1, T3): block size and ramp steps from the new code frequency; the
-// block starts at pos_n with code phase rem_n.  `prev_stp` = the lane's ramp step of the block the candidates were
-// prepared with (0 = none: block 0).  Writes N's chain part; returns the new state.
+// block starts at pos_n with code phase rem_n.  Writes N's chain part; returns the new state.
 __device__ __forceinline__ T2DllState t2_code_chain(const T2DllConst& D, double codeFreq, double rem_n, long long pos_n,
-                                                    double prev_stp, bool have_prev, bool gave_up, int P, T2Code& N, int lane) {
+                                                    bool gave_up, int P, T2Code& N, int lane) {
     const int l4 = lane & 3;
     const double off = (l4 == 0) ? -D.spacing : ((l4 == 2) ? D.spacing : 0.0);   // rem - spc == rem + (-spc) exactly
     const double step = div_rn(codeFreq, D.fs, D.inv_fs);                       // codeFreq / fs
@@ -230,12 +211,11 @@ __device__ __forceinline__ T2DllState t2_code_chain(const T2DllConst& D, double 
     double stp;
     if (__builtin_expect(known, 1)) stp = div_rn(d, nb, ynb);
     else stp = d / nb;
-    bool ok_fast = true;
-    if (have_prev) ok_fast = __all(fabs(stp - prev_stp) * (nb + 80.0) < 0.45 * step);
     if (lane < 3) N.step[lane] = stp;
     if (lane == 0) {
         const int stop = gave_up ? 2 : ((blk <= 0 || pos_n + blk > D.rec_len) ? 1 : ((blk + 15 > P * TRK_UNIT) ? 3 : 0));
-        *reinterpret_cast<int4*>(&N.blk) = make_int4(blk, stop, ok_fast ? 1 : 0, 0);
+        *reinterpret_cast<int4*>(&N.blk) = make_int4(blk, stop, 0, 0);
+        N.inv_step = sgx_fast_rcp(step);
     }
     T2DllState st;
     st.rem = rem_n;
@@ -246,10 +226,10 @@ __device__ __forceinline__ T2DllState t2_code_chain(const T2DllConst& D, double 
     return st;
 }
 
-// Late part of block `st` (T4) and early part of the block after it: code phase and first sample of the next block, its
-// ramp starts, the reciprocal step for estimates; then `ready`.  Returns (rem_next, pos_next).
-__device__ __forceinline__ void t2_code_late(const T2DllConst& D, const T2DllState& st, int it, T2Code& C, T2Code& N, int lane,
-                                             double& rem_next, long long& pos_next) {
+// Code phase and first sample of the block after `st` (T4) and that block's ramp starts (its early part): nothing here
+// needs the sums of `st`.
+__device__ __forceinline__ void t2_code_late(const T2DllConst& D, const T2DllState& st, T2Code& N, int lane, double& rem_next,
+                                             long long& pos_next) {
     const int l4 = lane & 3;
     const double off = (l4 == 0) ? -D.spacing : ((l4 == 2) ? D.spacing : 0.0);
     const double start = st.rem + off;
@@ -258,25 +238,16 @@ __device__ __forceinline__ void t2_code_late(const T2DllConst& D, const T2DllSta
     rem_next = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rn_lane), 1),
                                 __builtin_amdgcn_readlane(__double2loint(rn_lane), 1));
     pos_next = st.pos + st.blk;
-    if (lane < 3) {
-        C.start_n[lane] = rem_next + off;
-        N.start[lane] = rem_next + off;
-    }
-    if (lane == 0) {
-        const double r0 = __builtin_amdgcn_rcp(st.step);
-        C.inv_step = __builtin_fma(r0, __builtin_fma(-st.step, r0, 1.0), r0);
-        C.pos_next = pos_next;
-        N.pos = pos_next;
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the stores above are in LDS before the flag
-    if (lane == 0) *(volatile int*)&C.ready = it + 1;
+    if (lane < 3) N.start[lane] = rem_next + off;
+    if (lane == 0) N.pos = pos_next;
 }
 
 #define T2_PIN(x) asm volatile("" : "+v"(x))
 
 // Everything a role needs that lives in LDS.
 struct T2Shared {
-    unsigned chip[1032];            // chip[k + 1] = chip of extended-code index k (tracking.py:111)
+    unsigned chip[1032];            // chip[k + 1] = chip of extended-code index k (tracking.py:111), exact-search path
+    unsigned cbits[40];             // the same as packed sign bits: bit k + 1 set where chip k is -1
     T2Code code[2];
     T2Carr carr[2];
     double part[2][16][8];          // row sums of the map waves by block parity: [wave * 4 + row][word]
@@ -325,41 +296,30 @@ __device__ __forceinline__ int t2_map_role(T2Shared& S, const int8_t* __restrict
     const long long lane_off = (long long)g * 16;
     T2_FP_DECL
     (void)prof_on;
-    // state prepared one block ahead
+    // state prepared one block ahead: the lane's 16 samples as fp64 and where they sit in the block
     double xd[16];
-    T2Ramp RE, RP, RL;
     int i0, ilo;
     double ilod;
     uint4 raw;
 
-#define T2_PREPARE(POS_NEXT, STARTS, STEP_E, STEP_P, STEP_L, INV_STEP)                                         \
+#define T2_PREPARE(POS_NEXT)                                                                                   \
     do {                                                                                                       \
         const int head_ = (int)((POS_NEXT) & 15);                                                              \
         i0 = g * 16 - head_;                                                                                   \
         ilo = i0 < 0 ? 0 : i0;                                                                                 \
         ilod = (double)ilo;                                                                                    \
         t2_convert(raw, i0, xd);                                                                               \
-        ramp_prepare(S.chip, (STARTS)[0], STEP_E, INV_STEP, ilo, RE);                                          \
-        ramp_prepare(S.chip, (STARTS)[1], STEP_P, INV_STEP, ilo, RP);                                          \
-        ramp_prepare(S.chip, (STARTS)[2], STEP_L, INV_STEP, ilo, RL);                                          \
     } while (0)
 
-    {
-        // block 0: prepared with its own (true) parameters
-        raw = load_group(rec, (pos0 & ~15ll) + lane_off, limit);
-        const T2Code& C0 = S.code[0];
-        const double s0 = C0.step[1];
-        const double r0 = __builtin_amdgcn_rcp(s0);
-        const double inv0 = __builtin_fma(r0, __builtin_fma(-s0, r0, 1.0), r0);
-        T2_PREPARE(C0.pos, C0.start, C0.step[0], C0.step[1], C0.step[2], inv0);
-    }
+    raw = load_group(rec, (pos0 & ~15ll) + lane_off, limit);
+    T2_PREPARE(pos0);
     int it = 0;
     for (; it < ms; ++it) {
         const int par = it & 1;
         const T2Code& C = S.code[par];
         // one batch of LDS reads: chain part, early part, the lane's carrier phasors
-        const int4 hd = *reinterpret_cast<const int4*>(&C.blk);      // blk, stop, fast_ok
-        const double stepE = C.step[0], stepP = C.step[1], stepL = C.step[2];
+        const int4 hd = *reinterpret_cast<const int4*>(&C.blk);      // blk, stop
+        const double stepE = C.step[0], stepP = C.step[1], stepL = C.step[2], inv_step = C.inv_step;
         const double startE = C.start[0], startP = C.start[1], startL = C.start[2];
         const long long pos = C.pos;
         const T2Carr& CR = S.carr[par];
@@ -371,30 +331,19 @@ __device__ __forceinline__ int t2_map_role(T2Shared& S, const int8_t* __restrict
         const long long pos_next = pos + blk;
         const uint4 nraw = load_group(rec, (pos_next & ~15ll) + lane_off, limit);   // next block's bytes
         T2PROBE(prof_on, 0);   // parameters read, next block's load issued
-        double cE1, cE2, cP1, cP2, cL1, cL2;
-        int swE, swP, swL;
-        if (__builtin_expect(hd.z, 1)) {
-            ramp_resolve(RE, startE, stepE, ilod, ilo, cE1, cE2, swE);
-            ramp_resolve(RP, startP, stepP, ilod, ilo, cP1, cP2, swP);
-            ramp_resolve(RL, startL, stepL, ilod, ilo, cL1, cL2, swL);
-        } else {
-            // the rate moved too far for the prepared candidates: exact search (round-1 path)
-            const double r0 = __builtin_amdgcn_rcp(stepP);
-            const double inv_step = __builtin_fma(r0, __builtin_fma(-stepP, r0, 1.0), r0);
-            int kE, kP, kL;
+        int kE, kP, kL, swE, swP, swL;
+        bool bad = false;
+        ramp_locate(startE, stepE, inv_step, ilod, ilo, kE, swE, bad);
+        ramp_locate(startP, stepP, inv_step, ilod, ilo, kP, swP, bad);
+        ramp_locate(startL, stepL, inv_step, ilod, ilo, kL, swL, bad);
+        if (__builtin_expect(__any(bad && i0 < blk), 0)) {
+            // a chip boundary within 1e-7 samples of a sample somewhere in this wave: exact search (round-1 path)
             ramp_setup(startE, stepE, inv_step, ilo, kE, swE);
             ramp_setup(startP, stepP, inv_step, ilo, kP, swP);
             ramp_setup(startL, stepL, inv_step, ilo, kL, swL);
-            kE = kE < 0 ? 0 : (kE > 1024 ? 1024 : kE);
-            kP = kP < 0 ? 0 : (kP > 1024 ? 1024 : kP);
-            kL = kL < 0 ? 0 : (kL > 1024 ? 1024 : kL);
-            cE1 = __hiloint2double((int)chip_hi(S.chip, kE), 0);
-            cE2 = __hiloint2double((int)chip_hi(S.chip, kE + 1), 0);
-            cP1 = __hiloint2double((int)chip_hi(S.chip, kP), 0);
-            cP2 = __hiloint2double((int)chip_hi(S.chip, kP + 1), 0);
-            cL1 = __hiloint2double((int)chip_hi(S.chip, kL), 0);
-            cL2 = __hiloint2double((int)chip_hi(S.chip, kL + 1), 0);
         }
+        // chips k1 and k1 + 1 of every ramp (two sign bits each); they are needed only after the accumulation
+        const unsigned bE = chip_bits2(S.cbits, kE), bP = chip_bits2(S.cbits, kP), bL = chip_bits2(S.cbits, kL);
         // group-start phasor G = W1[tid & 15] * W2[(tid >> 4) & 15] * W3; a group that lies entirely beyond the block
         // (its samples belong to the next one) gets a zero phasor, i.e. adds nothing
         double gc, gs;
@@ -412,7 +361,10 @@ __device__ __forceinline__ int t2_map_role(T2Shared& S, const int8_t* __restrict
 #pragma unroll
             for (int b = 0; b < 16; ++b) xd[b] = (i0 + b < blk) ? xd[b] : 0.0;
         }
-        T2PROBE(prof_on, 1);   // switch samples and chips resolved
+        T2PROBE(prof_on, 1);   // switch samples resolved
+        const double cE1 = __hiloint2double((int)(0x3FF00000u | (bE << 31)), 0), cE2 = __hiloint2double((int)(0x3FF00000u | ((bE >> 1) << 31)), 0);
+        const double cP1 = __hiloint2double((int)(0x3FF00000u | (bP << 31)), 0), cP2 = __hiloint2double((int)(0x3FF00000u | ((bP >> 1) << 31)), 0);
+        const double cL1 = __hiloint2double((int)(0x3FF00000u | (bL << 31)), 0), cL2 = __hiloint2double((int)(0x3FF00000u | ((bL >> 1) << 31)), 0);
         double aIE, aQE, aIP, aQP, aIL, aQL;
         const int iend = i0 + 16;
         int swmin = swE < swP ? swE : swP;
@@ -522,8 +474,7 @@ __device__ __forceinline__ int t2_map_role(T2Shared& S, const int8_t* __restrict
         // ---- shadow: prepare the next block with this block's rates ----
         __builtin_amdgcn_s_setprio(0);
         raw = nraw;
-        while (*(volatile int*)&C.ready != it + 1) __builtin_amdgcn_s_sleep(1);   // (the late part was posted long ago)
-        T2_PREPARE(pos_next, C.start_n, stepE, stepP, stepL, C.inv_step);
+        T2_PREPARE(pos_next);
         T2STAMP(prof_on, 6);   // next block prepared
         wg_barrier();
         T2STAMP(prof_on, 7);   // waiting for the loop filter
@@ -714,7 +665,7 @@ __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const
         // late part of this block and early part of the next (nothing here needs the sums)
         double rem_next;
         long long pos_next;
-        t2_code_late(D, st, it, C, S.code[par ^ 1], lane, rem_next, pos_next);
+        t2_code_late(D, st, S.code[par ^ 1], lane, rem_next, pos_next);
         __builtin_amdgcn_s_setprio(3);
         const unsigned long long* gp = xbase + T2_XG + par * 96 + 32 + lane;
         const unsigned long long tag = (unsigned long long)((unsigned)(it + 1) & 0xFFFFu);
@@ -761,7 +712,7 @@ __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const
         oldCodeErr = codeError;
         T2PROBE(prof_on, 13);  // discriminator + NCO
         // T1, T3: block size and ramp steps of the next block
-        const T2DllState nx = t2_code_chain(D, cf_new, rem_next, pos_next, st.stp, true, gave_up, P, S.code[par ^ 1], lane);
+        const T2DllState nx = t2_code_chain(D, cf_new, rem_next, pos_next, gave_up, P, S.code[par ^ 1], lane);
         if (lane == 0 && nx.blk + 15 > P * TRK_UNIT && !gave_up) atomicExch(err, TRK_ERR_RANGE | (1 + ch));
         st = nx;
         r_v = v;
@@ -844,7 +795,6 @@ __global__ __launch_bounds__(T2_THREADS) void trk2_kernel(const int8_t* __restri
         S.rflag[tid] = 0;
         S.ticket[tid >> 1][tid & 1] = 0;
     }
-    if (tid < 2) S.code[tid].ready = 0;
     __syncthreads();
     if (wave == 4) {
         unsigned long long* pl = xbase + T2_XPLACE;
@@ -879,6 +829,15 @@ __global__ __launch_bounds__(T2_THREADS) void trk2_kernel(const int8_t* __restri
         S.chip[i] = (codes[(cc.prn - 1) * 1023 + j] > 0) ? 0x3FF00000u : 0xBFF00000u;
     }
     __syncthreads();
+    if (tid < 40) {
+        unsigned w = 0;
+        for (int bb = 0; bb < 32; ++bb) {
+            const int i = tid * 32 + bb;
+            if (i < 1032 && (S.chip[i] >> 31)) w |= 1u << bb;
+        }
+        S.cbits[tid] = w;
+    }
+    __syncthreads();
     const bool fast = S.flag[0] != 0;
     const bool dead = S.flag[1] != 0;
 
@@ -898,7 +857,7 @@ __global__ __launch_bounds__(T2_THREADS) void trk2_kernel(const int8_t* __restri
         D.inv_nb_lane = 1.0 / (double)(K.nb_base + (lane & 7));
         D.nb_base = K.nb_base;
         D.rec_len = K.rec_len;
-        st0 = t2_code_chain(D, K.code_basis, 0.0, cc.pos0, 0.0, false, false, P, S.code[0], lane);
+        st0 = t2_code_chain(D, K.code_basis, 0.0, cc.pos0, false, P, S.code[0], lane);
         const double off = ((lane & 3) == 0) ? -K.spacing : (((lane & 3) == 2) ? K.spacing : 0.0);
         if (lane < 3) S.code[0].start[lane] = 0.0 + off;
         if (lane == 0) {
