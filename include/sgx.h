@@ -256,6 +256,10 @@ int sgx_find_utm_zone(double latitude, double longitude, int32_t* utmZone);     
 int sgx_cart2utm(double X, double Y, double Z, int32_t zone, double* E, double* N, double* U);      /* :176-372 */
 
 /* ---- RCCL peak gather (multi-GPU acquisition shard) ------------------
+ * (SURVEY.md section 8(b) sketched single-process sgx_group_* entry points - one host thread driving every device
+ * through ncclCommInitAll.  The build runs ONE PROCESS PER GPU instead, as the bench contract launches it, so the
+ * collective side of the boundary is a per-rank communicator; sharding itself is a loop over PRN / channel index
+ * ranges on the caller's side: softgnss-python_amd/shard.py.)
  * One process per GPU.  Rank 0 calls sgx_comm_unique_id and ships the 128 bytes to the other
  * ranks by any host channel; every rank then calls sgx_comm_create.  sgx_comm_allgather
  * all-gathers `bytes` bytes per rank (host buffers, staged through HBM, ncclAllGather on the
