@@ -598,7 +598,7 @@ static int acquire_fine(sgx_ctx* c, const int8_t* x, size_t n_samples, const std
     int* d_detprn = (int*)(dsm + 1024 + 12 * 4096 + 512);
     int* d_detph = d_detprn + 32;
     double* d_pv = (double*)(dsm + 65536);
-    long long* d_pi = (long long*)(dsm + 65536 + 8 * 32 * 256);
+    long long* d_pi = nullptr;
     int rc = SGX_OK;
     const int n_det = (int)det_prn.size();
     if (n_det > 0) {
@@ -620,24 +620,39 @@ static int acquire_fine(sgx_ctx* c, const int8_t* x, size_t n_samples, const std
             return rc;
         if ((rc = ensure_buf((void**)&c->d_fine[1], &c->cap_f1, (size_t)n_rows * sizeof(cplx) * (size_t)npts)) != SGX_OK)
             return rc;
-        long long h_sum = 0;
-        SGX_HIP(hipMemcpyAsync(&h_sum, d_sum, 8, hipMemcpyDeviceToHost, st));
         SGX_HIP(hipMemcpyAsync(d_detprn, det_prn.data(), sizeof(int) * (size_t)n_det, hipMemcpyHostToDevice, st));
         SGX_HIP(hipMemcpyAsync(d_detph, det_phase.data(), sizeof(int) * (size_t)n_det, hipMemcpyHostToDevice, st));
-        SGX_HIP(hipStreamSynchronize(st));
-        const double mean = (double)h_sum / (double)n_samples;   // longSignal.mean(), acquisition.py:59
         const double tc1 = 1.0 / S.codeFreqBasis;
-        dim3 grid((unsigned)((len + 255) / 256), (unsigned)n_rows);
-        acq_fine_prep_kernel<<<grid, 256, 0, st>>>(x, c->d_codes, c->d_fine[0], len, npts, mean, ts, tc1, d_detprn,
-                                                   d_detph, n_det);
-        cplx* res = nullptr;
-        rc = sgx_fft_forward(&c->plan_fine, c->d_fine[0], c->d_fine[1], n_rows, st, &res, len);
-        if (rc != SGX_OK) return rc;
-        const int nblk = 256;
-        dim3 g2((unsigned)nblk, (unsigned)n_det);
-        acq_fine_argmax_kernel<<<g2, 256, 0, st>>>(res, npts, 4, uniq - 5, d_pv, d_pi);
+        const char* fv1 = getenv("SGX_ACQ_FINE_V1");
+        const bool fine2 = sgx_fft_fine_supported(npts) && !(fv1 && fv1[0] == '1');
+        double mean = 0.0;
+        if (!fine2) {
+            long long h_sum = 0;
+            SGX_HIP(hipMemcpyAsync(&h_sum, d_sum, 8, hipMemcpyDeviceToHost, st));
+            SGX_HIP(hipStreamSynchronize(st));
+            mean = (double)h_sum / (double)n_samples;   // longSignal.mean(), acquisition.py:59
+        }
+        int nblk = 256;
         double* h_pv = (double*)(hsm + 65536);
-        long long* h_pi = (long long*)(hsm + 65536 + 8 * 32 * 256);
+        long long* h_pi = (long long*)(hsm + 400000);   // (behind the row-map area at 200000)
+        d_pi = (long long*)(dsm + 400000);
+        if (fine2) {
+            // two kernels with LDS-resident sub-transforms, input built on the fly (the mean comes from the device-side
+            // sum: no host look), arg-max fused (sgx_fft.hip)
+            nblk = sgx_fft_fine_partials();
+            rc = sgx_fft_fine_search(&c->plan_fine, x, c->d_codes, d_detprn, d_detph, n_det, len, d_sum, (double)n_samples, ts,
+                                     tc1, c->d_fine[0], 4, uniq - 5, d_pv, d_pi, st);
+            if (rc != SGX_OK) return rc;
+        } else {
+            dim3 grid((unsigned)((len + 255) / 256), (unsigned)n_rows);
+            acq_fine_prep_kernel<<<grid, 256, 0, st>>>(x, c->d_codes, c->d_fine[0], len, npts, mean, ts, tc1, d_detprn,
+                                                       d_detph, n_det);
+            cplx* res = nullptr;
+            rc = sgx_fft_forward(&c->plan_fine, c->d_fine[0], c->d_fine[1], n_rows, st, &res, len);
+            if (rc != SGX_OK) return rc;
+            dim3 g2((unsigned)nblk, (unsigned)n_det);
+            acq_fine_argmax_kernel<<<g2, 256, 0, st>>>(res, npts, 4, uniq - 5, d_pv, d_pi);
+        }
         SGX_HIP(hipMemcpyAsync(h_pv, d_pv, sizeof(double) * (size_t)n_det * nblk, hipMemcpyDeviceToHost, st));
         SGX_HIP(hipMemcpyAsync(h_pi, d_pi, sizeof(long long) * (size_t)n_det * nblk, hipMemcpyDeviceToHost, st));
         hipEventRecord(c->ev[2], st);
@@ -788,9 +803,9 @@ static int acquire_four_step(sgx_ctx* c, const sgx_if* r, size_t offset, size_t 
     const int rows_fwd = n_blocks * n_phi;
     const int rows_per_prn = n_blocks * n_bins;
     SGX_CHECK_ARG(rows_per_prn <= ACQ_MAX_ROWS);
-    // PRN chunks small enough for the intermediate (written by the columns kernel, read back by the rows kernel) to
-    // stay in the 256 MiB Infinity Cache: ~230 rows of 611 KB
-    int chunk_rows = 232;
+    // PRN chunks: measured (tools/acq_chunk_probe.py), keeping a chunk's intermediate inside the 256 MiB Infinity Cache
+    // (~230 rows) buys nothing and costs launches; chunks are as large as the row limit allows
+    int chunk_rows = ACQ_MAX_ROWS;
     {
         const char* ce = getenv("SGX_ACQ_CHUNK_ROWS");
         if (ce && atoi(ce) > 0) chunk_rows = atoi(ce);

@@ -504,11 +504,22 @@ __device__ __forceinline__ cplx f4_twiddle(const F4Args& a, long long t) {
     return cmul(h, l);
 }
 
+// Sub-transform twiddles W_L^t in LDS: one table, or (long transforms) a product of two small ones.
+struct TwDirect {
+    const cplx* t;
+    __device__ __forceinline__ cplx operator[](int i) const { return t[i]; }
+};
+struct TwTwoLevel {   // W_L^t = hi[t >> 6] * lo[t & 63]
+    const cplx* hi;
+    const cplx* lo;
+    __device__ __forceinline__ cplx operator[](int i) const { return cmul(hi[i >> 6], lo[i & 63]); }
+};
+
 // One Stockham radix-R pass over C sequences of length L in LDS; element n of sequence c lives at buf[n * SN + c * SC].
 // CFAST: consecutive threads take consecutive sequences (use when SC == 1), else consecutive butterflies.
-// twl = W_L^t, t < L, in LDS (needed when NS > 1).
-template <int L, int R, int NS, int C, int SN, int SC, int TPB, bool CFAST>
-__device__ __forceinline__ void lds_radix_pass(cplx* __restrict__ buf, const cplx* __restrict__ twl,
+// twl[t] = W_L^t, t < L (needed when NS > 1).
+template <int L, int R, int NS, int C, int SN, int SC, int TPB, bool CFAST, class TW>
+__device__ __forceinline__ void lds_radix_pass(cplx* __restrict__ buf, const TW twl,
                                                const cplx* __restrict__ wr, int tid) {
     constexpr int M = L / R;
     constexpr int TOTAL = M * C;
@@ -589,8 +600,8 @@ __device__ __forceinline__ void dft_odd_part(const cplx (&a)[(R - 1) / 2], const
     }
 }
 
-template <int L, int R, int NS, int C, int SN, int SC, int TPB, bool CFAST, int PARTS>
-__device__ __forceinline__ void lds_odd_pass_split(cplx* __restrict__ buf, const cplx* __restrict__ twl,
+template <int L, int R, int NS, int C, int SN, int SC, int TPB, bool CFAST, int PARTS, class TW>
+__device__ __forceinline__ void lds_odd_pass_split(cplx* __restrict__ buf, const TW twl,
                                                    const cplx* __restrict__ wr, int tid) {
     static_assert(PARTS == 4, "instantiated for four parts");
     constexpr int M = L / R, H = (R - 1) / 2;
@@ -684,9 +695,10 @@ __global__ __launch_bounds__(TPB) void fft4_cols_kernel(F4Args a) {
     }
     __syncthreads();
     // R3 = 4: the second radix is a large odd one whose butterflies are split over four waves each
-    lds_radix_pass<N1, R1, 1, C, C, 1, TPB, true>(buf, twl, a.wr[0], tid);
-    if constexpr (R3 == 4) lds_odd_pass_split<N1, R2, R1, C, C, 1, TPB, true, 4>(buf, twl, a.wr[1], tid);
-    else lds_radix_pass<N1, R2, R1, C, C, 1, TPB, true>(buf, twl, a.wr[1], tid);
+    const TwDirect tw{twl};
+    lds_radix_pass<N1, R1, 1, C, C, 1, TPB, true>(buf, tw, a.wr[0], tid);
+    if constexpr (R3 == 4) lds_odd_pass_split<N1, R2, R1, C, C, 1, TPB, true, 4>(buf, tw, a.wr[1], tid);
+    else lds_radix_pass<N1, R2, R1, C, C, 1, TPB, true>(buf, tw, a.wr[1], tid);
     cplx* __restrict__ out = a.out + row * a.n;
     for (int e = tid; e < N1 * C; e += TPB) {
         const int k1 = e / C, c = e % C;
@@ -717,9 +729,10 @@ __global__ __launch_bounds__(TPB) void fft4_rows_kernel(F4Args a) {
         if (b > 0) __syncthreads();
         for (int e = tid; e < E; e += TPB) buf[e] = in[e];
         __syncthreads();
-        lds_radix_pass<N2, R1, 1, CB, 1, N2, TPB, false>(buf, twl, a.wr[0], tid);
-        if constexpr (R3 == 4) lds_odd_pass_split<N2, R2, R1, CB, 1, N2, TPB, false, 4>(buf, twl, a.wr[1], tid);
-        else lds_radix_pass<N2, R2, R1, CB, 1, N2, TPB, false>(buf, twl, a.wr[1], tid);
+        const TwDirect tw{twl};
+        lds_radix_pass<N2, R1, 1, CB, 1, N2, TPB, false>(buf, tw, a.wr[0], tid);
+        if constexpr (R3 == 4) lds_odd_pass_split<N2, R2, R1, CB, 1, N2, TPB, false, 4>(buf, tw, a.wr[1], tid);
+        else lds_radix_pass<N2, R2, R1, CB, 1, N2, TPB, false>(buf, tw, a.wr[1], tid);
         if (MODE == 0) {
             cplx* __restrict__ out = a.out + row * a.n;
             for (int e = tid; e < E; e += TPB) {
@@ -906,6 +919,252 @@ int sgx_fft4_forward(const FftPlan* p, const cplx* in, cplx* work, cplx* out, in
     } else {
         f4_launch_rows<0>(a, rows, st);
     }
+    SGX_HIP(hipGetLastError());
+    return SGX_OK;
+}
+
+
+// =====================================================================================================================
+// Fine-frequency search on a two-kernel 2^22-point transform (acquisition.py:170-191): M = 1024 x 4096.
+//   columns kernel   builds its input on the fly - two detected PRNs per complex row, (x - mean) * code(floor(ts k / tc))
+//                    of the first in the real part, of the second in the imaginary part (acquisition.py:172-177), zeros
+//                    beyond 10 ms - for 8 adjacent columns, runs their 1024-point transforms in LDS (radix 16, 16, 4),
+//                    multiplies by W_M^(n2 k1) and stores element (k1, n2);
+//   rows kernel      takes rows k1 and 1024 - k1 together (row 0 and row 512 alone), runs their 4096-point transforms in
+//                    LDS (radix 16 x 3) and, without storing the spectrum, separates the two real signals
+//                    X_a[k] = (Z[k] + conj(Z[M-k]))/2, X_b[k] = (Z[k] - conj(Z[M-k]))/(2i) - Z[M-k] of row k1 lives in
+//                    row 1024 - k1 - and reduces |X|^2 over k in [4, M/2 - 4) to one (max, first index) per workgroup
+//                    and detection (acquisition.py:182-187).  The spectrum crosses HBM once each way.
+#define FF_N1 1024
+#define FF_N2 4096
+#define FF_C 8
+#define FF_TPB 512
+
+struct FineArgs {
+    const int8_t* x;
+    const int8_t* codes;      // [32][1023]
+    const int* det_prn;
+    const int* det_phase;
+    int n_det;
+    long long len;            // 10 N samples of signal, zeros beyond
+    const long long* d_sum;   // integer sum of the record window; mean = sum / n_mean (acquisition.py:59)
+    double n_mean, ts, tc1;
+    cplx* work;               // [rows][M] intermediate
+    const cplx* tw_hi;        // two-level table of W_M
+    const cplx* tw_lo;
+    int lo_bits;
+    const cplx* wr16;
+    const cplx* wr4;
+    const cplx* tw_n1;        // W_1024^t
+    const cplx* tw_n2_hi;     // W_4096^(64 h), h < 64
+    const cplx* tw_n2_lo;     // W_4096^l, l < 64
+    long long lo, hi;         // arg-max range [lo, hi)
+    double* pv;               // [n_det][FF_N1 / 2 + 1] per-workgroup maxima
+    long long* pi;
+};
+
+__global__ __launch_bounds__(FF_TPB) void fine_cols_kernel(FineArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char f4_smem[];
+    cplx* __restrict__ buf = reinterpret_cast<cplx*>(f4_smem);   // [FF_N1][FF_C]
+    cplx* __restrict__ twl = buf + FF_N1 * FF_C;                 // [FF_N1]
+    const int tid = threadIdx.x;
+    lds_fill_twiddles<FF_N1, FF_TPB>(twl, a.tw_n1, tid);
+    const int c0 = blockIdx.x * FF_C;
+    const int r = blockIdx.y;
+    const int d0 = 2 * r, d1 = 2 * r + 1;
+    const int8_t* __restrict__ xa = a.x + a.det_phase[d0];
+    const int8_t* __restrict__ ca = a.codes + a.det_prn[d0] * 1023;
+    const bool two = d1 < a.n_det;
+    const int8_t* __restrict__ xb = two ? a.x + a.det_phase[d1] : xa;
+    const int8_t* __restrict__ cb = two ? a.codes + a.det_prn[d1] * 1023 : ca;
+    const double mean = (double)a.d_sum[0] / a.n_mean;
+    for (int e = tid; e < FF_N1 * FF_C; e += FF_TPB) {
+        const int n1 = e / FF_C, c = e % FF_C;
+        const long long i = (long long)n1 * FF_N2 + c0 + c;
+        cplx val = make_double2(0.0, 0.0);
+        if (i < a.len) {
+            const double v = floor((a.ts * (double)(i + 1)) / a.tc1);       // acquisition.py:172 (A9)
+            const int chip = (int)((long long)v % 1023);
+            const double va = ((double)xa[i] - mean) * (double)ca[chip];
+            const double vb = two ? ((double)xb[i] - mean) * (double)cb[chip] : 0.0;
+            val = make_double2(va, vb);
+        }
+        buf[e] = val;
+    }
+    __syncthreads();
+    const TwDirect tw{twl};
+    lds_radix_pass<FF_N1, 16, 1, FF_C, FF_C, 1, FF_TPB, true>(buf, tw, a.wr16, tid);
+    lds_radix_pass<FF_N1, 16, 16, FF_C, FF_C, 1, FF_TPB, true>(buf, tw, a.wr16, tid);
+    lds_radix_pass<FF_N1, 4, 256, FF_C, FF_C, 1, FF_TPB, true>(buf, tw, a.wr4, tid);
+    cplx* __restrict__ out = a.work + (long long)r * FF_N1 * FF_N2;
+    for (int e = tid; e < FF_N1 * FF_C; e += FF_TPB) {
+        const int k1 = e / FF_C, c = e % FF_C;
+        const long long t = (long long)(c0 + c) * k1;   // < M
+        const cplx h = a.tw_hi[t >> a.lo_bits];
+        const cplx l = a.tw_lo[t & ((1ll << a.lo_bits) - 1)];
+        out[(long long)k1 * FF_N2 + c0 + c] = cmul(buf[e], cmul(h, l));
+    }
+}
+
+__global__ __launch_bounds__(FF_TPB) void fine_rows_kernel(FineArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char f4_smem[];
+    cplx* __restrict__ buf = reinterpret_cast<cplx*>(f4_smem);   // [2][FF_N2]
+    cplx* __restrict__ thi = buf + 2 * FF_N2;                    // [64]
+    cplx* __restrict__ tlo = thi + 64;                           // [64]
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        thi[tid] = a.tw_n2_hi[tid];
+        tlo[tid] = a.tw_n2_lo[tid];
+    }
+    const int bx = blockIdx.x;                 // 0: row 0 alone; FF_N1 / 2: row 512 alone; else rows bx and FF_N1 - bx
+    const int r = blockIdx.y;
+    const bool single = (bx == 0 || bx == FF_N1 / 2);
+    const int rowA = bx, rowB = single ? bx : FF_N1 - bx;
+    const cplx* __restrict__ in = a.work + (long long)r * FF_N1 * FF_N2;
+    for (int e = tid; e < FF_N2; e += FF_TPB) {
+        buf[e] = in[(long long)rowA * FF_N2 + e];
+        buf[FF_N2 + e] = in[(long long)rowB * FF_N2 + e];    // (a single row is simply transformed twice)
+    }
+    __syncthreads();
+    const TwTwoLevel tw{thi, tlo};
+    lds_radix_pass<FF_N2, 16, 1, 2, 1, FF_N2, FF_TPB, false>(buf, tw, a.wr16, tid);
+    lds_radix_pass<FF_N2, 16, 16, 2, 1, FF_N2, FF_TPB, false>(buf, tw, a.wr16, tid);
+    lds_radix_pass<FF_N2, 16, 256, 2, 1, FF_N2, FF_TPB, false>(buf, tw, a.wr16, tid);
+    // Z[k1 + 1024 k2] = row k1, element k2;  Z[M - k] = row (1024 - k1) mod 1024, element 4095 - k2 (k1 > 0) or
+    // 4096 - k2 (k1 = 0, k2 > 0)
+    double best[2] = {-1.0, -1.0};
+    long long arg[2] = {a.lo, a.lo};
+    const int nrow = single ? 1 : 2;
+    for (int rr = 0; rr < nrow; ++rr) {
+        const int k1 = rr == 0 ? rowA : rowB;
+        const cplx* __restrict__ me = buf + rr * FF_N2;
+        const cplx* __restrict__ other = buf + (single ? 0 : (1 - rr)) * FF_N2;
+        for (int k2 = tid; k2 < FF_N2; k2 += FF_TPB) {
+            const long long k = (long long)k1 + (long long)FF_N1 * k2;
+            if (k < a.lo || k >= a.hi) continue;
+            const int ko = (k1 == 0) ? FF_N2 - k2 : FF_N2 - 1 - k2;     // k >= 4 excludes k1 = 0, k2 = 0
+            const cplx z = me[k2];
+            const cplx w = other[ko];
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const double sgn = d ? -1.0 : 1.0;
+                const double re = z.x + sgn * w.x, im = z.y - sgn * w.y;   // z +- conj(w)
+                const double v = re * re + im * im;
+                if (v > best[d] || (v == best[d] && k < arg[d])) {
+                    best[d] = v;
+                    arg[d] = k;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    double* s_v = reinterpret_cast<double*>(f4_smem);
+    long long* s_i = reinterpret_cast<long long*>(f4_smem + sizeof(double) * FF_TPB);
+    for (int d = 0; d < 2; ++d) {
+        const int det = 2 * r + d;
+        if (det >= a.n_det) break;
+        s_v[tid] = best[d];
+        s_i[tid] = arg[d];
+        __syncthreads();
+        for (int st = FF_TPB / 2; st > 0; st >>= 1) {
+            if (tid < st) {
+                const double ov = s_v[tid + st];
+                const long long oi = s_i[tid + st];
+                if (ov > s_v[tid] || (ov == s_v[tid] && oi < s_i[tid])) {
+                    s_v[tid] = ov;
+                    s_i[tid] = oi;
+                }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            a.pv[(long long)det * gridDim.x + bx] = s_v[0];
+            a.pi[(long long)det * gridDim.x + bx] = s_i[0];
+        }
+        __syncthreads();
+    }
+}
+
+static cplx* g_ff_tab[SGX_MAX_DEVICES][3] = {{nullptr, nullptr, nullptr}};   // W_1024^t | W_4096^(64 h) | W_4096^l
+
+bool sgx_fft_fine_supported(int64_t npts) { return npts == (int64_t)FF_N1 * FF_N2; }
+int sgx_fft_fine_partials(void) { return FF_N1 / 2 + 1; }
+
+// Fine search of n_det detections (two per complex row) on the 2^22-point two-kernel transform.  `plan` = the 2^22
+// plan (its two-level table of W_M is used for the inter-step twiddles).  Fills pv / pi [n_det][sgx_fft_fine_partials()].
+int sgx_fft_fine_search(const FftPlan* plan, const int8_t* x, const int8_t* codes, const int* d_det_prn,
+                        const int* d_det_phase, int n_det, long long len, const long long* d_sum, double n_mean, double ts,
+                        double tc1, cplx* work, long long lo, long long hi, double* pv, long long* pi, hipStream_t st) {
+    if (!plan->tw_hi || !sgx_fft_fine_supported(plan->n) || n_det < 1) {
+        sgx_set_error("sgx_fft_fine_search: %lld points not supported", (long long)plan->n);
+        return SGX_E_ARG;
+    }
+    int dev = 0;
+    SGX_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= SGX_MAX_DEVICES) return SGX_E_ARG;
+    for (int r : {16, 4}) {
+        const int rc = ensure_roots(r);
+        if (rc != SGX_OK) return rc;
+    }
+    {
+        std::lock_guard<std::mutex> hold(g_wr_lock);
+        if (!g_ff_tab[dev][0]) {
+            const long double twopi = 2.0L * 3.14159265358979323846264338327950288L;
+            std::vector<cplx> t1(FF_N1), th(64), tl(64);
+            for (int t = 0; t < FF_N1; ++t) {
+                const long double ang = -twopi * (long double)t / (long double)FF_N1;
+                t1[(size_t)t] = make_double2((double)cosl(ang), (double)sinl(ang));
+            }
+            for (int t = 0; t < 64; ++t) {
+                const long double ah = -twopi * (long double)(64 * t) / (long double)FF_N2;
+                const long double al = -twopi * (long double)t / (long double)FF_N2;
+                th[(size_t)t] = make_double2((double)cosl(ah), (double)sinl(ah));
+                tl[(size_t)t] = make_double2((double)cosl(al), (double)sinl(al));
+            }
+            SGX_HIP(hipMalloc((void**)&g_ff_tab[dev][0], sizeof(cplx) * FF_N1));
+            SGX_HIP(hipMalloc((void**)&g_ff_tab[dev][1], sizeof(cplx) * 64));
+            SGX_HIP(hipMalloc((void**)&g_ff_tab[dev][2], sizeof(cplx) * 64));
+            SGX_HIP(hipMemcpy(g_ff_tab[dev][0], t1.data(), sizeof(cplx) * FF_N1, hipMemcpyHostToDevice));
+            SGX_HIP(hipMemcpy(g_ff_tab[dev][1], th.data(), sizeof(cplx) * 64, hipMemcpyHostToDevice));
+            SGX_HIP(hipMemcpy(g_ff_tab[dev][2], tl.data(), sizeof(cplx) * 64, hipMemcpyHostToDevice));
+        }
+    }
+    FineArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x;
+    a.codes = codes;
+    a.det_prn = d_det_prn;
+    a.det_phase = d_det_phase;
+    a.n_det = n_det;
+    a.len = len;
+    a.d_sum = d_sum;
+    a.n_mean = n_mean;
+    a.ts = ts;
+    a.tc1 = tc1;
+    a.work = work;
+    a.tw_hi = plan->tw_hi;
+    a.tw_lo = plan->tw_lo;
+    a.lo_bits = plan->lo_bits;
+    a.wr16 = g_wr[dev][16];
+    a.wr4 = g_wr[dev][4];
+    a.tw_n1 = g_ff_tab[dev][0];
+    a.tw_n2_hi = g_ff_tab[dev][1];
+    a.tw_n2_lo = g_ff_tab[dev][2];
+    a.lo = lo;
+    a.hi = hi;
+    a.pv = pv;
+    a.pi = pi;
+    const int n_rows = (n_det + 1) / 2;
+    const size_t lds_c = sizeof(cplx) * (FF_N1 * FF_C + FF_N1);
+    const size_t lds_r = sizeof(cplx) * (2 * FF_N2 + 128);
+    static bool once = false;
+    if (!once) {
+        hipFuncSetAttribute((const void*)fine_cols_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
+        hipFuncSetAttribute((const void*)fine_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
+        once = true;
+    }
+    fine_cols_kernel<<<dim3(FF_N2 / FF_C, (unsigned)n_rows), FF_TPB, lds_c, st>>>(a);
+    fine_rows_kernel<<<dim3(FF_N1 / 2 + 1, (unsigned)n_rows), FF_TPB, lds_r, st>>>(a);
     SGX_HIP(hipGetLastError());
     return SGX_OK;
 }

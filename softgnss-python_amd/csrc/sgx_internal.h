@@ -136,6 +136,11 @@ struct Fft4Fuse {
     double inv_n = 0.0;
     int sum_blocks = 1;            // powers of this many consecutive rows are added before the reduction / store
 };
+bool sgx_fft_fine_supported(int64_t npts);
+int sgx_fft_fine_partials(void);
+int sgx_fft_fine_search(const FftPlan* plan, const int8_t* x, const int8_t* codes, const int* d_det_prn,
+                        const int* d_det_phase, int n_det, long long len, const long long* d_sum, double n_mean, double ts,
+                        double tc1, cplx* work, long long lo, long long hi, double* pv, long long* pi, hipStream_t st);
 bool sgx_fft4_supported(int64_t n);
 int sgx_fft4_row_blocks(void);
 int sgx_fft4_forward(const FftPlan* p, const cplx* in, cplx* work, cplx* out, int64_t rows, hipStream_t st,
