@@ -158,14 +158,19 @@ struct SecondArgs {
 };
 
 // acquisition.py:162: max of the chosen frequency row over the exclusion index list
+// (grid (PRNs, SEC_SPLIT): every workgroup takes a slice of the ranges and folds its maximum into out[p] with an integer
+// atomic max on the bit pattern - powers are non-negative, so the patterns order like the values; out[] starts at 0)
+#define SEC_SPLIT 16
 __global__ __launch_bounds__(256) void acq_second_kernel(const double* __restrict__ P, double* __restrict__ out,
-                                                         long long n, SecondArgs a) {
+                                                         long long n, const SecondArgs* __restrict__ ap) {
+    const SecondArgs& a = *ap;
     const int p = blockIdx.x;
-    double best = -1.0;
+    const int t0 = blockIdx.y * 256 + threadIdx.x, ts = gridDim.y * 256;
+    double best = 0.0;
     if (a.row[p] >= 0) {
         const double* __restrict__ prow = P + (long long)a.row[p] * n;
-        for (int i = a.lo0[p] + threadIdx.x; i < a.hi0[p]; i += 256) best = fmax(best, prow[i]);
-        for (int i = a.lo1[p] + threadIdx.x; i < a.hi1[p]; i += 256) best = fmax(best, prow[i]);
+        for (int i = a.lo0[p] + t0; i < a.hi0[p]; i += ts) best = fmax(best, prow[i]);
+        for (int i = a.lo1[p] + t0; i < a.hi1[p]; i += ts) best = fmax(best, prow[i]);
     }
     __shared__ double s_v[256];
     s_v[threadIdx.x] = best;
@@ -174,22 +179,24 @@ __global__ __launch_bounds__(256) void acq_second_kernel(const double* __restric
         if ((int)threadIdx.x < s) s_v[threadIdx.x] = fmax(s_v[threadIdx.x], s_v[threadIdx.x + s]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[p] = s_v[0];
+    if (threadIdx.x == 0) atomicMax((unsigned long long*)&out[p], (unsigned long long)__double_as_longlong(s_v[0]));
 }
 
 // the same on a recomputed complex correlation row: |z|^2 / N^2 formed on the fly, identical arithmetic to
 // the fused last pass, so peak / second peak is a ratio of consistently rounded values
 __global__ __launch_bounds__(256) void acq_second_cplx_kernel(const cplx* __restrict__ Z, double* __restrict__ out,
-                                                              long long n, double inv_n, SecondArgs a) {
+                                                              long long n, double inv_n, const SecondArgs* __restrict__ ap) {
+    const SecondArgs& a = *ap;
     const int p = blockIdx.x;
-    double best = -1.0;
+    const int t0 = blockIdx.y * 256 + threadIdx.x, ts = gridDim.y * 256;
+    double best = 0.0;
     if (a.row[p] >= 0) {
         const cplx* __restrict__ zrow = Z + (long long)a.row[p] * n;
-        for (int i = a.lo0[p] + threadIdx.x; i < a.hi0[p]; i += 256) {
+        for (int i = a.lo0[p] + t0; i < a.hi0[p]; i += ts) {
             const double re = zrow[i].x * inv_n, im = zrow[i].y * inv_n;
             best = fmax(best, re * re + im * im);
         }
-        for (int i = a.lo1[p] + threadIdx.x; i < a.hi1[p]; i += 256) {
+        for (int i = a.lo1[p] + t0; i < a.hi1[p]; i += ts) {
             const double re = zrow[i].x * inv_n, im = zrow[i].y * inv_n;
             best = fmax(best, re * re + im * im);
         }
@@ -201,15 +208,28 @@ __global__ __launch_bounds__(256) void acq_second_cplx_kernel(const cplx* __rest
         if ((int)threadIdx.x < s) s_v[threadIdx.x] = fmax(s_v[threadIdx.x], s_v[threadIdx.x + s]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[p] = s_v[0];
+    if (threadIdx.x == 0) atomicMax((unsigned long long*)&out[p], (unsigned long long)__double_as_longlong(s_v[0]));
 }
 
-// integer sum of the record window (mean for acquisition.py:59)
+// integer sum of the record window (mean for acquisition.py:59): bytes up to the first 16-byte boundary, 16 bytes per
+// lane from there, bytes again for the rest
 __global__ __launch_bounds__(256) void acq_sum_kernel(const int8_t* __restrict__ x, long long n,
                                                       long long* __restrict__ out) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x, gsz = (long long)gridDim.x * 256;
+    long long head = (16 - ((unsigned long long)x & 15)) & 15;
+    if (head > n) head = n;
+    const long long n16 = (n - head) / 16;
     long long acc = 0;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
-        acc += x[i];
+    if (gid < head) acc += x[gid];
+    const uint4* __restrict__ x16 = reinterpret_cast<const uint4*>(x + head);
+    for (long long i = gid; i < n16; i += gsz) {
+        const uint4 v = x16[i];
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            acc += (int)(w[d] << 24) >> 24, acc += (int)(w[d] << 16) >> 24, acc += (int)(w[d] << 8) >> 24, acc += (int)w[d] >> 24;
+    }
+    for (long long i = head + n16 * 16 + gid; i < n; i += gsz) acc += x[i];
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
     if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long*)out, (unsigned long long)acc);
 }
@@ -390,8 +410,7 @@ extern "C" int sgx_acquire(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n_
     int* d_detph = d_detprn + 32;
     const int nblk_last = sgx_fft_last_pass_blocks(&c->plan_code);
     int2* d_map = (int2*)(dsm + 200000);
-    double* d_pv = (double*)(dsm + 65536);
-    long long* d_pi = (long long*)(dsm + 65536 + 8 * 32 * 256);
+    SecondArgs* d_sa = (SecondArgs*)(dsm + 600000);
 
     // per-workgroup maxima of the fused last pass live in the (otherwise unused) power buffer
     double* d_pmax = c->d_pow;
@@ -535,7 +554,9 @@ extern "C" int sgx_acquire(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n_
         }
         if (status != SGX_OK) break;
         if (noncoh) {
-            acq_second_kernel<<<np, 256, 0, st>>>(c->d_pow, d_second, N, sa);
+            SGX_HIP(hipMemcpyAsync(d_sa, &sa, sizeof(sa), hipMemcpyHostToDevice, st));
+            SGX_HIP(hipMemsetAsync(d_second, 0, sizeof(double) * 32, st));
+            acq_second_kernel<<<dim3((unsigned)np, SEC_SPLIT), 256, 0, st>>>(c->d_pow, d_second, N, d_sa);
         } else {
             // recompute only the np rows the second-peak search reads (one per PRN)
             int2* h_map = (int2*)(hsm + 200000);
@@ -551,7 +572,9 @@ extern "C" int sgx_acquire(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n_
             cplx* r2 = nullptr;
             rc = sgx_fft_forward_fused(&c->plan_code, c->d_work[0], c->d_work[1], np, st, &r2, N, &fu);
             if (rc != SGX_OK) return rc;
-            acq_second_cplx_kernel<<<np, 256, 0, st>>>(r2, d_second, N, inv_n, sa);
+            SGX_HIP(hipMemcpyAsync(d_sa, &sa, sizeof(sa), hipMemcpyHostToDevice, st));
+            SGX_HIP(hipMemsetAsync(d_second, 0, sizeof(double) * 32, st));
+            acq_second_cplx_kernel<<<dim3((unsigned)np, SEC_SPLIT), 256, 0, st>>>(r2, d_second, N, inv_n, d_sa);
         }
         double* h_second = (double*)(hsm + 1024 + 12 * 4096);
         SGX_HIP(hipMemcpyAsync(h_second, d_second, sizeof(double) * (size_t)np, hipMemcpyDeviceToHost, st));
@@ -681,12 +704,12 @@ static int acquire_fine(sgx_ctx* c, const int8_t* x, size_t n_samples, const std
     return SGX_OK;
 }
 
-// Host part of the peak logic for one PRN (acquisition.py:129-162): block choice per bin (A7), global peak, first
-// row / first column attaining it (A8), exclusion list (A8b).  rowmax / rowarg: per (block, bin) row of this PRN, or per
-// bin (non-coherent).  Returns SGX_E_INDEX where the reference raises IndexError (Q5).
-static int acq_peak_logic(const double* rowmax, const int* rowarg, int n_bins, int n_blocks, bool noncoh, long long N,
-                          int spc, int prn_for_msg, double* peak, int* cph, int* fbi, int* best_block, int* lo0, int* hi0,
-                          int* lo1, int* hi1) {
+// Peak logic for one PRN (acquisition.py:129-162): block choice per bin (A7), global peak, first row / first column
+// attaining it (A8), exclusion list (A8b).  rowmax / rowarg: per (block, bin) row of this PRN, or per bin
+// (non-coherent).  Returns 1 where the reference raises IndexError (Q5), else 0.
+__host__ __device__ static inline int acq_peak_logic(const double* rowmax, const int* rowarg, int n_bins, int n_blocks,
+                                                     bool noncoh, long long N, int spc, double* peak, int* cph, int* fbi,
+                                                     int* best_block, int* lo0, int* hi0, int* lo1, int* hi1) {
     double gmax = -1.0;
     int gk = 0, gc = 0, gb = 0;
     bool have = false;
@@ -723,12 +746,7 @@ static int acq_peak_logic(const double* rowmax, const int* rowarg, int n_bins, i
     *lo0 = *hi0 = *lo1 = *hi1 = 0;
     const int e1 = gc - spc, e2 = gc + spc;
     if (e1 <= 0) {
-        if ((long long)N + e1 + 1 > N) {   // index N would be read: the reference's IndexError (Q5)
-            sgx_set_error("IndexError: index %lld is out of bounds for axis 1 with size %lld "
-                          "(PRN index %d, codePhase %d; reference acquisition.py:152-162)",
-                          N, N, prn_for_msg, gc);
-            return SGX_E_INDEX;
-        }
+        if ((long long)N + e1 + 1 > N) return 1;   // index N would be read: the reference's IndexError (Q5)
         *lo0 = e2;
         *hi0 = (int)(N + e1 + 1);
     } else if (e2 >= N - 1) {
@@ -748,7 +766,45 @@ static int acq_peak_logic(const double* rowmax, const int* rowarg, int n_bins, i
         *lo1 = e2;
         *hi1 = (int)N;
     }
-    return SGX_OK;
+    return 0;
+}
+
+// The same for every PRN of a call on the device: fills the second-peak search's arguments and row map, so the host
+// looks at the coarse search once (after the second peaks).
+struct PeakOut {
+    double peak[32];
+    int cph[32], fbi[32];
+    int index_error[32];
+};
+__global__ __launch_bounds__(64) void acq_peak_kernel(const double* __restrict__ rowmax, const int* __restrict__ rowarg,
+                                                      int n_prn, int out_per_prn, int n_bins, int n_blocks, int noncoh,
+                                                      long long N, int spc, PeakOut* __restrict__ po,
+                                                      SecondArgs* __restrict__ sa, int2* __restrict__ row_map) {
+    const int pi = threadIdx.x;
+    if (pi >= 32) return;
+    sa->row[pi] = -1;
+    sa->lo0[pi] = sa->hi0[pi] = sa->lo1[pi] = sa->hi1[pi] = 0;
+    if (pi >= n_prn) return;
+    int bb = 0, lo0, hi0, lo1, hi1, cph, fbi;
+    double peak;
+    const int bad = acq_peak_logic(rowmax + (long long)pi * out_per_prn, rowarg + (long long)pi * out_per_prn, n_bins,
+                                   n_blocks, noncoh != 0, N, spc, &peak, &cph, &fbi, &bb, &lo0, &hi0, &lo1, &hi1);
+    po->peak[pi] = peak;
+    po->cph[pi] = cph;
+    po->fbi[pi] = fbi;
+    po->index_error[pi] = bad;
+    if (!bad) {
+        sa->row[pi] = pi;
+        sa->lo0[pi] = lo0;
+        sa->hi0[pi] = hi0;
+        sa->lo1[pi] = lo1;
+        sa->hi1[pi] = hi1;
+    }
+    if (noncoh) {
+        for (int b = 0; b < n_blocks; ++b) row_map[pi * n_blocks + b] = make_int2(b * n_bins + fbi, pi);
+    } else {
+        row_map[pi] = make_int2(bb * n_bins + fbi, pi);
+    }
 }
 
 // The acquisition on the four-step transform (sgx_fft.hip): every 38192-point transform is two kernels with LDS-resident
@@ -848,6 +904,7 @@ static int acquire_four_step(sgx_ctx* c, const sgx_if* r, size_t offset, size_t 
     SGX_HIP(hipMemsetAsync(d_sum, 0, 8, st));
     SGX_HIP(hipMemcpyAsync(d_prn, prn0, sizeof(int) * (size_t)n_prn, hipMemcpyHostToDevice, st));
     SGX_HIP(hipMemcpyAsync(d_binmap, bin_map.data(), sizeof(int2) * (size_t)n_bins, hipMemcpyHostToDevice, st));
+    SGX_HIP(hipMemsetAsync(d_second, 0, sizeof(double) * 32, st));
     acq_sum_kernel<<<256, 256, 0, st>>>(x, (long long)n_samples, d_sum);
 
     // ---- PRN-independent part: n_blocks x n_phi forward spectra, straight into d_fwd --------------------------
@@ -894,40 +951,13 @@ static int acquire_four_step(sgx_ctx* c, const sgx_if* r, size_t offset, size_t 
         if (rc != SGX_OK) return rc;
     }
     acq_rowmax_finish_kernel<<<rows_out_all, 64, 0, st>>>(d_pmax, d_parg, nblk, d_rowmax, d_rowarg);
-    std::vector<double> h_rowmax((size_t)rows_out_all);
-    std::vector<int> h_rowarg((size_t)rows_out_all);
-    SGX_HIP(hipMemcpyAsync(h_rowmax.data(), d_rowmax, sizeof(double) * (size_t)rows_out_all, hipMemcpyDeviceToHost, st));
-    SGX_HIP(hipMemcpyAsync(h_rowarg.data(), d_rowarg, sizeof(int) * (size_t)rows_out_all, hipMemcpyDeviceToHost, st));
-    SGX_HIP(hipStreamSynchronize(st));
-
-    // ---- host: block choice, global peak, exclusion list of every PRN; the rows the second-peak search reads -------
-    SecondArgs sa;
-    double peak[32];
-    int cph[32], fbi[32];
-    int2* h_map = (int2*)(hsm + 200000);
-    int status = SGX_OK;
-    for (int pi = 0; pi < 32; ++pi) sa.row[pi] = -1, sa.lo0[pi] = sa.hi0[pi] = sa.lo1[pi] = sa.hi1[pi] = 0;
-    for (int pi = 0; pi < n_prn; ++pi) {
-        int bb = 0;
-        status = acq_peak_logic(h_rowmax.data() + (size_t)pi * out_per_prn, h_rowarg.data() + (size_t)pi * out_per_prn, n_bins,
-                                n_blocks, noncoh != 0, N, spc, prn0[pi], &peak[pi], &cph[pi], &fbi[pi], &bb, &sa.lo0[pi],
-                                &sa.hi0[pi], &sa.lo1[pi], &sa.hi1[pi]);
-        if (status != SGX_OK) break;
-        sa.row[pi] = pi;
-        if (noncoh) {
-            for (int b = 0; b < n_blocks; ++b) h_map[pi * n_blocks + b] = make_int2(b * n_bins + fbi[pi], pi);
-        } else {
-            h_map[pi] = make_int2(bb * n_bins + fbi[pi], pi);
-        }
-    }
-    if (status != SGX_OK) {
-        hipEventRecord(c->ev[1], st);
-        hipStreamSynchronize(st);
-        return status;
-    }
+    // ---- device: block choice, global peak, exclusion list of every PRN; the rows the second-peak search reads -------
+    PeakOut* d_po = (PeakOut*)(dsm + 620000);
+    SecondArgs* d_sa = (SecondArgs*)(dsm + 600000);
+    acq_peak_kernel<<<1, 64, 0, st>>>(d_rowmax, d_rowarg, n_prn, out_per_prn, n_bins, n_blocks, noncoh, N, spc, d_po, d_sa,
+                                      d_map);
     {
         const int rows2 = n_prn * (noncoh ? n_blocks : 1);
-        SGX_HIP(hipMemcpyAsync(d_map, h_map, sizeof(int2) * (size_t)rows2, hipMemcpyHostToDevice, st));
         Fft4Fuse fu;
         fu.mul_x = c->d_fwd;
         fu.mul_f = c->d_codefd;
@@ -942,17 +972,31 @@ static int acquire_four_step(sgx_ctx* c, const sgx_if* r, size_t offset, size_t 
             fu.sum_blocks = n_blocks;
             rc = sgx_fft4_forward(&c->plan_code, nullptr, c->d_work[0], nullptr, rows2, st, &fu);
             if (rc != SGX_OK) return rc;
-            acq_second_kernel<<<n_prn, 256, 0, st>>>(d_power, d_second, N, sa);
+            acq_second_kernel<<<dim3((unsigned)n_prn, SEC_SPLIT), 256, 0, st>>>(d_power, d_second, N, d_sa);
         } else {
             rc = sgx_fft4_forward(&c->plan_code, nullptr, c->d_work[0], c->d_work[1], rows2, st, &fu);
             if (rc != SGX_OK) return rc;
-            acq_second_cplx_kernel<<<n_prn, 256, 0, st>>>(c->d_work[1], d_second, N, inv_n, sa);
+            acq_second_cplx_kernel<<<dim3((unsigned)n_prn, SEC_SPLIT), 256, 0, st>>>(c->d_work[1], d_second, N, inv_n, d_sa);
         }
     }
-    double h_second[32];
+    // ---- the host's one look at the coarse search ------------------------------------------------------------------------
+    PeakOut* h_po = (PeakOut*)(hsm + 620000);
+    double* h_second = (double*)(hsm + 1024 + 12 * 4096);
+    SGX_HIP(hipMemcpyAsync(h_po, d_po, sizeof(PeakOut), hipMemcpyDeviceToHost, st));
     SGX_HIP(hipMemcpyAsync(h_second, d_second, sizeof(double) * (size_t)n_prn, hipMemcpyDeviceToHost, st));
     hipEventRecord(c->ev[1], st);
     SGX_HIP(hipStreamSynchronize(st));
+    const double* peak = h_po->peak;
+    const int* cph = h_po->cph;
+    const int* fbi = h_po->fbi;
+    for (int pi = 0; pi < n_prn; ++pi) {
+        if (h_po->index_error[pi]) {
+            sgx_set_error("IndexError: index %lld is out of bounds for axis 1 with size %lld "
+                          "(PRN index %d, codePhase %d; reference acquisition.py:152-162)",
+                          N, N, prn0[pi], cph[pi]);
+            return SGX_E_INDEX;
+        }
+    }
     std::vector<int> det_prn, det_phase, det_slot;
     for (int pi = 0; pi < n_prn; ++pi) {
         const double ratio = peak[pi] / h_second[pi];
