@@ -872,12 +872,11 @@ static int acquire_four_step(sgx_ctx* c, const sgx_if* r, size_t offset, size_t 
     if (prn_chunk > n_prn) prn_chunk = n_prn;
     const size_t row_bytes = sizeof(cplx) * (size_t)N;
     size_t work_rows = (size_t)prn_chunk * rows_per_prn;
-    if (work_rows < (size_t)rows_fwd) work_rows = rows_fwd;
+    if (work_rows < (size_t)(rows_fwd + n_prn)) work_rows = (size_t)(rows_fwd + n_prn);
     if (work_rows < (size_t)n_prn * (noncoh ? n_blocks : 1)) work_rows = (size_t)n_prn * (noncoh ? n_blocks : 1);
     if ((rc = ensure_buf((void**)&c->d_work[0], &c->cap_w0, work_rows * row_bytes)) != SGX_OK) return rc;
     if ((rc = ensure_buf((void**)&c->d_work[1], &c->cap_w1, work_rows * row_bytes)) != SGX_OK) return rc;
-    if ((rc = ensure_buf((void**)&c->d_fwd, &c->cap_fwd, (size_t)rows_fwd * row_bytes)) != SGX_OK) return rc;
-    if ((rc = ensure_buf((void**)&c->d_codefd, &c->cap_code, (size_t)n_prn * row_bytes)) != SGX_OK) return rc;
+    if ((rc = ensure_buf((void**)&c->d_fwd, &c->cap_fwd, (size_t)(rows_fwd + n_prn) * row_bytes)) != SGX_OK) return rc;
     const int nblk = sgx_fft4_row_blocks();
     const int rows_out_all = n_prn * (noncoh ? n_bins : rows_per_prn);
     size_t pow_need = (size_t)rows_out_all * nblk * 12 + 4096;
@@ -907,18 +906,15 @@ static int acquire_four_step(sgx_ctx* c, const sgx_if* r, size_t offset, size_t 
     SGX_HIP(hipMemsetAsync(d_second, 0, sizeof(double) * 32, st));
     acq_sum_kernel<<<256, 256, 0, st>>>(x, (long long)n_samples, d_sum);
 
-    // ---- PRN-independent part: n_blocks x n_phi forward spectra, straight into d_fwd --------------------------
+    // ---- forward spectra (n_blocks x n_phi rows, PRN independent) and code spectra (n_prn rows): ONE batch, results
+    //      straight into d_fwd = [forward | code] ----------------------------------------------------------------------
+    cplx* const d_codefd = c->d_fwd + (size_t)rows_fwd * (size_t)N;
     {
         dim3 grid((unsigned)((N + 255) / 256), (unsigned)rows_fwd);
         acq_mixphi_kernel<<<grid, 256, 0, st>>>(x, c->d_work[1], N, pa);
-        rc = sgx_fft4_forward(&c->plan_code, c->d_work[1], c->d_work[0], c->d_fwd, rows_fwd, st, nullptr);
-        if (rc != SGX_OK) return rc;
-    }
-    // ---- code spectra, straight into d_codefd -------------------------------------------------------------------
-    {
-        dim3 grid((unsigned)((N + 255) / 256), (unsigned)n_prn);
-        acq_code_kernel<<<grid, 256, 0, st>>>(c->d_codes, d_prn, c->d_work[1], N, ts, tc);
-        rc = sgx_fft4_forward(&c->plan_code, c->d_work[1], c->d_work[0], c->d_codefd, n_prn, st, nullptr);
+        dim3 grid2((unsigned)((N + 255) / 256), (unsigned)n_prn);
+        acq_code_kernel<<<grid2, 256, 0, st>>>(c->d_codes, d_prn, c->d_work[1] + (size_t)rows_fwd * (size_t)N, N, ts, tc);
+        rc = sgx_fft4_forward(&c->plan_code, c->d_work[1], c->d_work[0], c->d_fwd, rows_fwd + n_prn, st, nullptr);
         if (rc != SGX_OK) return rc;
     }
     for (int i = 0; i < n_prn; ++i) {
@@ -935,7 +931,7 @@ static int acquire_four_step(sgx_ctx* c, const sgx_if* r, size_t offset, size_t 
         const int np = (p0 + prn_chunk <= n_prn) ? prn_chunk : (n_prn - p0);
         Fft4Fuse fu;
         fu.mul_x = c->d_fwd;
-        fu.mul_f = c->d_codefd;
+        fu.mul_f = d_codefd;
         fu.bin_map = d_binmap;
         fu.n_bins = n_bins;
         fu.n_phi = n_phi;
@@ -960,7 +956,7 @@ static int acquire_four_step(sgx_ctx* c, const sgx_if* r, size_t offset, size_t 
         const int rows2 = n_prn * (noncoh ? n_blocks : 1);
         Fft4Fuse fu;
         fu.mul_x = c->d_fwd;
-        fu.mul_f = c->d_codefd;
+        fu.mul_f = d_codefd;
         fu.bin_map = d_binmap;
         fu.row_map = d_map;
         fu.n_bins = n_bins;
