@@ -172,6 +172,13 @@ int sgx_acquire(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n_samples,
                 double* carrFreq, double* codePhase, double* peakMetric,
                 int32_t* freqBin, int32_t* fineIdx);
 
+/* The same for a signal that is not int8: acquisition.py:55-59 works on whatever real dtype numpy hands it (float
+ * samples, int16 values, a record rescaled on the host).  `signal` = n_samples fp64 samples on the host; they are copied to
+ * HBM and the kernels read them in place of the int8 record (same fp64 arithmetic, same outputs as sgx_acquire). */
+int sgx_acquire_f64(sgx_ctx* c, const double* signal, size_t n_samples, const int32_t* prn0, int32_t n_prn,
+                    int32_t n_blocks, int32_t noncoh, double* carrFreq, double* codePhase, double* peakMetric,
+                    int32_t* freqBin, int32_t* fineIdx);
+
 /* ---- TrackingResult.track (tracking.py:13-295) ----------------------------------------------
  * Tracks n_ch channels for `ms` code periods on the record.  rec_file_offset is the byte offset
  * in the reference's file of the record's first sample (0 when the whole file was uploaded):

@@ -85,6 +85,7 @@ _PROTOS = {
     "sgx_if_free": (C.c_int, [_P, _P]),
     "sgx_acquire": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, C.c_int32, C.c_int32, C.c_int32,
                               _P, _P, _P, _P, _P]),
+    "sgx_acquire_f64": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
     "sgx_track": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, C.c_int32, _P, _P]),
     "sgx_stream_rates": (C.c_int, [_P, C.c_size_t, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "sgx_probe_stats": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, C.c_double, _P, _P, _P, C.POINTER(C.c_int32)]),
@@ -330,6 +331,20 @@ class Context(object):
         fi = np.zeros(n, dtype=np.int32)
         check(lib().sgx_acquire(self._h, rec._h, int(offset), int(n_samples), _ptr(prn), n, int(n_blocks),
                                 1 if noncoh else 0, _ptr(carr), _ptr(cph), _ptr(met), _ptr(fb), _ptr(fi)))
+        return dict(carrFreq=carr, codePhase=cph, peakMetric=met, freqBin=fb, fineIdx=fi)
+
+    def acquire_f64(self, signal, prn0, n_blocks=2, noncoh=False):
+        """acquire() on a host signal of any real dtype (copied to HBM as fp64)."""
+        sig = np.ascontiguousarray(signal, dtype=np.float64)
+        prn = np.ascontiguousarray(prn0, dtype=np.int32)
+        n = prn.size
+        carr = np.zeros(n)
+        cph = np.zeros(n)
+        met = np.zeros(n)
+        fb = np.zeros(n, dtype=np.int32)
+        fi = np.zeros(n, dtype=np.int32)
+        check(lib().sgx_acquire_f64(self._h, _ptr(sig), sig.size, _ptr(prn), n, int(n_blocks), 1 if noncoh else 0,
+                                    _ptr(carr), _ptr(cph), _ptr(met), _ptr(fb), _ptr(fi)))
         return dict(carrFreq=carr, codePhase=cph, peakMetric=met, freqBin=fb, fineIdx=fi)
 
     def probe_stats(self, rec, offset, n, fs_mhz):

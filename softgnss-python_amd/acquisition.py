@@ -52,22 +52,28 @@ class AcquisitionResult(Result):
             prn_indices = range(len(settings.acqSatelliteList))
         prn_indices = [int(p) for p in prn_indices]
         own = None
+        f64 = None
         if isinstance(longSignal, DeviceSignal):
             rec, off, n = longSignal.record, longSignal.offset, longSignal.length
         else:
             arr = np.asarray(longSignal)
             if arr.ndim != 1:
                 raise ValueError("longSignal must be one-dimensional")
-            if arr.dtype != np.int8:
-                if np.any(arr != np.round(arr)) or np.any(np.abs(arr) > 127):
-                    raise TypeError("the GPU path takes int8 IF samples (Settings.dataType 'int8')")
-                arr = arr.astype(np.int8)
-            own = rec = ctx.upload(arr)
-            off, n = 0, arr.size
+            if arr.dtype == np.int8:
+                own = rec = ctx.upload(arr)
+                off, n = 0, arr.size
+            else:
+                # the reference works on whatever real dtype it is handed (acquisition.py:55-59): fp64 copy in HBM
+                if not np.isrealobj(arr):
+                    raise TypeError("longSignal must be real-valued")
+                f64 = arr.astype(np.float64)
         if self._verbose:
             print('(')
         try:
-            r = ctx.acquire(rec, off, n, prn_indices, n_blocks=n_blocks, noncoh=noncoh)
+            if f64 is not None:
+                r = ctx.acquire_f64(f64, prn_indices, n_blocks=n_blocks, noncoh=noncoh)
+            else:
+                r = ctx.acquire(rec, off, n, prn_indices, n_blocks=n_blocks, noncoh=noncoh)
         finally:
             if own is not None:
                 own.free()

@@ -25,7 +25,7 @@ struct MixArgs {
 };
 
 // acquisition.py:62-117: phasePoints[n] = ((n*2)*pi)*ts ; theta = frq*phasePoints ; I = sin*x, Q = cos*x
-__global__ __launch_bounds__(256) void acq_mix_kernel(const int8_t* __restrict__ x, cplx* __restrict__ out,
+__global__ __launch_bounds__(256) void acq_mix_kernel(SgxSig x, cplx* __restrict__ out,
                                                       long long n, double ts, MixArgs a) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void acq_mix_kernel(const int8_t* __restrict__
     const double th = a.frq[k] * pp;
     double s, c;
     sincos(th, &s, &c);
-    const double xv = (double)x[(long long)b * n + i];
+    const double xv = x.at((long long)b * n + i);
     out[((long long)b * a.n_bins + k) * n + i] = make_double2(s * xv, c * xv);
 }
 
@@ -234,10 +234,25 @@ __global__ __launch_bounds__(256) void acq_sum_kernel(const int8_t* __restrict__
     if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long*)out, (unsigned long long)acc);
 }
 
+// the same for an fp64 signal: one workgroup, fixed summation order (reproducible); the double's bits go to the same slot
+__global__ __launch_bounds__(1024) void acq_sum_f64_kernel(const double* __restrict__ x, long long n,
+                                                           long long* __restrict__ out) {
+    __shared__ double s_v[1024];
+    double acc = 0.0;
+    for (long long i = threadIdx.x; i < n; i += 1024) acc += x[i];
+    s_v[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) s_v[threadIdx.x] += s_v[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = __double_as_longlong(s_v[0]);
+}
+
 // acquisition.py:170-177 (A9): xCarrier = (x - mean)[c : c+10N] * code[floor((ts*k)/tc1) mod 1023].
 // Two detected PRNs share one complex row (first -> real part, second -> imaginary part): the two real-input
 // spectra are separated again in the argmax kernel, which halves the 2^22-point FFT work.
-__global__ __launch_bounds__(256) void acq_fine_prep_kernel(const int8_t* __restrict__ x,
+__global__ __launch_bounds__(256) void acq_fine_prep_kernel(SgxSig x,
                                                             const int8_t* __restrict__ codes, cplx* __restrict__ out,
                                                             long long len, long long row_stride, double mean,
                                                             double ts, double tc1, const int* __restrict__ det_prn,
@@ -248,8 +263,8 @@ __global__ __launch_bounds__(256) void acq_fine_prep_kernel(const int8_t* __rest
     const double v = floor((ts * (double)(i + 1)) / tc1);
     const int chip = (int)((long long)v % 1023);
     const int d0 = 2 * r, d1 = 2 * r + 1;
-    const double a = ((double)x[det_phase[d0] + i] - mean) * (double)codes[det_prn[d0] * 1023 + chip];
-    const double b = (d1 < n_det) ? ((double)x[det_phase[d1] + i] - mean) * (double)codes[det_prn[d1] * 1023 + chip] : 0.0;
+    const double a = (x.at(det_phase[d0] + i) - mean) * (double)codes[det_prn[d0] * 1023 + chip];
+    const double b = (d1 < n_det) ? (x.at(det_phase[d1] + i) - mean) * (double)codes[det_prn[d1] * 1023 + chip] : 0.0;
     out[(long long)r * row_stride + i] = make_double2(a, b);
 }
 
@@ -305,13 +320,13 @@ struct PhiArgs {
     double phi[4];
     int n_phi;
 };
-__global__ __launch_bounds__(256) void acq_mixphi_kernel(const int8_t* __restrict__ x, cplx* __restrict__ out,
+__global__ __launch_bounds__(256) void acq_mixphi_kernel(SgxSig x, cplx* __restrict__ out,
                                                          long long n, PhiArgs a) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int j = blockIdx.y % a.n_phi;
     const int b = blockIdx.y / a.n_phi;
-    const double xv = (double)x[(long long)b * n + i];
+    const double xv = x.at((long long)b * n + i);
     double s = 0.0, c = 1.0;
     if (a.phi[j] != 0.0) sincospi((2.0 * a.phi[j]) * ((double)i / (double)n), &s, &c);
     out[(long long)blockIdx.y * n + i] = make_double2(c * xv, -(s * xv));
@@ -331,12 +346,26 @@ static int ensure_buf(void** p, size_t* cap_bytes, size_t need) {
     return SGX_OK;
 }
 
-static int acquire_four_step(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n_samples, const int32_t* prn0,
+static int acquire_four_step(sgx_ctx* c, SgxSig x, size_t n_samples, const int32_t* prn0,
                              int32_t n_prn, int32_t n_blocks, int32_t noncoh, double* carrFreq, double* codePhase,
                              double* peakMetric, int32_t* freqBin, int32_t* fineIdx, bool* handled);
-static int acquire_fine(sgx_ctx* c, const int8_t* x, size_t n_samples, const std::vector<int>& det_prn,
+static int acquire_passes(sgx_ctx* c, SgxSig x, size_t n_samples, const int32_t* prn0, int32_t n_prn, int32_t n_blocks,
+                          int32_t noncoh, double* carrFreq, double* codePhase, double* peakMetric, int32_t* freqBin,
+                          int32_t* fineIdx);
+static int acquire_fine(sgx_ctx* c, SgxSig x, size_t n_samples, const std::vector<int>& det_prn,
                         const std::vector<int>& det_phase, const std::vector<int>& det_slot, long long* d_sum,
                         double* carrFreq, double* codePhase, int32_t* fineIdx);
+
+static int acquire_any(sgx_ctx* c, SgxSig x, size_t n_samples, const int32_t* prn0, int32_t n_prn, int32_t n_blocks,
+                       int32_t noncoh, double* carrFreq, double* codePhase, double* peakMetric, int32_t* freqBin,
+                       int32_t* fineIdx) {
+    // the four-step path (LDS-resident sub-transforms, shifted forward spectra) where it applies
+    bool handled = false;
+    const int rc4 = acquire_four_step(c, x, n_samples, prn0, n_prn, n_blocks, noncoh, carrFreq, codePhase, peakMetric,
+                                      freqBin, fineIdx, &handled);
+    if (handled) return rc4;
+    return acquire_passes(c, x, n_samples, prn0, n_prn, n_blocks, noncoh, carrFreq, codePhase, peakMetric, freqBin, fineIdx);
+}
 
 extern "C" int sgx_acquire(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n_samples, const int32_t* prn0,
                            int32_t n_prn, int32_t n_blocks, int32_t noncoh, double* carrFreq, double* codePhase,
@@ -345,7 +374,6 @@ extern "C" int sgx_acquire(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n_
     SGX_CHECK_ARG(n_prn >= 1 && n_prn <= 32 && n_blocks >= 1 && n_blocks <= 64);
     for (int i = 0; i < n_prn; ++i) SGX_CHECK_ARG(prn0[i] >= 0 && prn0[i] < 32);
     const long long N = c->n_code;
-    const sgx_settings& S = c->s;
     if (offset > r->n || n_samples > r->n - offset || (long long)n_samples < (long long)n_blocks * N) {
         sgx_set_error("record window too short: %zu samples at offset %zu, %lld needed for the coarse search",
                       n_samples, offset, (long long)n_blocks * N);
@@ -356,15 +384,53 @@ extern "C" int sgx_acquire(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n_
         if (rq != SGX_OK) return rq;
     }
     SGX_HIP(hipSetDevice(c->device));
-    {
-        // the four-step path (LDS-resident sub-transforms, shifted forward spectra) where it applies
-        bool handled = false;
-        const int rc4 = acquire_four_step(c, r, offset, n_samples, prn0, n_prn, n_blocks, noncoh, carrFreq, codePhase,
-                                          peakMetric, freqBin, fineIdx, &handled);
-        if (handled) return rc4;
+    SgxSig x;
+    x.i8 = r->d + offset;
+    x.f64 = nullptr;
+    return acquire_any(c, x, n_samples, prn0, n_prn, n_blocks, noncoh, carrFreq, codePhase, peakMetric, freqBin, fineIdx);
+}
+
+// acquire() on a signal that is not int8 (acquisition.py:55-59 takes whatever real dtype numpy hands it): the caller's
+// fp64 samples are copied to HBM and every kernel reads them instead of the int8 record; the arithmetic is the same
+// fp64 arithmetic either way.
+extern "C" int sgx_acquire_f64(sgx_ctx* c, const double* signal, size_t n_samples, const int32_t* prn0, int32_t n_prn,
+                               int32_t n_blocks, int32_t noncoh, double* carrFreq, double* codePhase, double* peakMetric,
+                               int32_t* freqBin, int32_t* fineIdx) {
+    SGX_CHECK_ARG(c && signal && prn0 && carrFreq && codePhase && peakMetric && freqBin && fineIdx);
+    SGX_CHECK_ARG(n_prn >= 1 && n_prn <= 32 && n_blocks >= 1 && n_blocks <= 64);
+    for (int i = 0; i < n_prn; ++i) SGX_CHECK_ARG(prn0[i] >= 0 && prn0[i] < 32);
+    const long long N = c->n_code;
+    if ((long long)n_samples < (long long)n_blocks * N) {
+        sgx_set_error("signal too short: %zu samples, %lld needed for the coarse search", n_samples, (long long)n_blocks * N);
+        return SGX_E_RANGE;
     }
+    SGX_HIP(hipSetDevice(c->device));
+    const size_t need = sizeof(double) * (n_samples + 64);
+    if (c->cap_sig64 < need) {
+        if (c->d_sig64) hipFree(c->d_sig64);
+        c->d_sig64 = nullptr;
+        c->cap_sig64 = 0;
+        if (hipMalloc((void**)&c->d_sig64, need) != hipSuccess) {
+            sgx_set_error("hipMalloc of %zu signal bytes failed", need);
+            return SGX_E_NOMEM;
+        }
+        c->cap_sig64 = need;
+    }
+    SGX_HIP(hipMemcpyAsync(c->d_sig64, signal, sizeof(double) * n_samples, hipMemcpyHostToDevice, c->stream));
+    SGX_HIP(hipStreamSynchronize(c->stream));   // the caller may free `signal` on return
+    SgxSig x;
+    x.i8 = nullptr;
+    x.f64 = c->d_sig64;
+    return acquire_any(c, x, n_samples, prn0, n_prn, n_blocks, noncoh, carrFreq, codePhase, peakMetric, freqBin, fineIdx);
+}
+
+// The round-1 path: one launch per radix pass, every Doppler bin mixed separately (any factorable samplesPerCode).
+static int acquire_passes(sgx_ctx* c, SgxSig x, size_t n_samples, const int32_t* prn0, int32_t n_prn, int32_t n_blocks,
+                          int32_t noncoh, double* carrFreq, double* codePhase, double* peakMetric, int32_t* freqBin,
+                          int32_t* fineIdx) {
+    const long long N = c->n_code;
+    const sgx_settings& S = c->s;
     hipStream_t st = c->stream;
-    const int8_t* x = r->d + offset;
 
     // A4 frequency grid (acquisition.py:68,99-101)
     const int n_bins = (int)(nearbyint(S.acqSearchBand * 2) + 1);
@@ -419,7 +485,8 @@ extern "C" int sgx_acquire(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n_
     hipEventRecord(c->ev[0], st);
     SGX_HIP(hipMemsetAsync(d_sum, 0, 8, st));
     SGX_HIP(hipMemcpyAsync(d_prn, prn0, sizeof(int) * (size_t)n_prn, hipMemcpyHostToDevice, st));
-    acq_sum_kernel<<<256, 256, 0, st>>>(x, (long long)n_samples, d_sum);
+    if (x.f64) acq_sum_f64_kernel<<<1, 1024, 0, st>>>(x.f64, (long long)n_samples, d_sum);
+    else acq_sum_kernel<<<256, 256, 0, st>>>(x.i8, (long long)n_samples, d_sum);
 
     // ---- PRN-independent part: mix + forward FFTs ------------------------------------------------
     {
@@ -609,7 +676,7 @@ extern "C" int sgx_acquire(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n_
 }
 
 // Fine frequency search (acquisition.py:167-193) for the detected PRNs; records event ev[2] and synchronises.
-static int acquire_fine(sgx_ctx* c, const int8_t* x, size_t n_samples, const std::vector<int>& det_prn,
+static int acquire_fine(sgx_ctx* c, SgxSig x, size_t n_samples, const std::vector<int>& det_prn,
                         const std::vector<int>& det_phase, const std::vector<int>& det_slot, long long* d_sum,
                         double* carrFreq, double* codePhase, int32_t* fineIdx) {
     hipStream_t st = c->stream;
@@ -653,7 +720,9 @@ static int acquire_fine(sgx_ctx* c, const int8_t* x, size_t n_samples, const std
             long long h_sum = 0;
             SGX_HIP(hipMemcpyAsync(&h_sum, d_sum, 8, hipMemcpyDeviceToHost, st));
             SGX_HIP(hipStreamSynchronize(st));
-            mean = (double)h_sum / (double)n_samples;   // longSignal.mean(), acquisition.py:59
+            double h_sumd;
+            memcpy(&h_sumd, &h_sum, 8);
+            mean = (x.f64 ? h_sumd : (double)h_sum) / (double)n_samples;   // longSignal.mean(), acquisition.py:59
         }
         int nblk = 256;
         double* h_pv = (double*)(hsm + 65536);
@@ -811,7 +880,7 @@ __global__ __launch_bounds__(64) void acq_peak_kernel(const double* __restrict__
 // sub-transforms, the mixed-signal spectra are computed once per (block, phi) and read with a circular shift, results
 // land where they are needed (no device-to-device copies) and the host looks at the device twice before the fine search
 // (row maxima of ALL PRNs, then the second peaks) whatever the number of PRN chunks.
-static int acquire_four_step(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n_samples, const int32_t* prn0,
+static int acquire_four_step(sgx_ctx* c, SgxSig x, size_t n_samples, const int32_t* prn0,
                              int32_t n_prn, int32_t n_blocks, int32_t noncoh, double* carrFreq, double* codePhase,
                              double* peakMetric, int32_t* freqBin, int32_t* fineIdx, bool* handled) {
     *handled = false;
@@ -847,7 +916,6 @@ static int acquire_four_step(sgx_ctx* c, const sgx_if* r, size_t offset, size_t 
     *handled = true;
 
     hipStream_t st = c->stream;
-    const int8_t* x = r->d + offset;
     const double ts = 1.0 / S.samplingFreq;
     const double tc = 1.0 / S.codeFreqBasis;
     const int spc = (int)llround(S.samplingFreq / S.codeFreqBasis);   // acquisition.py:145
@@ -904,7 +972,8 @@ static int acquire_four_step(sgx_ctx* c, const sgx_if* r, size_t offset, size_t 
     SGX_HIP(hipMemcpyAsync(d_prn, prn0, sizeof(int) * (size_t)n_prn, hipMemcpyHostToDevice, st));
     SGX_HIP(hipMemcpyAsync(d_binmap, bin_map.data(), sizeof(int2) * (size_t)n_bins, hipMemcpyHostToDevice, st));
     SGX_HIP(hipMemsetAsync(d_second, 0, sizeof(double) * 32, st));
-    acq_sum_kernel<<<256, 256, 0, st>>>(x, (long long)n_samples, d_sum);
+    if (x.f64) acq_sum_f64_kernel<<<1, 1024, 0, st>>>(x.f64, (long long)n_samples, d_sum);
+    else acq_sum_kernel<<<256, 256, 0, st>>>(x.i8, (long long)n_samples, d_sum);
 
     // ---- forward spectra (n_blocks x n_phi rows, PRN independent) and code spectra (n_prn rows): ONE batch, results
     //      straight into d_fwd = [forward | code] ----------------------------------------------------------------------

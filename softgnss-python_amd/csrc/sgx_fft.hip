@@ -941,13 +941,14 @@ int sgx_fft4_forward(const FftPlan* p, const cplx* in, cplx* work, cplx* out, in
 #define FF_TPB 512
 
 struct FineArgs {
-    const int8_t* x;
+    SgxSig x;
     const int8_t* codes;      // [32][1023]
     const int* det_prn;
     const int* det_phase;
     int n_det;
     long long len;            // 10 N samples of signal, zeros beyond
-    const long long* d_sum;   // integer sum of the record window; mean = sum / n_mean (acquisition.py:59)
+    const long long* d_sum;   // sum of the record window (an integer for int8 samples, the bits of a double otherwise);
+                              // mean = sum / n_mean (acquisition.py:59)
     double n_mean, ts, tc1;
     cplx* work;               // [rows][M] intermediate
     const cplx* tw_hi;        // two-level table of W_M
@@ -972,12 +973,12 @@ __global__ __launch_bounds__(FF_TPB) void fine_cols_kernel(FineArgs a) {
     const int c0 = blockIdx.x * FF_C;
     const int r = blockIdx.y;
     const int d0 = 2 * r, d1 = 2 * r + 1;
-    const int8_t* __restrict__ xa = a.x + a.det_phase[d0];
+    const long long pa = a.det_phase[d0];
     const int8_t* __restrict__ ca = a.codes + a.det_prn[d0] * 1023;
     const bool two = d1 < a.n_det;
-    const int8_t* __restrict__ xb = two ? a.x + a.det_phase[d1] : xa;
+    const long long pb = two ? a.det_phase[d1] : pa;
     const int8_t* __restrict__ cb = two ? a.codes + a.det_prn[d1] * 1023 : ca;
-    const double mean = (double)a.d_sum[0] / a.n_mean;
+    const double mean = (a.x.f64 ? __longlong_as_double(a.d_sum[0]) : (double)a.d_sum[0]) / a.n_mean;
     for (int e = tid; e < FF_N1 * FF_C; e += FF_TPB) {
         const int n1 = e / FF_C, c = e % FF_C;
         const long long i = (long long)n1 * FF_N2 + c0 + c;
@@ -985,8 +986,8 @@ __global__ __launch_bounds__(FF_TPB) void fine_cols_kernel(FineArgs a) {
         if (i < a.len) {
             const double v = floor((a.ts * (double)(i + 1)) / a.tc1);       // acquisition.py:172 (A9)
             const int chip = (int)((long long)v % 1023);
-            const double va = ((double)xa[i] - mean) * (double)ca[chip];
-            const double vb = two ? ((double)xb[i] - mean) * (double)cb[chip] : 0.0;
+            const double va = (a.x.at(pa + i) - mean) * (double)ca[chip];
+            const double vb = two ? (a.x.at(pb + i) - mean) * (double)cb[chip] : 0.0;
             val = make_double2(va, vb);
         }
         buf[e] = val;
@@ -1092,7 +1093,7 @@ int sgx_fft_fine_partials(void) { return FF_N1 / 2 + 1; }
 
 // Fine search of n_det detections (two per complex row) on the 2^22-point two-kernel transform.  `plan` = the 2^22
 // plan (its two-level table of W_M is used for the inter-step twiddles).  Fills pv / pi [n_det][sgx_fft_fine_partials()].
-int sgx_fft_fine_search(const FftPlan* plan, const int8_t* x, const int8_t* codes, const int* d_det_prn,
+int sgx_fft_fine_search(const FftPlan* plan, SgxSig x, const int8_t* codes, const int* d_det_prn,
                         const int* d_det_phase, int n_det, long long len, const long long* d_sum, double n_mean, double ts,
                         double tc1, cplx* work, long long lo, long long hi, double* pv, long long* pi, hipStream_t st) {
     if (!plan->tw_hi || !sgx_fft_fine_supported(plan->n) || n_det < 1) {

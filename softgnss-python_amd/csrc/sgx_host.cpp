@@ -196,6 +196,7 @@ extern "C" int sgx_ctx_destroy(sgx_ctx* c) {
     for (int i = 0; i < 2; ++i)
         if (c->stage[i]) hipHostFree(c->stage[i]);
     hipFree(c->d_codes);
+    if (c->d_sig64) hipFree(c->d_sig64);
     hipFree(c->d_fwd);
     hipFree(c->d_codefd);
     hipFree(c->d_work[0]);

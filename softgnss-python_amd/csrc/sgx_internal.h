@@ -35,6 +35,16 @@ void sgx_set_error(const char* fmt, ...);
 
 typedef double2 cplx;   // complex128 as (re, im)
 
+// The samples an acquisition reads: the int8 record (Settings.dataType 'int8'), or - acquire() handed any other real
+// array (acquisition.py:55-59 works on whatever numpy dtype it gets) - an fp64 copy of it.
+struct SgxSig {
+    const int8_t* i8;
+    const double* f64;
+#ifdef __HIPCC__
+    __device__ __forceinline__ double at(long long i) const { return f64 ? f64[i] : (double)i8[i]; }
+#endif
+};
+
 // Twiddle tables for one FFT length: W_N^t = hi[t >> lo_bits] * lo[t & lo_mask]
 struct FftPlan {
     int64_t n = 0;
@@ -79,6 +89,8 @@ struct sgx_ctx {
     cplx* d_work[2] = {nullptr, nullptr};   // ping-pong [rows][N]
     double* d_pow = nullptr;     // [rows][N] correlation power
     cplx* d_fine[2] = {nullptr, nullptr};
+    double* d_sig64 = nullptr;   // fp64 copy of a non-int8 signal handed to sgx_acquire_f64
+    size_t cap_sig64 = 0;
     size_t cap_fwd = 0, cap_code = 0, cap_w0 = 0, cap_w1 = 0, cap_pow = 0, cap_f0 = 0, cap_f1 = 0;   // bytes
     void* d_small = nullptr;     // small result area
     void* h_small = nullptr;     // pinned mirror
@@ -138,7 +150,7 @@ struct Fft4Fuse {
 };
 bool sgx_fft_fine_supported(int64_t npts);
 int sgx_fft_fine_partials(void);
-int sgx_fft_fine_search(const FftPlan* plan, const int8_t* x, const int8_t* codes, const int* d_det_prn,
+int sgx_fft_fine_search(const FftPlan* plan, SgxSig x, const int8_t* codes, const int* d_det_prn,
                         const int* d_det_phase, int n_det, long long len, const long long* d_sum, double n_mean, double ts,
                         double tc1, cplx* work, long long lo, long long hi, double* pv, long long* pi, hipStream_t st);
 bool sgx_fft4_supported(int64_t n);

@@ -1195,3 +1195,33 @@ def test_bench_refuses_more_gpus_than_the_box_has():
     assert r.returncode != 0
     assert b"n_gpus" not in r.stdout
     assert b"refusing" in r.stderr
+
+
+def test_acquire_accepts_any_real_valued_signal(default_record):
+    """acquisition.py:55-59 works on whatever real dtype it is handed.  A non-int8 longSignal goes to HBM as fp64
+    (sgx_acquire_f64); indices bit-exact and the metric within 1e-9 of the oracle on the SAME array: a rescaled and
+    offset float record, an int16-valued one, and the int8 record as float64 (must equal the int8 path exactly)."""
+    m = pkg()
+    s = m.Settings()
+    n = 11 * s.samplesPerCode
+    x8 = default_record[:n]
+    ref8 = m.AcquisitionResult(s, device=0)
+    ref8.acquire(x8)
+    a = m.AcquisitionResult(s, device=0)
+    a.acquire(x8.astype(np.float64))
+    assert np.array_equal(a.codePhase, ref8.codePhase) and np.array_equal(a.carrFreq, ref8.carrFreq)
+    assert np.array_equal(a.internals["freqBin"], ref8.internals["freqBin"])
+    assert np.allclose(a.peakMetric, ref8.peakMetric, rtol=1e-12, atol=0)
+    for sig in (x8.astype(np.float64) * 0.37 + 0.123, x8.astype(np.int16) * 211, (x8.astype(np.float32) - 0.5)):
+        os_ = orc.OracleSettings(acqSatelliteList=list(range(1, 13)))
+        s12 = m.Settings()
+        s12.acqSatelliteList = list(range(1, 13))
+        want = orc.acquire(os_, np.asarray(sig, dtype=np.float64))
+        b = m.AcquisitionResult(s12, device=0)
+        b.acquire(sig)
+        assert np.array_equal(b.codePhase[:12], want["codePhase"][:12])
+        assert np.array_equal(b.carrFreq[:12], want["carrFreq"][:12])
+        assert np.array_equal(b.internals["freqBin"][:12], want["freqBin"][:12])
+        assert np.allclose(b.peakMetric[:12], want["peakMetric"][:12], rtol=1e-9, atol=0)
+    with pytest.raises(TypeError):
+        m.AcquisitionResult(s, device=0).acquire(x8.astype(np.complex128))
