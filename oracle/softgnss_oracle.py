@@ -241,12 +241,17 @@ def pre_run(s, acq):
 def track(s, channels, record, ms=None):
     """DLL/PLL tracking of every active channel.  Follows tracking.py:35-294.
 
-    record   int8 array holding the file from byte 0 (the reference seeks/reads a file object;
-             positions here are the same byte offsets).
+    record   array holding the file from byte 0 (the reference seeks/reads a file object; positions
+             here are the same BYTE offsets).  Samples are s.dataType (tracking.py:154 reads
+             np.fromfile(fid, settings.dataType, blksize)); note that the reference seeks to
+             skipNumberOfBytes + codePhase BYTES and records fid.tell() in bytes for every dtype
+             (tracking.py:107,255) - kept as it is.
     Returns None on a short read (tracking.py:159-163), else a list with one dict per ACTIVE
     channel (Q8) holding PRN, status and the 13 per-ms float64 series.
     """
-    rec = np.asarray(record)
+    dt = np.dtype(getattr(s, "dataType", "int8"))
+    isz = dt.itemsize
+    rec = np.ascontiguousarray(record).view(np.uint8).ravel()      # the file's bytes
     n_ms = int(s.msToProcess if ms is None else ms)
     spc_el = s.dllCorrelatorSpacing
     pdi = 0.001
@@ -271,10 +276,10 @@ def track(s, channels, record, ms=None):
         for it in range(n_ms):
             step = code_freq / fs                                       # tracking.py:148 (T1)
             blk = int(np.ceil((s.codeLength - rem_code) / step))
-            raw = rec[pos:pos + blk]                                    # tracking.py:154 (T2)
+            raw = np.frombuffer(rec[pos:pos + blk * isz].tobytes(), dtype=dt)   # tracking.py:154 (T2)
             if len(raw) != blk:
                 return None
-            pos += blk
+            pos += blk * isz
             # tracking.py:166-188 (T3): three linspace ramps, ceil, gather
             te = np.linspace(rem_code - spc_el, blk * step + rem_code - spc_el, blk, endpoint=False)
             early = code[np.ceil(te).astype(np.int64)]

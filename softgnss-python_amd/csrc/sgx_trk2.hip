@@ -358,8 +358,10 @@ __device__ __forceinline__ int t2_map_role(T2Shared& S, const int8_t* __restrict
         }
         if (__builtin_expect(i0 < blk && i0 + 16 > blk, 0)) {
             // the block ends inside this group (one lane per block): samples from blk on belong to the next block
+            // (integer mask on the high dword, as for the samples before a switch below)
+            const int e = blk - i0;
 #pragma unroll
-            for (int b = 0; b < 16; ++b) xd[b] = (i0 + b < blk) ? xd[b] : 0.0;
+            for (int b = 0; b < 16; ++b) xd[b] = __hiloint2double(__double2hiint(xd[b]) & ((b - e) >> 31), 0);
         }
         T2PROBE(prof_on, 1);   // switch samples resolved
         const double cE1 = __hiloint2double((int)(0x3FF00000u | (bE << 31)), 0), cE2 = __hiloint2double((int)(0x3FF00000u | ((bE >> 1) << 31)), 0);

@@ -8,7 +8,7 @@ from this repo's deterministic generator and stores ONLY inputs' parameters and 
 reference's outputs as small .npz fixtures next to this file.
 
     python tests/golden/make_golden.py            # regenerates every fixture (~30 min, one core, < 4 GiB)
-    SGX_GOLDEN_ONLY=<part> python tests/golden/make_golden.py  # one part only:
+    SGX_GOLDEN_ONLY=<part> python tests/golden/make_golden.py  # one part only (probe, eph, geo, fix, nav, int16):
         probe  probe_default.npz   Settings.probeData (Welch PSD, histogram)
         eph    eph_cases.npz       ephemeris.ephemeris on the generator's navigation frames
         geo    geo_cases.npz       satpos, leastSquarePos, cart2geo, findUtmZone, cart2utm and helpers
@@ -383,6 +383,52 @@ def golden_nav(tmp, initialize, acquisition, tracking):
     print("nav_preambles.npz", first, active)
 
 
+def golden_int16(tmp, initialize, acquisition, tracking):
+    """Settings.dataType = 'int16' (tracking.py:154 reads np.fromfile(fid, settings.dataType, blksize)): the default
+    scene's int8 record rescaled by 57 and written as little-endian int16.  The reference seeks to
+    skipNumberOfBytes + codePhase BYTES whatever the sample size (tracking.py:107), so a channel starts on its code
+    only if skipNumberOfBytes == codePhase (then the seek lands on byte 2 * codePhase = sample codePhase): case "locked",
+    one channel.  Case "as_is": skipNumberOfBytes = 0, two channels, started wherever the byte seek puts them."""
+    s = initialize.Settings()
+    n = s.samplesPerCode
+    sc = synth.Scene.default(n_sats=3)
+    ms = 120
+    rec8 = synth.generate(sc, synth.record_length(n, ms + 40))
+    rec16 = (rec8.astype(np.int16) * 57).astype("<i2")
+    acq = acquisition.AcquisitionResult(s)
+    with Quiet():
+        acq.acquire(rec16[:11 * n])          # acquisition.py works on whatever dtype it is handed
+    names = ("absoluteSample", "codeFreq", "carrFreq", "I_P", "I_E", "I_L", "Q_E", "Q_P", "Q_L",
+             "dllDiscr", "dllDiscrFilt", "pllDiscr", "pllDiscrFilt")
+    out = dict(scene=scene_json(sc), n_samples=np.int64(len(rec16)), scale=np.int64(57), ms=np.int64(ms),
+               names=np.array(names), carrFreq=acq.carrFreq, codePhase=acq.codePhase, peakMetric=acq.peakMetric)
+    for case, nch in (("locked", 1), ("as_is", 2)):
+        st = initialize.Settings()
+        st.dataType = 'int16'
+        st.msToProcess = float(ms)
+        st.numberOfChannels = nch
+        a2 = acquisition.AcquisitionResult(st)
+        a2.results = acq.results
+        with Quiet():
+            a2.preRun()
+        if case == "locked":
+            st.skipNumberOfBytes = int(a2.channels.codePhase[0])
+        trk = tracking.TrackingResult(a2)
+        fid = as_file(tmp, "rec16_%s.bin" % case, rec16)
+        with Quiet():
+            trk.track(fid)
+        r = trk.results
+        series = np.stack([np.stack([np.asarray(r[i][k], dtype=np.float64) for k in names]) for i in range(len(r))])
+        out[case + "_series"] = series
+        out[case + "_skip"] = np.int64(st.skipNumberOfBytes)
+        out[case + "_PRN"] = a2.channels.PRN
+        out[case + "_acquiredFreq"] = a2.channels.acquiredFreq
+        out[case + "_codePhase"] = a2.channels.codePhase
+        print("trk_int16", case, series.shape, "codePhase", a2.channels.codePhase, "I_P rms",
+              np.sqrt(np.mean(series[:, 3, 40:] ** 2, axis=1)))
+    np.savez_compressed(os.path.join(HERE, "trk_int16.npz"), **out)
+
+
 def scene_json(sc):
     return json.dumps(dict(seed=sc.seed, fs=sc.fs, sats=sc.sats))
 
@@ -400,6 +446,9 @@ def main():
             return
         if os.environ.get("SGX_GOLDEN_ONLY", "") == "fix":
             golden_fix(tmp, initialize, acquisition, tracking)
+            return
+        if os.environ.get("SGX_GOLDEN_ONLY", "") == "int16":
+            golden_int16(tmp, initialize, acquisition, tracking)
             return
         if os.environ.get("SGX_GOLDEN_ONLY", "") == "nav":
             golden_nav(tmp, initialize, acquisition, tracking)

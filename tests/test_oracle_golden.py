@@ -103,6 +103,25 @@ def test_track_matches_reference(default_record):
     assert got[0, 0, 0] == g["ch_codePhase"][0] + 38192
 
 
+def test_track_int16_matches_reference():
+    """Settings.dataType = 'int16' (tracking.py:154): samples of two bytes, byte seeks and byte positions as the
+    reference has them (tracking.py:107,255).  A locked channel and two channels started where the byte seek lands."""
+    g = load_golden("trk_int16.npz")
+    synth = pkg("synth")
+    rec16 = (synth.generate(scene_from_json(g["scene"]), int(g["n_samples"])).astype(np.int16) * int(g["scale"])).astype("<i2")
+    acq = orc.acquire(orc.OracleSettings(), rec16[:11 * 38192])
+    assert np.array_equal(acq["codePhase"], g["codePhase"]) and np.array_equal(acq["carrFreq"], g["carrFreq"])
+    for case in ("locked", "as_is"):
+        nch = len(g[case + "_PRN"])
+        s = orc.OracleSettings(numberOfChannels=nch, msToProcess=float(g["ms"]), dataType='int16',
+                               skipNumberOfBytes=int(g[case + "_skip"]))
+        ch = dict(PRN=g[case + "_PRN"], acquiredFreq=g[case + "_acquiredFreq"], codePhase=g[case + "_codePhase"],
+                  status=['T'] * nch)
+        out = orc.track(s, ch, rec16)
+        assert out is not None
+        assert np.array_equal(orc.stack_series(out), g[case + "_series"]), case
+
+
 def test_track_short_read_returns_none(default_record):
     g = load_golden("trk_short.npz")
     gt = load_golden("trk_default.npz")
