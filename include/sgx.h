@@ -192,6 +192,19 @@ int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset,
               const sgx_chan_init* ch, int32_t n_ch, int32_t ms,
               double* out, int32_t* ms_done);
 
+/* The same for a record of Settings.dataType samples (settings.dataType, initialize.py:60; read with
+ * np.fromfile(fid, dataType, blksize) at tracking.py:154).  data_type SGX_DT_INT8 is sgx_track; with SGX_DT_INT16 the
+ * record handle holds the file's BYTES as they are (upload 2 n bytes for n samples, little endian) and
+ * rec_file_offset, skipNumberOfBytes + codePhase and absoluteSample stay BYTE positions, exactly as the reference's
+ * fid.seek / fid.tell treat them (tracking.py:107, 167) - so a channel whose start byte is odd reads samples that
+ * straddle the file's, as it does there.  Needs the one-unit-per-workgroup kernel: 8 ceil(n_ch / 8) x units CUs free
+ * and samplingFreq >= 16 x codeFreqBasis, otherwise SGX_E_ARG. */
+#define SGX_DT_INT8  0
+#define SGX_DT_INT16 1
+int sgx_track_ex(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset,
+                 const sgx_chan_init* ch, int32_t n_ch, int32_t ms,
+                 double* out, int32_t* ms_done, int32_t data_type);
+
 /* Measured HBM rates of this device for the roofline report (no reference counterpart): a read-only stream and a
  * copy (read + write bytes counted) over `bytes` of device memory, `reps` timed launches each, GB/s. */
 int sgx_stream_rates(sgx_ctx* c, size_t bytes, int reps, double* read_gbs, double* copy_gbs);

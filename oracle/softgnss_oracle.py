@@ -276,7 +276,8 @@ def track(s, channels, record, ms=None):
         for it in range(n_ms):
             step = code_freq / fs                                       # tracking.py:148 (T1)
             blk = int(np.ceil((s.codeLength - rem_code) / step))
-            raw = np.frombuffer(rec[pos:pos + blk * isz].tobytes(), dtype=dt)   # tracking.py:154 (T2)
+            chunk = rec[pos:pos + blk * isz].tobytes()
+            raw = np.frombuffer(chunk[:len(chunk) - len(chunk) % isz], dtype=dt)   # tracking.py:154 (T2): whole items
             if len(raw) != blk:
                 return None
             pos += blk * isz

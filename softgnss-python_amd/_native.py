@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libsgx.so")
 SGX_OK = 0
 SGX_E_ARG, SGX_E_HIP, SGX_E_NOMEM, SGX_E_INDEX, SGX_E_RCCL, SGX_E_RANGE = -1, -2, -3, -4, -5, -6
 NUM_SERIES = 13
+DT_INT8, DT_INT16 = 0, 1          # sgx_track_ex data_type (include/sgx.h)
 MAX_SATS = 16
 SERIES = ("absoluteSample", "codeFreq", "carrFreq", "I_P", "I_E", "I_L", "Q_E", "Q_P", "Q_L",
           "dllDiscr", "dllDiscrFilt", "pllDiscr", "pllDiscrFilt")
@@ -87,6 +88,7 @@ _PROTOS = {
                               _P, _P, _P, _P, _P]),
     "sgx_acquire_f64": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
     "sgx_track": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, C.c_int32, _P, _P]),
+    "sgx_track_ex": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32]),
     "sgx_stream_rates": (C.c_int, [_P, C.c_size_t, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "sgx_probe_stats": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, C.c_double, _P, _P, _P, C.POINTER(C.c_int32)]),
     "sgx_find_preambles": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
@@ -292,10 +294,15 @@ class Context(object):
 
     # ---- records ----
     def upload(self, samples):
+        """int8 samples - or, for a two-byte record, the file's bytes viewed as int8 (upload_bytes)."""
         a = np.ascontiguousarray(samples, dtype=np.int8)
         h = _P()
         check(lib().sgx_if_upload(self._h, _ptr(a), a.size, C.byref(h)))
         return Record(self, h, a.size)
+
+    def upload_bytes(self, data):
+        """The raw bytes of a record of any sample type (bytes / any contiguous array), as they lie in the file."""
+        return self.upload(np.frombuffer(memoryview(np.ascontiguousarray(data)).cast('B'), dtype=np.int8))
 
     def upload_file(self, path, file_offset, n):
         """Stream bytes [file_offset, file_offset+n) of a raw int8 record file into HBM."""
@@ -371,16 +378,17 @@ class Context(object):
         check(rc)
         return out.astype(int)
 
-    def track(self, rec, chans, ms, rec_file_offset=0):
-        """chans: sequence of (prn, acquiredFreq, codePhase). Returns (series[n_ch,13,ms], ms_done)."""
+    def track(self, rec, chans, ms, rec_file_offset=0, data_type=DT_INT8):
+        """chans: sequence of (prn, acquiredFreq, codePhase). Returns (series[n_ch,13,ms], ms_done).
+        data_type DT_INT16: `rec` holds the BYTES of a little-endian int16 file (see sgx_track_ex in include/sgx.h)."""
         n = len(chans)
         arr = (ChanInit * n)()
         for i, (prn, f, cp) in enumerate(chans):
             arr[i] = ChanInit(float(f), float(cp), int(prn), 0)
         out = pinned_empty((n, NUM_SERIES, int(ms)))
         done = np.zeros(n, dtype=np.int32)
-        check(lib().sgx_track(self._h, rec._h, int(rec_file_offset), C.cast(arr, _P), n, int(ms), _ptr(out),
-                              _ptr(done)))
+        check(lib().sgx_track_ex(self._h, rec._h, int(rec_file_offset), C.cast(arr, _P), n, int(ms), _ptr(out),
+                                 _ptr(done), int(data_type)))
         return out, done
 
 

@@ -48,7 +48,8 @@ void sgx_trk_tp_launch(int n_blocks, hipStream_t st, const int8_t* rec, const in
 
 // sgx_trk2.hip: the round-2 latency-mode kernel (one unit per member, integer-atomic exchange, dedicated filter waves)
 void sgx_trk2_launch(int n_blocks, hipStream_t st, const int8_t* rec, const int8_t* codes, const TrkChan* chans,
-                     double* out, int* done, const TrkConst& K, long long* prof, unsigned long long* xch, int* err);
+                     double* out, int* done, const TrkConst& K, long long* prof, unsigned long long* xch, int* err,
+                     int sample_bytes);
 #define T2_MAXP 16
 #define T2_XCH_STRIDE 256
 
@@ -71,8 +72,12 @@ __global__ __launch_bounds__(256) void trk_fill_kernel(double* __restrict__ out,
     out[i] = zero ? 0.0 : __longlong_as_double(0x7FF0000000000000ll);
 }
 
-extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const sgx_chan_init* ch,
-                         int32_t n_ch, int32_t ms, double* out, int32_t* ms_done) {
+// sample_bytes: 1 (int8 record) or 2 (little-endian int16 record; the record handle holds the file's BYTES).  The
+// reference seeks skipNumberOfBytes + codePhase BYTES whatever the sample type and reports fid.tell(), also bytes
+// (tracking.py:107, 167); so a two-byte channel may start on an odd byte - its samples then straddle the file's - and
+// the kernel follows it there (per-channel byte shift of the record pointer, unaligned 16-byte loads).
+static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const sgx_chan_init* ch, int32_t n_ch,
+                      int32_t ms, double* out, int32_t* ms_done, int sample_bytes) {
     SGX_CHECK_ARG(c && r && ch && out && ms_done);
     SGX_CHECK_ARG(n_ch >= 1 && n_ch <= 65535 && ms >= 1);
     if (!(c->s.dllCorrelatorSpacing > 0.0 && c->s.dllCorrelatorSpacing < 1.0)) {
@@ -103,8 +108,8 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
         K.inv_2pifs_lo = (double)(inv - (long double)K.inv_2pifs_hi);
         K.inv_2pi = (double)(1.0L / two_pi);
     }
-    K.rec_len = (long long)r->n;
-    K.rec_alloc = (long long)r->n + SGX_IF_PAD;
+    K.rec_len = (long long)r->n;                         // bytes; two-byte samples: the kernel divides (per-channel shift)
+    K.rec_alloc = (long long)r->n + SGX_IF_PAD - (sample_bytes - 1);   // bytes, less the largest per-channel shift
     K.mark = nullptr;
     // 16 consecutive samples span 15 code-phase steps: below one chip (with margin for the code NCO's excursions)
     // a group holds at most one switch per ramp, which the fast map relies on
@@ -154,7 +159,9 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
                           (long long)S.skipNumberOfBytes + (long long)ch[i].codePhase, (long long)rec_file_offset);
             return SGX_E_RANGE;
         }
-        hc[(size_t)i].pos0 = p0;
+        // two-byte samples: the channel's own sample grid starts at byte (p0 & 1) of the record
+        hc[(size_t)i].pos0 = p0 / sample_bytes;
+        hc[(size_t)i].pad = (int)(p0 % sample_bytes);
     }
     const size_t elems = (size_t)n_ch * SGX_NUM_SERIES * (size_t)ms;
     // If the caller's result buffer is pinned host memory (sgx_host_alloc; the Python binding's is), the kernel's
@@ -234,7 +241,7 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
         // a record that is still streaming in is followed by the round-1 kernel's watermark variant
         const char* se2 = getenv("SGX_TRK_STREAM");
         const bool want_stream = r->loader && !r->load_done.load() && attempt == 0 && !(se2 && se2[0] == '0') && !K.multi &&
-                                 !(split_v1 == 1 && n_ch > 128);
+                                 !(split_v1 == 1 && n_ch > 128) && sample_bytes == 1;
         const bool v2 = use_v2 && attempt == 0 && !want_stream;
         if (attempt == 0) K.split = v2 ? K.n_units : split_v1;
         // Cooperating workgroups wait for each other, so all of a launch must be resident at once: one workgroup per CU
@@ -245,6 +252,11 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
             if (reserved == 0) {
                 K.split = 1;
             }
+        }
+        if (sample_bytes != 1 && !(v2 && K.split > 1)) {
+            sgx_set_error("two-byte samples are tracked by the one-unit-per-workgroup kernel only: it needs %d free CUs "
+                          "(%d channels x %d units) and samplingFreq >= 16 x the chip rate", ch8 * K.n_units, ch8, K.n_units);
+            return SGX_E_ARG;
         }
         const int n_blocks = ch8 * K.split;
         // a record that is still streaming in: the cooperative kernel follows the device watermark; the other
@@ -262,7 +274,7 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
         else if (v2 && K.split > 1) {
             const char* wh = getenv("SGX_TRK_TEST_WITHHOLD");   // test hook: launch without each channel's last member
             const int nb2 = (wh && wh[0] == '1') ? n_blocks - 8 : n_blocks;
-            sgx_trk2_launch(nb2, st, r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err);
+            sgx_trk2_launch(nb2, st, r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err, sample_bytes);
             used_v2 = true;
         }
         else if (K.split == 1 && n_ch > 128)   // (general in the sampling rate: one lane per prompt chip)
@@ -344,4 +356,18 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
     }
     hipEventElapsedTime(&c->timing.track_ms, c->ev[3], c->ev[4]);
     return SGX_OK;
+}
+
+extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const sgx_chan_init* ch,
+                         int32_t n_ch, int32_t ms, double* out, int32_t* ms_done) {
+    return track_impl(c, r, rec_file_offset, ch, n_ch, ms, out, ms_done, 1);
+}
+
+extern "C" int sgx_track_ex(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const sgx_chan_init* ch,
+                            int32_t n_ch, int32_t ms, double* out, int32_t* ms_done, int32_t data_type) {
+    if (data_type != SGX_DT_INT8 && data_type != SGX_DT_INT16) {
+        sgx_set_error("sgx_track_ex: data_type %d (SGX_DT_INT8 = 0 and SGX_DT_INT16 = 1 are tracked)", (int)data_type);
+        return SGX_E_ARG;
+    }
+    return track_impl(c, r, rec_file_offset, ch, n_ch, ms, out, ms_done, data_type == SGX_DT_INT16 ? 2 : 1);
 }

@@ -46,6 +46,11 @@
 #define T2_XABORT 192              //   abort word
 #define T2_XPLACE 208              //   [16] placement granules
 #define T2_FIX 268435456.0         // 2^28: fixed-point scale of a granule's 48-bit payload (member sums are < 2^19)
+#define T2_FIX16 524288.0          // 2^19: the same for two-byte samples (member sums are < 2^28)
+// SB = bytes per IF sample (1: int8, 2: int16).  Positions are counted in samples everywhere; only the loads, the
+// fixed-point scale and the reported file position (bytes, tracking.py:107 / fid.tell()) depend on it.
+template <int SB>
+__device__ __forceinline__ constexpr double t2_fix() { return SB == 1 ? T2_FIX : T2_FIX16; }
 #define T2_MAGIC 6755399441055744.0   // 1.5 * 2^52: fl(x + MAGIC) holds round(x) in its low mantissa bits
 #define T2_POLL_BUDGET (1 << 20)
 
@@ -271,8 +276,40 @@ struct T2Shared {
 #define T2_FP_PRINT(role, lo, hi)
 #endif
 
+// a lane's 16 samples as loaded: one 16-byte word of int8, or two of int16
+template <int SB> struct T2Raw;
+template <> struct T2Raw<1> { uint4 a; };
+template <> struct T2Raw<2> { uint4 a, b; };
+
+template <int SB>
+__device__ __forceinline__ T2Raw<SB> t2_load(const int8_t* __restrict__ rec, long long first_sample, long long limit) {
+    T2Raw<SB> r;
+    if constexpr (SB == 1) {
+        r.a = load_group(rec, first_sample, limit);
+    } else {
+        r.a = load_group(rec, first_sample * 2, limit);
+        r.b = load_group(rec, first_sample * 2 + 16, limit);
+    }
+    return r;
+}
+
+// 16 int16 samples -> fp64, samples before the block's first one (i0 + b < 0) zeroed
+__device__ __forceinline__ void t2_convert(const T2Raw<2>& raw, int i0, double (&xd)[16]) {
+#define T2_CV(b, w, hi)                                                                          \
+    {                                                                                            \
+        const int xi_ = hi ? ((int)(w) >> 16) : (int)(short)((w) & 0xFFFF);                      \
+        xd[b] = (i0 + b >= 0) ? (double)xi_ : 0.0;                                               \
+    }
+    T2_CV(0, raw.a.x, 0) T2_CV(1, raw.a.x, 1) T2_CV(2, raw.a.y, 0) T2_CV(3, raw.a.y, 1)
+    T2_CV(4, raw.a.z, 0) T2_CV(5, raw.a.z, 1) T2_CV(6, raw.a.w, 0) T2_CV(7, raw.a.w, 1)
+    T2_CV(8, raw.b.x, 0) T2_CV(9, raw.b.x, 1) T2_CV(10, raw.b.y, 0) T2_CV(11, raw.b.y, 1)
+    T2_CV(12, raw.b.z, 0) T2_CV(13, raw.b.z, 1) T2_CV(14, raw.b.w, 0) T2_CV(15, raw.b.w, 1)
+#undef T2_CV
+}
+
 // 16 int8 samples -> fp64, samples before the block's first one (i0 + b < 0) zeroed
-__device__ __forceinline__ void t2_convert(const uint4& raw, int i0, double (&xd)[16]) {
+__device__ __forceinline__ void t2_convert(const T2Raw<1>& raw1, int i0, double (&xd)[16]) {
+    const uint4& raw = raw1.a;
 #define T2_CV(b, w, sh)                                                                          \
     {                                                                                            \
         const int xi_ = (sh == 24) ? ((int)(w) >> 24) : (int)(signed char)(((w) >> sh) & 0xFF);  \
@@ -286,12 +323,13 @@ __device__ __forceinline__ void t2_convert(const uint4& raw, int i0, double (&xd
 }
 
 // ================================ MAP (waves 0-3) ================================
+template <int SB>
 __device__ __forceinline__ int t2_map_role(T2Shared& S, const int8_t* __restrict__ rec, long long rec_alloc, int ms,
                                            long long pos0, int member, int tid, unsigned long long* __restrict__ xbase,
                                            bool fast, bool prof_on, bool prof_any) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const long long limit = rec_alloc - 16;
+    const long long limit = rec_alloc - 16;                  // bytes: the last 16-byte word that may be loaded
     const int g = (tid & 255) + member * T2_MAP;             // the lane's group inside the block's aligned window
     const long long lane_off = (long long)g * 16;
     T2_FP_DECL
@@ -300,7 +338,7 @@ __device__ __forceinline__ int t2_map_role(T2Shared& S, const int8_t* __restrict
     double xd[16];
     int i0, ilo;
     double ilod;
-    uint4 raw;
+    T2Raw<SB> raw;
 
 #define T2_PREPARE(POS_NEXT)                                                                                   \
     do {                                                                                                       \
@@ -311,7 +349,7 @@ __device__ __forceinline__ int t2_map_role(T2Shared& S, const int8_t* __restrict
         t2_convert(raw, i0, xd);                                                                               \
     } while (0)
 
-    raw = load_group(rec, (pos0 & ~15ll) + lane_off, limit);
+    raw = t2_load<SB>(rec, (pos0 & ~15ll) + lane_off, limit);
     T2_PREPARE(pos0);
     int it = 0;
     for (; it < ms; ++it) {
@@ -329,7 +367,7 @@ __device__ __forceinline__ int t2_map_role(T2Shared& S, const int8_t* __restrict
         __builtin_amdgcn_s_setprio(2);
         const int blk = hd.x;
         const long long pos_next = pos + blk;
-        const uint4 nraw = load_group(rec, (pos_next & ~15ll) + lane_off, limit);   // next block's bytes
+        const T2Raw<SB> nraw = t2_load<SB>(rec, (pos_next & ~15ll) + lane_off, limit);   // next block's bytes
         T2PROBE(prof_on, 0);   // parameters read, next block's load issued
         int kE, kP, kL, swE, swP, swL;
         bool bad = false;
@@ -465,7 +503,7 @@ __device__ __forceinline__ int t2_map_role(T2Shared& S, const int8_t* __restrict
             v = v + dpp_mov<0x141>(v);   // row_half_mirror: the other quad of the eight
             if (pp == 0 && word < 6) {
                 // {16-bit epoch tag | 48-bit two's-complement fixed point}, ONE aligned 8-byte store
-                const double t = __builtin_fma(v, T2_FIX, T2_MAGIC);
+                const double t = __builtin_fma(v, t2_fix<SB>(), T2_MAGIC);
                 const unsigned long long q = (unsigned long long)(__double_as_longlong(t) - __double_as_longlong(T2_MAGIC));
                 const unsigned long long gran = ((unsigned long long)((unsigned)(it + 1) & 0xFFFFu) << 48) | (q & 0xFFFFFFFFFFFFull);
                 granule_store(xbase + T2_XG + par * 96 + word * 16 + member, gran, fast);
@@ -486,6 +524,7 @@ __device__ __forceinline__ int t2_map_role(T2Shared& S, const int8_t* __restrict
 }
 
 // ================================ PLL (wave 4) ================================
+template <int SB>
 __device__ __forceinline__ int t2_pll_role(T2Shared& S, const TrkConst& K, const TrkChan& cc, int member, int lane, int P,
                                            int ch, unsigned long long* __restrict__ xbase, int* __restrict__ err,
                                            bool prof_on, long long* __restrict__ prof) {
@@ -570,7 +609,7 @@ __device__ __forceinline__ int t2_pll_role(T2Shared& S, const TrkConst& K, const
         q += dpp_movl<0x4E>(q);
         q += dpp_movl<0x141>(q);
         q += dpp_movl<0x140>(q);
-        const double v = (double)q * (1.0 / T2_FIX);
+        const double v = (double)q * (1.0 / t2_fix<SB>());
         const double I_P = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 0),
                                             __builtin_amdgcn_readlane(__double2loint(v), 0));
         const double Q_P = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16),
@@ -626,14 +665,14 @@ __device__ __forceinline__ int t2_pll_role(T2Shared& S, const TrkConst& K, const
 }
 
 // ================================ DLL (wave 5) ================================
+template <int SB>
 __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const T2DllConst& D, T2DllState st, int member,
                                            int lane, int P, int ch, unsigned long long* __restrict__ xbase,
-                                           int* __restrict__ err, bool prof_on) {
+                                           int* __restrict__ err, bool prof_on, long long file_off) {
     // tracking.py:114-121; `st` describes block 0 (its chain and early parts are posted)
     double oldCodeNco = 0.0, oldCodeErr = 0.0;
     double k_a = K.k_code_a, k_b = K.k_code_b, basis = K.code_basis;
     T2_PIN(k_a); T2_PIN(k_b); T2_PIN(basis);
-    const long long file_off = K.file_off;
     const int ms = K.ms;
     // lane = 16 row + member polls that member's granule of word 2 + row: rows I_E, Q_E, I_L, Q_L
     const int l4 = lane & 3;
@@ -654,7 +693,7 @@ __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const
             // I_E -> 4, Q_E -> 6, I_L -> 5, Q_L -> 8 (series order of _native.SERIES)
             if (lane < 4) R[lane == 0 ? 4 : (lane == 1 ? 6 : (lane == 2 ? 5 : 8))] = r_v;
             if (lane == 0) {
-                R[0] = (double)(st.pos + file_off);   // position after block it - 1 = first sample of block it
+                R[0] = (double)(st.pos * SB + file_off);   // position after block it - 1 = first sample of block it
                 R[1] = r_cf;
                 R[9] = r_err;
                 R[10] = r_nco;
@@ -693,7 +732,7 @@ __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const
         q += dpp_movl<0x4E>(q);
         q += dpp_movl<0x141>(q);
         q += dpp_movl<0x140>(q);
-        const double vr = (double)q * (1.0 / T2_FIX);
+        const double vr = (double)q * (1.0 / t2_fix<SB>());
         const int vh = __double2hiint(vr), vl = __double2loint(vr);
         const int h0 = __builtin_amdgcn_readlane(vh, 0), l0 = __builtin_amdgcn_readlane(vl, 0);
         const int h1 = __builtin_amdgcn_readlane(vh, 16), l1 = __builtin_amdgcn_readlane(vl, 16);
@@ -737,7 +776,7 @@ __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const
         double* R = S.rec[(it - 1) & 1];
         if (lane < 4) R[lane == 0 ? 4 : (lane == 1 ? 6 : (lane == 2 ? 5 : 8))] = r_v;
         if (lane == 0) {
-            R[0] = (double)(st.pos + file_off);
+            R[0] = (double)(st.pos * SB + file_off);
             R[1] = r_cf;
             R[9] = r_err;
             R[10] = r_nco;
@@ -769,6 +808,7 @@ __device__ __forceinline__ int t2_rec_role(T2Shared& S, int ms, int member, int 
     return it;
 }
 
+template <int SB>
 __global__ __launch_bounds__(T2_THREADS) void trk2_kernel(const int8_t* __restrict__ rec, const int8_t* __restrict__ codes,
                                                           const TrkChan* __restrict__ chans, double* __restrict__ out,
                                                           int* __restrict__ ms_done, TrkConst K,
@@ -858,7 +898,7 @@ __global__ __launch_bounds__(T2_THREADS) void trk2_kernel(const int8_t* __restri
         D.spacing = K.spacing;
         D.inv_nb_lane = 1.0 / (double)(K.nb_base + (lane & 7));
         D.nb_base = K.nb_base;
-        D.rec_len = K.rec_len;
+        D.rec_len = (K.rec_len - cc.pad) / SB;      // samples on the channel's grid (cc.pad: its byte shift, SB = 2 only)
         st0 = t2_code_chain(D, K.code_basis, 0.0, cc.pos0, false, P, S.code[0], lane);
         const double off = ((lane & 3) == 0) ? -K.spacing : (((lane & 3) == 2) ? K.spacing : 0.0);
         if (lane < 3) S.code[0].start[lane] = 0.0 + off;
@@ -876,9 +916,9 @@ __global__ __launch_bounds__(T2_THREADS) void trk2_kernel(const int8_t* __restri
 
     double* __restrict__ o = out + (long long)ch * SGX_NUM_SERIES * K.ms;
     int done;
-    if (wave < 4) done = t2_map_role(S, rec, K.rec_alloc, K.ms, cc.pos0, member, tid, xbase, fast, prof_on, prof != nullptr);
-    else if (wave == 4) done = t2_pll_role(S, K, cc, member, lane, P, ch, xbase, err, prof_on, prof);
-    else if (wave == 5) done = t2_dll_role(S, K, D, st0, member, lane, P, ch, xbase, err, prof_on);
+    if (wave < 4) done = t2_map_role<SB>(S, rec + cc.pad, K.rec_alloc, K.ms, cc.pos0, member, tid, xbase, fast, prof_on, prof != nullptr);
+    else if (wave == 4) done = t2_pll_role<SB>(S, K, cc, member, lane, P, ch, xbase, err, prof_on, prof);
+    else if (wave == 5) done = t2_dll_role<SB>(S, K, D, st0, member, lane, P, ch, xbase, err, prof_on, K.file_off + cc.pad);
     else done = t2_rec_role(S, K.ms, member, lane, o);
 
     // a channel that was given up reports the blocks completed before the abort
@@ -889,6 +929,8 @@ __global__ __launch_bounds__(T2_THREADS) void trk2_kernel(const int8_t* __restri
 }
 
 void sgx_trk2_launch(int n_blocks, hipStream_t st, const int8_t* rec, const int8_t* codes, const TrkChan* chans,
-                     double* out, int* done, const TrkConst& K, long long* prof, unsigned long long* xch, int* err) {
-    trk2_kernel<<<n_blocks, T2_THREADS, 0, st>>>(rec, codes, chans, out, done, K, prof, xch, err);
+                     double* out, int* done, const TrkConst& K, long long* prof, unsigned long long* xch, int* err,
+                     int sample_bytes) {
+    if (sample_bytes == 2) trk2_kernel<2><<<n_blocks, T2_THREADS, 0, st>>>(rec, codes, chans, out, done, K, prof, xch, err);
+    else trk2_kernel<1><<<n_blocks, T2_THREADS, 0, st>>>(rec, codes, chans, out, done, K, prof, xch, err);
 }

@@ -60,7 +60,7 @@ struct TrkChan {
     double acquiredFreq;
     long long pos0;   // record index of the channel's first sample
     int prn;          // 1-based, 0 = off
-    int pad;
+    int pad;          // two-byte samples: byte shift (0 / 1) of the channel's sample grid in the record; else 0
 };
 
 // Per-block parameters: code part written by wave 1, carrier part by wave 0, read by everybody.

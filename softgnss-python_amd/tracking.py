@@ -30,13 +30,21 @@ class TrackingResult(Result):
         self.series = None          # float64[n_active, 13, ms] in _native.SERIES order
         self.kernel_ms = None       # HIP-event duration of the tracking kernel
 
+    def _data_type(self):
+        """Settings.dataType -> (sgx_track_ex data_type, bytes per sample).  The reference reads np.fromfile(fid,
+        dataType, blksize) (tracking.py:154) but seeks and tells in BYTES (tracking.py:107, 167): both are kept."""
+        dt = np.dtype(self._settings.dataType)
+        if dt == np.dtype(np.int8):
+            return _native.DT_INT8, 1
+        if dt == np.dtype('<i2'):
+            return _native.DT_INT16, 2
+        raise TypeError("the GPU path tracks int8 and int16 IF samples (Settings.dataType %r)"
+                        % (self._settings.dataType,))
+
     def _window(self, fid, first, need):
         """Bytes [first, first+need) of the reference's file, as an HBM record."""
         ctx = engine.get_context(self._settings, self._device)
-        if np.dtype(self._settings.dataType) != np.dtype(np.int8):
-            # the reference seeks in bytes but counts in samples (tracking.py:107), i.e. it too is only
-            # consistent for one-byte samples
-            raise TypeError("the GPU path takes int8 IF samples (Settings.dataType %r)" % (self._settings.dataType,))
+        dtype_code, isz = self._data_type()
         # a real file on disk: stream it natively (pinned double buffering, no numpy copy of the record), and let
         # tracking start while the transfer is still running
         name = getattr(fid, 'name', None)
@@ -55,8 +63,8 @@ class TrackingResult(Result):
     def track(self, fid):
         """Code and carrier tracking of all channels (reference tracking.py:13-295).
 
-        fid   open binary file of int8 samples (seek/read/tell/close), or a DeviceFile over a
-              record already in HBM.  Each active channel starts at byte
+        fid   open binary file of Settings.dataType samples (int8 or int16; seek/read/tell/close), or a
+              DeviceFile over a record already in HBM (for int16: the file's bytes, Context.upload_bytes).  Each active channel starts at byte
               skipNumberOfBytes + codePhase (tracking.py:107).
         On a short record the reference prints a message, closes fid and returns None without
         setting results (tracking.py:159-163); so does this method.
@@ -73,6 +81,7 @@ class TrackingResult(Result):
             return
         chans = [(int(channel[i].PRN), float(channel[i].acquiredFreq), float(channel[i].codePhase))
                  for i in active]
+        dtype_code, isz = self._data_type()
         own = None
         if isinstance(fid, DeviceFile):
             rec, file_off = fid.record, fid.file_offset
@@ -80,11 +89,11 @@ class TrackingResult(Result):
             n = settings.samplesPerCode
             first = int(settings.skipNumberOfBytes + min(c[2] for c in chans))
             last = int(settings.skipNumberOfBytes + max(c[2] for c in chans))
-            need = (last - first) + ms * (n + 2) + n      # a block is at most samplesPerCode + 1 long
+            need = (last - first) + (ms * (n + 2) + n) * isz      # a block is at most samplesPerCode + 1 long
             own = rec = self._window(fid, first, need)
             file_off = first
         try:
-            series, done = ctx.track(rec, chans, ms, rec_file_offset=file_off)
+            series, done = ctx.track(rec, chans, ms, rec_file_offset=file_off, data_type=dtype_code)
             self.kernel_ms = ctx.timing()["track_ms"]
         finally:
             if own is not None:

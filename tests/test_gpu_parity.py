@@ -1089,12 +1089,88 @@ def test_tiny_runs_and_unsupported_sample_type(default_record):
         assert np.array_equal(t.series[:, 0], g["series"][:, 0, :ms])
         assert _trk_err(t.series, g["series"][:, :, :ms]) < TRK_TOL
     s, t = _golden_tracker(m, g, ms=5)
-    s.dataType = 'int16'
+    s.dataType = 'float32'
     with tempfile.NamedTemporaryFile(suffix=".bin") as f:
         default_record[:8 * 38192].tofile(f.name)
         with open(f.name, "rb") as fid:
             with pytest.raises(TypeError):
                 t.track(fid)
+
+
+def _int16_tracker(m, g, case, ms=None, prn=None, freq=None, phase=None, skip=None):
+    s = m.Settings()
+    s.dataType = 'int16'
+    prn = g[case + "_PRN"] if prn is None else prn
+    s.numberOfChannels = len(prn)
+    s.msToProcess = float(int(g["ms"]) if ms is None else ms)
+    s.skipNumberOfBytes = int(g[case + "_skip"]) if skip is None else skip
+    a = m.AcquisitionResult(s, device=0)
+    a._channels = np.rec.fromarrays([prn, g[case + "_acquiredFreq"] if freq is None else freq,
+                                     g[case + "_codePhase"] if phase is None else phase, ['T'] * len(prn)],
+                                    names='PRN,acquiredFreq,codePhase,status')
+    return s, m.TrackingResult(a, device=0)
+
+
+def test_track_int16_record_matches_reference():
+    """Settings.dataType = 'int16' (tracking.py:154) with the reference's byte seeks and byte positions
+    (tracking.py:107, 255): its own outputs (tests/golden/trk_int16.npz) for a locked channel and for two channels
+    started where the byte seek lands; through a real file and through a record already in HBM."""
+    g = load_golden("trk_int16.npz")
+    m = pkg()
+    rec16 = (m.synth.generate(scene_from_json(g["scene"]), int(g["n_samples"])).astype(np.int16)
+             * int(g["scale"])).astype("<i2")
+    for case in ("locked", "as_is"):
+        want = g[case + "_series"]
+        s, t = _int16_tracker(m, g, case)
+        with tempfile.NamedTemporaryFile(suffix=".bin") as f:
+            rec16.tofile(f.name)
+            with open(f.name, "rb") as fid:
+                t.track(fid)
+                assert fid.tell() == int(want[-1, 0, -1])
+        assert t.series.shape == want.shape
+        assert np.array_equal(t.series[:, 0], want[:, 0]), case          # absoluteSample (bytes) bit-exact
+        assert _trk_err(t.series, want) < TRK_TOL, case
+        assert np.max(np.abs(t.series[:, 1] - want[:, 1])) < 1e-6
+        assert np.max(np.abs(t.series[:, 2] - want[:, 2])) < 1e-5
+        # the same from HBM
+        ctx = m.engine.get_context(s, 0)
+        dev = m.DeviceFile(ctx.upload_bytes(rec16), 0)
+        s2, t2 = _int16_tracker(m, g, case)
+        t2.track(dev)
+        # (another alignment of the blocks in the record: another summation order, equal to rounding)
+        assert np.array_equal(t2.series[:, 0], t.series[:, 0]) and _trk_err(t2.series, t.series) < 1e-9
+
+
+def test_track_int16_odd_start_byte_and_short_record():
+    """A channel whose start byte skipNumberOfBytes + codePhase is odd reads int16 values that straddle the file's
+    samples (the reference's fid.seek takes bytes, tracking.py:107) - followed as is, against the oracle; and the
+    short-read exit (tracking.py:159-163) counted in bytes."""
+    g = load_golden("trk_int16.npz")
+    m = pkg()
+    rec16 = (m.synth.generate(scene_from_json(g["scene"]), int(g["n_samples"])).astype(np.int16)
+             * int(g["scale"])).astype("<i2")
+    prn = np.array([int(g["locked_PRN"][0])] * 3)
+    freq = np.array([float(g["locked_acquiredFreq"][0])] * 3)
+    phase = np.array([12345.0, 2 * 12346.0, 7.0])        # odd byte, the sample-aligned start (locks), odd byte
+    ms = 40
+    s, t = _int16_tracker(m, g, "locked", ms=ms, prn=prn, freq=freq, phase=phase, skip=0)
+    so = orc.OracleSettings(numberOfChannels=3, msToProcess=float(ms), dataType='int16', skipNumberOfBytes=0)
+    want = orc.stack_series(orc.track(so, dict(PRN=prn, acquiredFreq=freq, codePhase=phase, status=['T'] * 3), rec16))
+    dev = m.DeviceFile(m.engine.get_context(s, 0).upload_bytes(rec16), 0)
+    t.track(dev)
+    assert np.array_equal(t.series[:, 0], want[:, 0])
+    assert _trk_err(t.series, want) < TRK_TOL
+    assert np.sqrt(np.mean(want[1, 3] ** 2)) > 2 * np.sqrt(np.mean(want[0, 3] ** 2))    # only the aligned one locks
+    # short record: one byte fewer than the last block of the last channel needs -> the reference's exit
+    end = int(want[:, 0, -1].max())
+    for cut, ok in ((end, True), (end - 1, False)):
+        s3, t3 = _int16_tracker(m, g, "locked", ms=ms, prn=prn, freq=freq, phase=phase, skip=0)
+        raw = rec16.view(np.int8)[:cut]
+        dev = m.DeviceFile(m.engine.get_context(s3, 0).upload_bytes(raw), 0)
+        t3.track(dev)
+        assert (t3.series is not None) == ok
+        o = orc.track(so, dict(PRN=prn, acquiredFreq=freq, codePhase=phase, status=['T'] * 3), raw)
+        assert (o is not None) == ok
 
 
 @pytest.mark.parametrize("seed", list(range(31, 43)))
