@@ -11,7 +11,7 @@ import weakref
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libsgx.so")
+LIB_PATH = os.environ.get("SGX_LIB") or os.path.join(HERE, "lib", "libsgx.so")   # SGX_LIB: another build of the same library (kernel variants side by side)
 
 SGX_OK = 0
 SGX_E_ARG, SGX_E_HIP, SGX_E_NOMEM, SGX_E_INDEX, SGX_E_RCCL, SGX_E_RANGE = -1, -2, -3, -4, -5, -6

@@ -645,7 +645,17 @@ __device__ __forceinline__ void lds_odd_pass_split(cplx* __restrict__ buf, const
 // W_L^t, t < L, into LDS (from the plan's table of the sub-transform's roots)
 template <int L, int TPB>
 __device__ __forceinline__ void lds_fill_twiddles(cplx* __restrict__ twl, const cplx* __restrict__ tab, int tid) {
-    for (int t = tid; t < L; t += TPB) twl[t] = tab[t];
+    constexpr int PER = (L + TPB - 1) / TPB;
+    static_assert(PER <= 4, "four staging registers");
+    cplx v0, v1, v2, v3;   // (named: see the rows kernel)
+    if (PER > 0 && tid < L) v0 = tab[tid];
+    if (PER > 1 && tid + TPB < L) v1 = tab[tid + TPB];
+    if (PER > 2 && tid + 2 * TPB < L) v2 = tab[tid + 2 * TPB];
+    if (PER > 3 && tid + 3 * TPB < L) v3 = tab[tid + 3 * TPB];
+    if (PER > 0 && tid < L) twl[tid] = v0;
+    if (PER > 1 && tid + TPB < L) twl[tid + TPB] = v1;
+    if (PER > 2 && tid + 2 * TPB < L) twl[tid + 2 * TPB] = v2;
+    if (PER > 3 && tid + 3 * TPB < L) twl[tid + 3 * TPB] = v3;
 }
 
 // MODE 0: plain.  MODE 1: input = conj(X[(i + shift) mod n]) * F[i] (correlation product, acquisition.py:120-123).
@@ -679,19 +689,37 @@ __global__ __launch_bounds__(TPB) void fft4_cols_kernel(F4Args a) {
         pf = a.mul_f + (long long)prn * a.n;
         shift = bm.y;
     }
-    for (int e = tid; e < N1 * C; e += TPB) {
-        const int n1 = e / C, c = e % C;
-        const long long idx = (long long)n1 * N2 + c0 + c;
-        cplx val;
-        if (MODE == 1) {
-            long long ix = idx + shift;
-            if (ix >= a.n) ix -= a.n;
-            const cplx xv = px[ix], fv = pf[idx];
-            val = make_double2(__builtin_fma(xv.x, fv.x, xv.y * fv.y), __builtin_fma(xv.x, fv.y, -(xv.y * fv.x)));
-        } else {
-            val = (idx < a.nonzero_len) ? in[idx] : make_double2(0.0, 0.0);
+    // every load of the tile is issued before the first one is waited for (a rolled loop runs one memory round trip
+    // per element and thread, ~1-2 us each)
+    {
+        constexpr int PER = (N1 * C + TPB - 1) / TPB;
+        cplx xv[PER], fv[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = tid + i * TPB;
+            if (e < N1 * C) {
+                const long long idx = (long long)(e / C) * N2 + c0 + e % C;
+                if (MODE == 1) {
+                    long long ix = idx + shift;
+                    if (ix >= a.n) ix -= a.n;
+                    xv[i] = px[ix];
+                    fv[i] = pf[idx];
+                } else {
+                    xv[i] = (idx < a.nonzero_len) ? in[idx] : make_double2(0.0, 0.0);
+                }
+            }
         }
-        buf[e] = val;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = tid + i * TPB;
+            if (e < N1 * C) {
+                cplx val = xv[i];
+                if (MODE == 1)
+                    val = make_double2(__builtin_fma(xv[i].x, fv[i].x, xv[i].y * fv[i].y),
+                                       __builtin_fma(xv[i].x, fv[i].y, -(xv[i].y * fv[i].x)));
+                buf[e] = val;
+            }
+        }
     }
     __syncthreads();
     // R3 = 4: the second radix is a large odd one whose butterflies are split over four waves each
@@ -699,18 +727,59 @@ __global__ __launch_bounds__(TPB) void fft4_cols_kernel(F4Args a) {
     lds_radix_pass<N1, R1, 1, C, C, 1, TPB, true>(buf, tw, a.wr[0], tid);
     if constexpr (R3 == 4) lds_odd_pass_split<N1, R2, R1, C, C, 1, TPB, true, 4>(buf, tw, a.wr[1], tid);
     else lds_radix_pass<N1, R2, R1, C, C, 1, TPB, true>(buf, tw, a.wr[1], tid);
+    // element (k1, n2) times W_n^(n2 k1).  A thread keeps its column n2 and advances k1 by STEP: one table look-up for
+    // its first element and one for the step factor W_n^(n2 STEP), the others by recurrence (<= 6 products: a few ulp)
+    static_assert(TPB % C == 0, "a thread keeps its column");
+    constexpr int STEP = TPB / C;
     cplx* __restrict__ out = a.out + row * a.n;
-    for (int e = tid; e < N1 * C; e += TPB) {
-        const int k1 = e / C, c = e % C;
-        const long long t = (long long)(c0 + c) * k1;   // < n
-        out[(long long)k1 * N2 + c0 + c] = cmul(buf[e], f4_twiddle(a, t));
+    const int n2 = c0 + tid % C, k1b = tid / C;
+    cplx w = f4_twiddle(a, (long long)n2 * k1b);
+    const cplx ws = f4_twiddle(a, (long long)n2 * STEP);
+#pragma unroll
+    for (int i = 0; i < (N1 + STEP - 1) / STEP; ++i) {
+        const int k1 = k1b + i * STEP;
+        if (k1 < N1) out[(long long)k1 * N2 + n2] = cmul(buf[k1 * C + tid % C], w);
+        w = cmul(w, ws);
+    }
+}
+
+// (value, first index) maximum over a workgroup of TPB threads; result valid in thread 0.  sv / si: TPB / 64 slots each.
+template <int TPB>
+__device__ __forceinline__ void wg_argmax(double& best, int& arg, double* __restrict__ sv, int* __restrict__ si, int tid) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_down(best, off, 64);
+        const int oi = __shfl_down(arg, off, 64);
+        if (ov > best || (ov == best && oi < arg)) {
+            best = ov;
+            arg = oi;
+        }
+    }
+    if ((tid & 63) == 0) {
+        sv[tid >> 6] = best;
+        si[tid >> 6] = arg;
+    }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int w = 1; w < TPB / 64; ++w) {
+            const double ov = sv[w];
+            const int oi = si[w];
+            if (ov > best || (ov == best && oi < arg)) {
+                best = ov;
+                arg = oi;
+            }
+        }
     }
 }
 
 // MODE 0: store X.  MODE 2: |X|^2 inv_n^2 (summed over sum_blocks input rows), per-workgroup (max, first index).
 // MODE 3: the same powers stored to pout (the rows the second-peak search reads).
+#ifndef F4_ROWS_WAVES
+#define F4_ROWS_WAVES 3
+#endif
 template <int N1, int N2, int CB, int TPB, int R1, int R2, int R3, int MODE>
-__global__ __launch_bounds__(TPB) void fft4_rows_kernel(F4Args a) {
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(F4_ROWS_WAVES))) void fft4_rows_kernel(F4Args a) {
     extern __shared__ __attribute__((aligned(16))) char f4_smem[];
     cplx* __restrict__ buf = reinterpret_cast<cplx*>(f4_smem);   // [CB][N2]
     cplx* __restrict__ twl = buf + CB * N2;                      // [N2]: W_N2^t
@@ -726,8 +795,21 @@ __global__ __launch_bounds__(TPB) void fft4_rows_kernel(F4Args a) {
     const int nb = (MODE == 0 || a.sum_blocks < 1) ? 1 : a.sum_blocks;
     for (int b = 0; b < nb; ++b) {
         const cplx* __restrict__ in = a.in + (row * nb + b) * a.n + (long long)k10 * N2;
-        if (b > 0) __syncthreads();
-        for (int e = tid; e < E; e += TPB) buf[e] = in[e];
+        {
+            // every load of the tile in flight together (a rolled loop runs one HBM round trip per element and thread);
+            // named registers: an array here, inside the block loop, is left in scratch memory by the compiler
+            static_assert(PER <= 10, "ten staging registers");
+            cplx p0, p1, p2, p3, p4, p5, p6, p7, p8, p9;
+#define F4_LD(i, r) if (PER > i && tid + i * TPB < E) r = in[tid + i * TPB];
+            F4_LD(0, p0) F4_LD(1, p1) F4_LD(2, p2) F4_LD(3, p3) F4_LD(4, p4)
+            F4_LD(5, p5) F4_LD(6, p6) F4_LD(7, p7) F4_LD(8, p8) F4_LD(9, p9)
+#undef F4_LD
+            if (b > 0) __syncthreads();
+#define F4_ST(i, r) if (PER > i && tid + i * TPB < E) buf[tid + i * TPB] = r;
+            F4_ST(0, p0) F4_ST(1, p1) F4_ST(2, p2) F4_ST(3, p3) F4_ST(4, p4)
+            F4_ST(5, p5) F4_ST(6, p6) F4_ST(7, p7) F4_ST(8, p8) F4_ST(9, p9)
+#undef F4_ST
+        }
         __syncthreads();
         const TwDirect tw{twl};
         lds_radix_pass<N2, R1, 1, CB, 1, N2, TPB, false>(buf, tw, a.wr[0], tid);
@@ -763,7 +845,7 @@ __global__ __launch_bounds__(TPB) void fft4_rows_kernel(F4Args a) {
         return;
     }
     double best = -1.0;
-    int arg = 0;
+    int arg = 0x7FFFFFFF;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int e = tid + i * TPB;
@@ -777,33 +859,20 @@ __global__ __launch_bounds__(TPB) void fft4_rows_kernel(F4Args a) {
     }
     __syncthreads();
     double* s_v = reinterpret_cast<double*>(f4_smem);
-    int* s_i = reinterpret_cast<int*>(f4_smem + sizeof(double) * TPB);
-    s_v[tid] = best;
-    s_i[tid] = arg;
-    __syncthreads();
-    for (int st = TPB / 2; st > 0; st >>= 1) {
-        if (tid < st) {
-            const double ov = s_v[tid + st];
-            const int oi = s_i[tid + st];
-            if (ov > s_v[tid] || (ov == s_v[tid] && oi < s_i[tid])) {
-                s_v[tid] = ov;
-                s_i[tid] = oi;
-            }
-        }
-        __syncthreads();
-    }
+    int* s_i = reinterpret_cast<int*>(f4_smem + sizeof(double) * (TPB / 64));
+    wg_argmax<TPB>(best, arg, s_v, s_i, tid);
     if (tid == 0) {
-        a.pmax[row * gridDim.x + blockIdx.x] = s_v[0];
-        a.parg[row * gridDim.x + blockIdx.x] = s_i[0];
+        a.pmax[row * gridDim.x + blockIdx.x] = best;
+        a.parg[row * gridDim.x + blockIdx.x] = arg;
     }
 }
 
 // ---- the plan the acquisition uses: n = 38192 = 176 x 217 (16*11, 7*31); other lengths keep the pass-per-radix path ----
 #define F4_N1 217          // columns: 7 x 31 (the radix-31 butterflies split over four waves each)
 #define F4_N2 176          // rows: 16 x 11
-#define F4_C 16            // 256 contiguous bytes per column-tile row; 59 KB of LDS: two workgroups per CU
+#define F4_C 8             // 128 contiguous bytes per column-tile row; 31 KB of LDS, 148 VGPRs: three workgroups per CU
 #define F4_CB 7            // 217 = 31 x 7 rows; 22 KB of LDS: seven workgroups per CU
-#define F4_TPB 512         // columns kernel: 496 radix-7 butterflies, 112 radix-31 butterflies x 4 waves
+#define F4_TPB 256         // columns kernel: 248 radix-7 butterflies, 56 radix-31 butterflies x 4 waves
 #define F4_TPB_ROWS 128    // rows kernel: 77 radix-16 / 112 radix-11 butterflies
 
 bool sgx_fft4_supported(int64_t n) { return n == (int64_t)F4_N1 * F4_N2; }
