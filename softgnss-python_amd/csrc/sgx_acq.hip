@@ -12,6 +12,7 @@
 //   fine     (x - mean) * code(floor((ts*k)/tc) mod 1023), zero-padded 2^22-point FFT, argmax of |X|
 // HBM-resident scratch replaces the reference's per-PRN numpy temporaries.
 #include <math.h>
+#include <chrono>
 
 #include "sgx_internal.h"
 
@@ -231,7 +232,27 @@ __global__ __launch_bounds__(256) void acq_sum_kernel(const int8_t* __restrict__
     }
     for (long long i = head + n16 * 16 + gid; i < n; i += gsz) acc += x[i];
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
-    if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long*)out, (unsigned long long)acc);
+    // one atomic per workgroup (a thousand 64-bit atomics on one address took most of this kernel's time)
+    __shared__ long long s_acc[4];
+    if ((threadIdx.x & 63) == 0) s_acc[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicAdd((unsigned long long*)out, (unsigned long long)(s_acc[0] + s_acc[1] + s_acc[2] + s_acc[3]));
+}
+
+// Call set-up in one launch: the PRN list and the bin map (by value) to their device tables, the accumulators zeroed.
+struct AcqSetup {
+    int prn[32];
+    int2 bin[ACQ_MAX_BINS];
+    int n_prn, n_bins;
+};
+__global__ __launch_bounds__(128) void acq_setup_kernel(AcqSetup a, int* __restrict__ d_prn, int2* __restrict__ d_bin,
+                                                        long long* __restrict__ d_sum, double* __restrict__ d_second) {
+    const int t = threadIdx.x;
+    if (t < a.n_prn) d_prn[t] = a.prn[t];
+    if (t < a.n_bins) d_bin[t] = a.bin[t];
+    if (t < 32) d_second[t] = 0.0;
+    if (t == 0) d_sum[0] = 0;
 }
 
 // the same for an fp64 signal: one workgroup, fixed summation order (reproducible); the double's bits go to the same slot
@@ -710,8 +731,6 @@ static int acquire_fine(sgx_ctx* c, SgxSig x, size_t n_samples, const std::vecto
             return rc;
         if ((rc = ensure_buf((void**)&c->d_fine[1], &c->cap_f1, (size_t)n_rows * sizeof(cplx) * (size_t)npts)) != SGX_OK)
             return rc;
-        SGX_HIP(hipMemcpyAsync(d_detprn, det_prn.data(), sizeof(int) * (size_t)n_det, hipMemcpyHostToDevice, st));
-        SGX_HIP(hipMemcpyAsync(d_detph, det_phase.data(), sizeof(int) * (size_t)n_det, hipMemcpyHostToDevice, st));
         const double tc1 = 1.0 / S.codeFreqBasis;
         const char* fv1 = getenv("SGX_ACQ_FINE_V1");
         const bool fine2 = sgx_fft_fine_supported(npts) && !(fv1 && fv1[0] == '1');
@@ -732,10 +751,12 @@ static int acquire_fine(sgx_ctx* c, SgxSig x, size_t n_samples, const std::vecto
             // two kernels with LDS-resident sub-transforms, input built on the fly (the mean comes from the device-side
             // sum: no host look), arg-max fused (sgx_fft.hip)
             nblk = sgx_fft_fine_partials();
-            rc = sgx_fft_fine_search(&c->plan_fine, x, c->d_codes, d_detprn, d_detph, n_det, len, d_sum, (double)n_samples, ts,
+            rc = sgx_fft_fine_search(&c->plan_fine, x, c->d_codes, det_prn.data(), det_phase.data(), n_det, len, d_sum, (double)n_samples, ts,
                                      tc1, c->d_fine[0], 4, uniq - 5, d_pv, d_pi, st);
             if (rc != SGX_OK) return rc;
         } else {
+            SGX_HIP(hipMemcpyAsync(d_detprn, det_prn.data(), sizeof(int) * (size_t)n_det, hipMemcpyHostToDevice, st));
+            SGX_HIP(hipMemcpyAsync(d_detph, det_phase.data(), sizeof(int) * (size_t)n_det, hipMemcpyHostToDevice, st));
             dim3 grid((unsigned)((len + 255) / 256), (unsigned)n_rows);
             acq_fine_prep_kernel<<<grid, 256, 0, st>>>(x, c->d_codes, c->d_fine[0], len, npts, mean, ts, tc1, d_detprn,
                                                        d_detph, n_det);
@@ -845,6 +866,48 @@ struct PeakOut {
     int cph[32], fbi[32];
     int index_error[32];
 };
+// The coarse search's outcome, written by one small kernel straight into a coherent pinned page: the host spins on
+// `seq` instead of sleeping in hipStreamSynchronize behind two device-to-host copies (~55 us -> ~10 us between the last
+// coarse kernel and the first fine one).
+struct CoarseLook {
+    PeakOut po;
+    double second[32];
+    unsigned long long seq;
+};
+__global__ __launch_bounds__(64) void acq_publish_kernel(const PeakOut* __restrict__ po, const double* __restrict__ second,
+                                                         int n_prn, CoarseLook* __restrict__ host, unsigned long long seq) {
+    const int t = threadIdx.x;
+    const int* src = reinterpret_cast<const int*>(po);
+    int* dst = reinterpret_cast<int*>(&host->po);
+    for (int i = t; i < (int)(sizeof(PeakOut) / sizeof(int)); i += 64) dst[i] = src[i];
+    if (t < n_prn) host->second[t] = second[t];
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Waits for acq_publish_kernel's `seq`.  Spins (bounded), then falls back to the stream synchronisation, after which the
+// page is complete in any case.
+static int coarse_look_wait(sgx_ctx* c, unsigned long long seq) {
+    const CoarseLook* h = (const CoarseLook*)c->h_look;
+    const char* sp = getenv("SGX_ACQ_SPIN");
+    if (!(sp && sp[0] == '0')) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned it = 0;; ++it) {
+            if (__atomic_load_n(&h->seq, __ATOMIC_ACQUIRE) == seq) return SGX_OK;
+            if ((it & 1023u) == 1023u &&
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.05)
+                break;
+        }
+    }
+    SGX_HIP(hipStreamSynchronize(c->stream));
+    if (__atomic_load_n(&h->seq, __ATOMIC_ACQUIRE) != seq) {
+        sgx_set_error("acquisition: the coarse search's result page was not written");
+        return SGX_E_HIP;
+    }
+    return SGX_OK;
+}
+
 __global__ __launch_bounds__(64) void acq_peak_kernel(const double* __restrict__ rowmax, const int* __restrict__ rowarg,
                                                       int n_prn, int out_per_prn, int n_bins, int n_blocks, int noncoh,
                                                       long long N, int spc, PeakOut* __restrict__ po,
@@ -968,12 +1031,17 @@ static int acquire_four_step(sgx_ctx* c, SgxSig x, size_t n_samples, const int32
     int2* d_map = (int2*)(dsm + 200000);
 
     hipEventRecord(c->ev[0], st);
-    SGX_HIP(hipMemsetAsync(d_sum, 0, 8, st));
-    SGX_HIP(hipMemcpyAsync(d_prn, prn0, sizeof(int) * (size_t)n_prn, hipMemcpyHostToDevice, st));
-    SGX_HIP(hipMemcpyAsync(d_binmap, bin_map.data(), sizeof(int2) * (size_t)n_bins, hipMemcpyHostToDevice, st));
-    SGX_HIP(hipMemsetAsync(d_second, 0, sizeof(double) * 32, st));
+    {
+        AcqSetup su;
+        memset(&su, 0, sizeof(su));
+        su.n_prn = n_prn;
+        su.n_bins = n_bins;
+        for (int i = 0; i < n_prn; ++i) su.prn[i] = prn0[i];
+        for (int k = 0; k < n_bins; ++k) su.bin[k] = bin_map[(size_t)k];
+        acq_setup_kernel<<<1, 128, 0, st>>>(su, d_prn, d_binmap, d_sum, d_second);
+    }
     if (x.f64) acq_sum_f64_kernel<<<1, 1024, 0, st>>>(x.f64, (long long)n_samples, d_sum);
-    else acq_sum_kernel<<<256, 256, 0, st>>>(x.i8, (long long)n_samples, d_sum);
+    else acq_sum_kernel<<<64, 256, 0, st>>>(x.i8, (long long)n_samples, d_sum);
 
     // ---- forward spectra (n_blocks x n_phi rows, PRN independent) and code spectra (n_prn rows): ONE batch, results
     //      straight into d_fwd = [forward | code] ----------------------------------------------------------------------
@@ -1045,12 +1113,14 @@ static int acquire_four_step(sgx_ctx* c, SgxSig x, size_t n_samples, const int32
         }
     }
     // ---- the host's one look at the coarse search ------------------------------------------------------------------------
-    PeakOut* h_po = (PeakOut*)(hsm + 620000);
-    double* h_second = (double*)(hsm + 1024 + 12 * 4096);
-    SGX_HIP(hipMemcpyAsync(h_po, d_po, sizeof(PeakOut), hipMemcpyDeviceToHost, st));
-    SGX_HIP(hipMemcpyAsync(h_second, d_second, sizeof(double) * (size_t)n_prn, hipMemcpyDeviceToHost, st));
+    const unsigned long long seq = ++c->look_seq;
+    acq_publish_kernel<<<1, 64, 0, st>>>(d_po, d_second, n_prn, (CoarseLook*)c->d_look, seq);
     hipEventRecord(c->ev[1], st);
-    SGX_HIP(hipStreamSynchronize(st));
+    SGX_HIP(hipGetLastError());
+    rc = coarse_look_wait(c, seq);
+    if (rc != SGX_OK) return rc;
+    const PeakOut* h_po = &((const CoarseLook*)c->h_look)->po;
+    const double* h_second = ((const CoarseLook*)c->h_look)->second;
     const double* peak = h_po->peak;
     const int* cph = h_po->cph;
     const int* fbi = h_po->fbi;

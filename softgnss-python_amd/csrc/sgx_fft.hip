@@ -1012,8 +1012,8 @@ int sgx_fft4_forward(const FftPlan* p, const cplx* in, cplx* work, cplx* out, in
 struct FineArgs {
     SgxSig x;
     const int8_t* codes;      // [32][1023]
-    const int* det_prn;
-    const int* det_phase;
+    int det_prn[32];          // by value: no host-to-device copy between the coarse and the fine search
+    int det_phase[32];
     int n_det;
     long long len;            // 10 N samples of signal, zeros beyond
     const long long* d_sum;   // sum of the record window (an integer for int8 samples, the bits of a double otherwise);
@@ -1066,13 +1066,21 @@ __global__ __launch_bounds__(FF_TPB) void fine_cols_kernel(FineArgs a) {
     lds_radix_pass<FF_N1, 16, 1, FF_C, FF_C, 1, FF_TPB, true>(buf, tw, a.wr16, tid);
     lds_radix_pass<FF_N1, 16, 16, FF_C, FF_C, 1, FF_TPB, true>(buf, tw, a.wr16, tid);
     lds_radix_pass<FF_N1, 4, 256, FF_C, FF_C, 1, FF_TPB, true>(buf, tw, a.wr4, tid);
+    // element (k1, n2) times W_M^(n2 k1): a thread keeps its column and advances k1 by FF_TPB / FF_C; table look-ups
+    // for its first element and for the step factor, the other 15 by recurrence (a rolled loop of look-ups runs one
+    // memory round trip per element)
     cplx* __restrict__ out = a.work + (long long)r * FF_N1 * FF_N2;
-    for (int e = tid; e < FF_N1 * FF_C; e += FF_TPB) {
-        const int k1 = e / FF_C, c = e % FF_C;
-        const long long t = (long long)(c0 + c) * k1;   // < M
-        const cplx h = a.tw_hi[t >> a.lo_bits];
-        const cplx l = a.tw_lo[t & ((1ll << a.lo_bits) - 1)];
-        out[(long long)k1 * FF_N2 + c0 + c] = cmul(buf[e], cmul(h, l));
+    static_assert(FF_TPB % FF_C == 0 && FF_N1 % (FF_TPB / FF_C) == 0, "a thread keeps its column");
+    constexpr int STEP = FF_TPB / FF_C;
+    const int n2 = c0 + tid % FF_C, k1b = tid / FF_C;
+    auto look = [&](long long t) { return cmul(a.tw_hi[t >> a.lo_bits], a.tw_lo[t & ((1ll << a.lo_bits) - 1)]); };
+    cplx w = look((long long)n2 * k1b);
+    const cplx ws = look((long long)n2 * STEP);
+#pragma unroll
+    for (int i = 0; i < FF_N1 / STEP; ++i) {
+        const int k1 = k1b + i * STEP;
+        out[(long long)k1 * FF_N2 + n2] = cmul(buf[k1 * FF_C + tid % FF_C], w);
+        w = cmul(w, ws);
     }
 }
 
@@ -1091,9 +1099,21 @@ __global__ __launch_bounds__(FF_TPB) void fine_rows_kernel(FineArgs a) {
     const bool single = (bx == 0 || bx == FF_N1 / 2);
     const int rowA = bx, rowB = single ? bx : FF_N1 - bx;
     const cplx* __restrict__ in = a.work + (long long)r * FF_N1 * FF_N2;
-    for (int e = tid; e < FF_N2; e += FF_TPB) {
-        buf[e] = in[(long long)rowA * FF_N2 + e];
-        buf[FF_N2 + e] = in[(long long)rowB * FF_N2 + e];    // (a single row is simply transformed twice)
+    {
+        // both rows' loads in flight together (a single row is simply transformed twice)
+        constexpr int PER = FF_N2 / FF_TPB;
+        static_assert(FF_N2 % FF_TPB == 0, "whole rounds");
+        cplx ra[PER], rb[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            ra[i] = in[(long long)rowA * FF_N2 + tid + i * FF_TPB];
+            rb[i] = in[(long long)rowB * FF_N2 + tid + i * FF_TPB];
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            buf[tid + i * FF_TPB] = ra[i];
+            buf[FF_N2 + tid + i * FF_TPB] = rb[i];
+        }
     }
     __syncthreads();
     const TwTwoLevel tw{thi, tlo};
@@ -1162,10 +1182,10 @@ int sgx_fft_fine_partials(void) { return FF_N1 / 2 + 1; }
 
 // Fine search of n_det detections (two per complex row) on the 2^22-point two-kernel transform.  `plan` = the 2^22
 // plan (its two-level table of W_M is used for the inter-step twiddles).  Fills pv / pi [n_det][sgx_fft_fine_partials()].
-int sgx_fft_fine_search(const FftPlan* plan, SgxSig x, const int8_t* codes, const int* d_det_prn,
-                        const int* d_det_phase, int n_det, long long len, const long long* d_sum, double n_mean, double ts,
+int sgx_fft_fine_search(const FftPlan* plan, SgxSig x, const int8_t* codes, const int* det_prn,
+                        const int* det_phase, int n_det, long long len, const long long* d_sum, double n_mean, double ts,
                         double tc1, cplx* work, long long lo, long long hi, double* pv, long long* pi, hipStream_t st) {
-    if (!plan->tw_hi || !sgx_fft_fine_supported(plan->n) || n_det < 1) {
+    if (!plan->tw_hi || !sgx_fft_fine_supported(plan->n) || n_det < 1 || n_det > 32) {
         sgx_set_error("sgx_fft_fine_search: %lld points not supported", (long long)plan->n);
         return SGX_E_ARG;
     }
@@ -1203,8 +1223,10 @@ int sgx_fft_fine_search(const FftPlan* plan, SgxSig x, const int8_t* codes, cons
     memset(&a, 0, sizeof(a));
     a.x = x;
     a.codes = codes;
-    a.det_prn = d_det_prn;
-    a.det_phase = d_det_phase;
+    for (int d = 0; d < n_det; ++d) {
+        a.det_prn[d] = det_prn[d];
+        a.det_phase[d] = det_phase[d];
+    }
     a.n_det = n_det;
     a.len = len;
     a.d_sum = d_sum;

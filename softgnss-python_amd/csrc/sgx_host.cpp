@@ -157,6 +157,9 @@ static int ctx_build(sgx_ctx* c, int priority) {
     SGX_HIP(hipMemcpy(c->d_codes, codes.data(), codes.size(), hipMemcpyHostToDevice));
     SGX_HIP(hipMalloc(&c->d_small, 1 << 20));
     SGX_HIP(hipHostMalloc(&c->h_small, 1 << 20, hipHostMallocDefault));
+    SGX_HIP(hipHostMalloc(&c->h_look, 4096, hipHostMallocCoherent | hipHostMallocMapped));
+    memset(c->h_look, 0, 4096);
+    SGX_HIP(hipHostGetDevicePointer(&c->d_look, c->h_look, 0));
     return SGX_OK;
 }
 
@@ -179,6 +182,7 @@ extern "C" int sgx_ctx_create_prio(const sgx_settings* s, int device, int priori
         if (c->d_codes) hipFree(c->d_codes);
         if (c->d_small) hipFree(c->d_small);
         if (c->h_small) hipHostFree(c->h_small);
+        if (c->h_look) hipHostFree(c->h_look);
         delete c;
         return rc;
     }
@@ -208,6 +212,7 @@ extern "C" int sgx_ctx_destroy(sgx_ctx* c) {
     hipFree(c->d_trk_out);
     hipFree(c->d_trk_aux);
     if (c->h_small) hipHostFree(c->h_small);
+    if (c->h_look) hipHostFree(c->h_look);
     for (int i = 0; i < 6; ++i)
         if (c->ev[i]) hipEventDestroy(c->ev[i]);
     if (c->stream) hipStreamDestroy(c->stream);

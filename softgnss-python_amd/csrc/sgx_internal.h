@@ -94,6 +94,9 @@ struct sgx_ctx {
     size_t cap_fwd = 0, cap_code = 0, cap_w0 = 0, cap_w1 = 0, cap_pow = 0, cap_f0 = 0, cap_f1 = 0;   // bytes
     void* d_small = nullptr;     // small result area
     void* h_small = nullptr;     // pinned mirror
+    void* h_look = nullptr;      // coherent pinned page a kernel publishes the coarse search's outcome to (host spins on it)
+    void* d_look = nullptr;      // its device address
+    unsigned long long look_seq = 0;
     // tracking
     double* d_trk_out = nullptr;
     size_t trk_out_elems = 0;
@@ -150,7 +153,7 @@ struct Fft4Fuse {
 };
 bool sgx_fft_fine_supported(int64_t npts);
 int sgx_fft_fine_partials(void);
-int sgx_fft_fine_search(const FftPlan* plan, SgxSig x, const int8_t* codes, const int* d_det_prn,
+int sgx_fft_fine_search(const FftPlan* plan, SgxSig x, const int8_t* codes, const int* det_prn /* host, <= 32 */,
                         const int* d_det_phase, int n_det, long long len, const long long* d_sum, double n_mean, double ts,
                         double tc1, cplx* work, long long lo, long long hi, double* pv, long long* pi, hipStream_t st);
 bool sgx_fft4_supported(int64_t n);

@@ -7,17 +7,11 @@ python3 - <<'PY'
 import glob, sqlite3
 db = glob.glob("gpurun_out/prof_acq1/*/*_results.db")[0]
 c = sqlite3.connect(db)
-tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
-kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
-ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
-rows = list(c.execute("select s.kernel_name, d.start, d.end, d.grid_size_x, d.workgroup_size_x from %s d join %s s on d.kernel_id = s.id order by d.start" % (kd, ks)))
-# the last call: everything after the last acq_mixphi_kernel... find the last 'acq_sum' start
-idx = [i for i, r in enumerate(rows) if r[0].startswith("acq_sum")]
-first = idx[-1]
-t0 = rows[first][1]
-prev_end = t0
+rows = list(c.execute("select name, start, end, grid_x, workgroup_x from kernels order by start"))
+first = [i for i, r in enumerate(rows) if r[0].startswith("acq_sum")][-1]
+t0 = rows[first][1]; prev_end = t0
 for name, st, en, g, w in rows[first:]:
-    print("%-58s start %8.1f us  dur %7.1f us  gap %6.1f  grid %d x %d" % (name[:58], (st - t0) / 1e3, (en - st) / 1e3, (st - prev_end) / 1e3, g // max(w, 1), w))
+    print("%-56s start %7.1f dur %6.1f gap %5.1f grid %5d x %3d" % (name[:56], (st - t0) / 1e3, (en - st) / 1e3, (st - prev_end) / 1e3, g // max(w, 1), w))
     prev_end = en
 print("span %.1f us" % ((rows[-1][2] - t0) / 1e3))
 PY
