@@ -341,23 +341,55 @@ def test_round1_and_round2_kernels_agree_on_a_long_run(full_run):
     assert np.max(np.abs(s2[:, 1:3] - series[:, 1:3, :ms])) < 1e-6
 
 
-def test_a_withheld_member_aborts_the_channel_quickly(full_run, capfd):
+@pytest.mark.parametrize("kernel", ["round2", "round1"])
+def test_a_withheld_member_aborts_the_channel_quickly(full_run, capfd, kernel):
     """The launch really lacks one member per channel (SGX_TRK_TEST_WITHHOLD=1): the others must give the channel up
     within one poll budget - not spin block after block - and the host's repeat with one workgroup per channel must
-    deliver the usual results."""
+    deliver the usual results.  Both cooperative kernels (SGX_TRK_V1=1: the round-1 one, which streaming records and
+    low sampling rates still use)."""
     import time
     m, s, ctx, sc, rec, a, chans, series, done = full_run
     os.environ["SGX_TRK_TEST_WITHHOLD"] = "1"
+    if kernel == "round1":
+        os.environ["SGX_TRK_V1"] = "1"
     try:
         t0 = time.perf_counter()
         s2, d2 = ctx.track(rec, chans, 500)
         dt = time.perf_counter() - t0
     finally:
         os.environ.pop("SGX_TRK_TEST_WITHHOLD", None)
+        os.environ.pop("SGX_TRK_V1", None)
     assert "repeating the launch with one workgroup per channel" in capfd.readouterr().err
     assert dt < 20.0, dt
     assert np.all(d2 == 500) and np.array_equal(s2[:, 0], series[:, 0, :500])
     assert _trk_err(s2, series[:, :, :500]) < 1e-9
+
+
+@pytest.mark.parametrize("kernel", ["round2", "round1"])
+def test_a_block_beyond_the_units_of_the_launch_is_an_error_not_a_silent_truncation(kernel):
+    """A DLL bandwidth of 6 kHz on a channel without a signal drives the code NCO tens of kHz off: blocks become longer than
+    the ten 4096-sample units of the launch.  Both cooperative kernels must say so (SGX_E_RANGE) instead of dropping
+    the tail samples; at 2 kHz the same run still fits and completes."""
+    m = pkg()
+    chans = [(7, 9.548e6, 1234.0), (1, 9.5478e6, 12345.0)]
+    if kernel == "round1":
+        os.environ["SGX_TRK_V1"] = "1"
+    try:
+        for bw, fits in ((2000.0, True), (6000.0, False)):
+            s = m.Settings()
+            s.dllNoiseBandwidth = bw
+            s.msToProcess = 60.0
+            s.numberOfChannels = 2
+            ctx = m.engine.get_context(s, 0)
+            rec = ctx.synth(m.synth.Scene.default(), m.synth.record_length(s.samplesPerCode, 80))
+            if fits:
+                ser, done = ctx.track(rec, chans, 60)
+                assert np.all(done == 60)
+            else:
+                with pytest.raises(m._native.SgxError, match="plausible range"):
+                    ctx.track(rec, chans, 60)
+    finally:
+        os.environ.pop("SGX_TRK_V1", None)
 
 
 def test_second_front_end_golden():
