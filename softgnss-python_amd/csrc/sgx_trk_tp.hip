@@ -16,7 +16,36 @@
 //   ~320 instructions per 37 samples instead of ~300 per 16 in the group kernel.
 #include "sgx_trk_common.h"
 
-__global__ __launch_bounds__(TRK_THREADS, 2) void trk_kernel_tp(const int8_t* __restrict__ rec,
+// first sample above thr from real arithmetic; `near` is raised when a sample lies within 1e-7 samples of the boundary
+__device__ __forceinline__ int tp_bound(double start, double inv_step, double thr, bool& near) {
+    const double u = (thr - start) * inv_step;
+    const double f = floor(u);
+    const double fr = u - f;
+    near = near || !(fr > 1e-7 && fr < 1.0 - 1e-7);
+    return (int)f + 1;
+}
+
+// 20 bytes starting at record byte `addr` (any alignment; the hardware takes unaligned 16-byte loads), bytes >= len
+// zeroed: five dwords
+__device__ __forceinline__ void load_run_u(const int8_t* __restrict__ rec, long long addr, long long limit, int len,
+                                           unsigned (&w)[5]) {
+    if (addr > limit) addr = limit;
+    const U4a q = *reinterpret_cast<const U4a*>(rec + addr);
+    const unsigned q4 = reinterpret_cast<const U2a*>(rec + addr + 16)->x;
+    w[0] = q.x;
+    w[1] = q.y;
+    w[2] = q.z;
+    w[3] = q.w;
+    w[4] = q4;
+#pragma unroll
+    for (int d = 0; d < 5; ++d) {
+        int keep = len - 4 * d;                      // bytes of this dword inside the run
+        keep = keep < 0 ? 0 : (keep > 4 ? 4 : keep);
+        w[d] &= (keep >= 4) ? 0xFFFFFFFFu : ((1u << (8 * keep)) - 1u);
+    }
+}
+
+__global__ __launch_bounds__(TRK_THREADS, 3) void trk_kernel_tp(const int8_t* __restrict__ rec,
                                                                 const int8_t* __restrict__ codes,
                                                                 const TrkChan* __restrict__ chans,
                                                                 double* __restrict__ out, int* __restrict__ ms_done,
@@ -76,24 +105,35 @@ __global__ __launch_bounds__(TRK_THREADS, 2) void trk_kernel_tp(const int8_t* __
         const double startP = s_blk.startP, stepP = s_blk.stepP;
         const double startL = s_blk.startL, stepL = s_blk.stepL;
         const double inv_step = s_blk.inv_step;
-        double2 B[TP_RUN];
-#pragma unroll
-        for (int k = 0; k < TP_RUN; ++k) B[k] = s_car.B[k];
         const int c_first = (int)ceil(ramp_at(0, stepP, startP));
         const int c_last = (int)ceil(ramp_at(blk - 1, stepP, startP));
 
         double aIE = 0.0, aQE = 0.0, aIP = 0.0, aQP = 0.0, aIL = 0.0, aQL = 0.0;
 #pragma unroll 1
         for (int c = c_first + tid; c <= c_last; c += TRK_THREADS) {
+            asm volatile("" ::: "memory");   // the slot phasors are re-read from LDS for every chip (80 registers otherwise)
             // ---- the chip's sample range and the early / late switch samples (exact) ----
-            int s0 = (c == c_first) ? 0 : first_above(startP, stepP, inv_step, (double)(c - 1));
-            int s1 = (c == c_last) ? blk : first_above(startP, stepP, inv_step, (double)c);
+            // boundaries from one multiply each, u = (thr - start) / step in real arithmetic: the reference's ramp
+            // fl(fl(i step) + start) lies within 1e-11 samples of the real one, so floor(u) + 1 is the first sample above
+            // thr unless u is within 1e-7 of an integer - then (any lane of the wave) the exact probes decide
+            bool near = false;
+            int s0 = (c == c_first) ? 0 : tp_bound(startP, inv_step, (double)(c - 1), near);
+            int s1 = (c == c_last) ? blk : tp_bound(startP, inv_step, (double)c, near);
+            if (__builtin_expect(__any(near), 0)) {
+                s0 = (c == c_first) ? 0 : first_above(startP, stepP, inv_step, (double)(c - 1));
+                s1 = (c == c_last) ? blk : first_above(startP, stepP, inv_step, (double)c);
+            }
             s0 = s0 < 0 ? 0 : s0;
             s1 = s1 > blk ? blk : s1;
             const int kE = (int)ceil(ramp_at(s0, stepE, startE));
             const int kL = (int)ceil(ramp_at(s0, stepL, startL));
-            int eE = first_above(startE, stepE, inv_step, (double)kE);
-            int eL = first_above(startL, stepL, inv_step, (double)kL);
+            near = false;
+            int eE = tp_bound(startE, inv_step, (double)kE, near);
+            int eL = tp_bound(startL, inv_step, (double)kL, near);
+            if (__builtin_expect(__any(near), 0)) {
+                eE = first_above(startE, stepE, inv_step, (double)kE);
+                eL = first_above(startL, stepL, inv_step, (double)kL);
+            }
             eE = eE > s1 ? s1 : eE;
             eL = eL > s1 ? s1 : eL;
             const int e1 = eE < eL ? eE : eL, e2 = eE < eL ? eL : eE;
@@ -127,8 +167,8 @@ __global__ __launch_bounds__(TRK_THREADS, 2) void trk_kernel_tp(const int8_t* __
                 }
             } else if (s1 > s0) {
                 unsigned wh[5], wt[5];
-                load_run(rec, pos + s0, limit, len_h, wh);
-                load_run(rec, pos + e2, limit, len_t, wt);
+                load_run_u(rec, pos + s0, limit, len_h, wh);
+                load_run_u(rec, pos + e2, limit, len_t, wt);
                 const double2 gt = cmul2(gh, s_car.B[e2 - s0]);
                 double Hc = 0.0, Hs = 0.0, Tc = 0.0, Ts = 0.0;
 #pragma unroll
@@ -137,10 +177,11 @@ __global__ __launch_bounds__(TRK_THREADS, 2) void trk_kernel_tp(const int8_t* __
                     const int xh = ((k & 3) == 3) ? ((int)a >> 24) : (int)(signed char)((a >> (8 * (k & 3))) & 0xFF);
                     const int xt = ((k & 3) == 3) ? ((int)b >> 24) : (int)(signed char)((b >> (8 * (k & 3))) & 0xFF);
                     const double dh = (double)xh, dt = (double)xt;
-                    Hc = __builtin_fma(dh, B[k].x, Hc);
-                    Hs = __builtin_fma(dh, B[k].y, Hs);
-                    Tc = __builtin_fma(dt, B[k].x, Tc);
-                    Ts = __builtin_fma(dt, B[k].y, Ts);
+                    const double2 Bk = s_car.B[k];
+                    Hc = __builtin_fma(dh, Bk.x, Hc);
+                    Hs = __builtin_fma(dh, Bk.y, Hs);
+                    Tc = __builtin_fma(dt, Bk.x, Tc);
+                    Ts = __builtin_fma(dt, Bk.y, Ts);
                 }
                 // rotate the runs by their start phasors: cos part -> Q, sin part -> I (tracking.py:205-207)
                 const double hQ = __builtin_fma(gh.x, Hc, -(gh.y * Hs)), hI = __builtin_fma(gh.y, Hc, gh.x * Hs);
