@@ -436,7 +436,7 @@ def main():
                        "peak_gather": gather.name},
             "acquire_ms": float(np.mean(acq_ms)), "track_kernel_ms": k_ms,
             "us_per_code_period": k_ms * 1e3 / args.ms,
-            "roofline": {"kernel": "trk_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"kernel": "trk2_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic[0]["hbm_bytes_per_launch"] if traffic else None,
                          "traffic_source": (traffic[1] + " (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes of this "
