@@ -60,17 +60,31 @@ def main():
             "HBM section): x2; WRITE_SIZE used as reported")
 
     def big(d, prefix):
-        ks = [k for k in d if k.startswith(prefix)]
+        ks = [k for k in d if prefix in k]          # (template instances are named "void name<...>(...)")
         return max(max(d[k]) for k in ks) * 1024.0 if ks else None
 
     f_trk, w_trk = big(fetch, "trk2_kernel"), big(write, "trk2_kernel")
     if f_trk is not None:
+        rec = {"kernel": "trk2_kernel", "fetch_size_raw_bytes_per_launch": f_trk,
+               "write_size_raw_bytes_per_launch": w_trk, "correction": corr,
+               "hbm_bytes_per_launch": 2.0 * f_trk + w_trk,
+               "note": "the 13 series per block go straight to pinned host memory and are not HBM writes",
+               "workload": {"channels": 8, "ms": 37000}}
+        vdb, gdb = db_of(os.path.join(out, "valu")), db_of(os.path.join(out, "grbm"))
+        if vdb and gdb:
+            def largest(db, counter):
+                d = by_kernel(per_dispatch(db, counter))
+                ks = [k for k in d if "trk2_kernel" in k]
+                return max(max(d[k]) for k in ks) if ks else None
+            insts, act, gui = largest(vdb, "SQ_INSTS_VALU"), largest(vdb, "SQ_ACTIVE_INST_VALU"), largest(gdb, "GRBM_GUI_ACTIVE")
+            if insts and act and gui:
+                rec["valu_insts_per_sample"] = insts * 64.0 / (8 * 37000 * 38192.0)
+                rec["valu_busy_frac_chip"] = act * 4.0 / 1024.0 / (gui / 8.0)
+                rec["valu_busy_frac_on_the_80_occupied_cus"] = rec["valu_busy_frac_chip"] * 256.0 / 80.0
+                rec["valu_formula"] = ("SQ_INSTS_VALU * 64 lanes / (8 channels * 37000 ms * 38192 samples); SQ_ACTIVE_INST_VALU * 4 / "
+                                       "1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs)")
         with open(os.path.join(dst, "%s_pmc_trk_kernel.json" % tag), "w") as f:
-            json.dump({"kernel": "trk2_kernel", "fetch_size_raw_bytes_per_launch": f_trk,
-                       "write_size_raw_bytes_per_launch": w_trk, "correction": corr,
-                       "hbm_bytes_per_launch": 2.0 * f_trk + w_trk,
-                       "note": "the 13 series per block go straight to pinned host memory and are not HBM writes",
-                       "workload": {"channels": 8, "ms": 37000}}, f, indent=1)
+            json.dump(rec, f, indent=1)
     # ---- many-channel (throughput-mode) kernel: traffic + VALU ----
     f_tp, w_tp = big(fetch, "trk_kernel_tp"), big(write, "trk_kernel_tp")
     valu_db = db_of(os.path.join(out, "valu"))
