@@ -339,18 +339,33 @@ __device__ __forceinline__ int t2_map_role(T2Shared& S, const int8_t* __restrict
     int i0, ilo;
     double ilod;
     T2Raw<SB> raw;
+    int blk_pred;                    // block length the prepared samples are cut for
 
-#define T2_PREPARE(POS_NEXT)                                                                                   \
+    // samples from block sample index END on belong to the next block: zeroed by an integer mask on the high dword
+#define T2_CUT(END)                                                                                            \
+    do {                                                                                                       \
+        if (i0 < (END) && i0 + 16 > (END)) {                                                                   \
+            const int e_ = (END) - i0;                                                                         \
+            _Pragma("unroll") for (int b_ = 0; b_ < 16; ++b_)                                                  \
+                xd[b_] = __hiloint2double(__double2hiint(xd[b_]) & ((b_ - e_) >> 31), 0);                      \
+        }                                                                                                      \
+    } while (0)
+    // The block's last, partial group is cut in the shadow too, for the length the block will most likely have (the
+    // current one): on the chain the one lane that holds it costs its whole member ~200 cycles every block, and every
+    // member waits for that member.
+#define T2_PREPARE(POS_NEXT, BLK_PRED)                                                                         \
     do {                                                                                                       \
         const int head_ = (int)((POS_NEXT) & 15);                                                              \
         i0 = g * 16 - head_;                                                                                   \
         ilo = i0 < 0 ? 0 : i0;                                                                                 \
         ilod = (double)ilo;                                                                                    \
         t2_convert(raw, i0, xd);                                                                               \
+        blk_pred = (BLK_PRED);                                                                                 \
+        T2_CUT(blk_pred);                                                                                      \
     } while (0)
 
     raw = t2_load<SB>(rec, (pos0 & ~15ll) + lane_off, limit);
-    T2_PREPARE(pos0);
+    T2_PREPARE(pos0, S.code[0].blk);
     int it = 0;
     for (; it < ms; ++it) {
         const int par = it & 1;
@@ -394,12 +409,14 @@ __device__ __forceinline__ int t2_map_role(T2Shared& S, const int8_t* __restrict
             gc = beyond ? 0.0 : gc;
             gs = beyond ? 0.0 : gs;
         }
-        if (__builtin_expect(i0 < blk && i0 + 16 > blk, 0)) {
-            // the block ends inside this group (one lane per block): samples from blk on belong to the next block
-            // (integer mask on the high dword, as for the samples before a switch below)
-            const int e = blk - i0;
-#pragma unroll
-            for (int b = 0; b < 16; ++b) xd[b] = __hiloint2double(__double2hiint(xd[b]) & ((b - e) >> 31), 0);
+        if (__builtin_expect(blk != blk_pred, 0)) {
+            // the block is a sample longer or shorter than predicted (about one block in ten): the lanes around its
+            // end convert their bytes again and cut them at the real length
+            const int lo_ = blk < blk_pred ? blk : blk_pred, hi_ = blk < blk_pred ? blk_pred : blk;
+            if (__any(i0 < hi_ && i0 + 16 > lo_)) {
+                t2_convert(raw, i0, xd);
+                T2_CUT(blk);
+            }
         }
         T2PROBE(prof_on, 1);   // switch samples resolved
         const double cE1 = __hiloint2double((int)(0x3FF00000u | (bE << 31)), 0), cE2 = __hiloint2double((int)(0x3FF00000u | ((bE >> 1) << 31)), 0);
@@ -514,7 +531,7 @@ __device__ __forceinline__ int t2_map_role(T2Shared& S, const int8_t* __restrict
         // ---- shadow: prepare the next block with this block's rates ----
         __builtin_amdgcn_s_setprio(0);
         raw = nraw;
-        T2_PREPARE(pos_next);
+        T2_PREPARE(pos_next, blk);
         T2STAMP(prof_on, 6);   // next block prepared
         wg_barrier();
         T2STAMP(prof_on, 7);   // waiting for the loop filter
