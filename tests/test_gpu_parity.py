@@ -131,6 +131,31 @@ def test_acquire_device_signal_equals_host_signal(default_record):
     assert np.array_equal(a.codePhase, g["codePhase"]) and np.array_equal(a.carrFreq, g["carrFreq"])
 
 
+def test_acquire_variants_agree(default_record):
+    """The knobs that pick another implementation of a stage: the coarse outcome fetched by a stream synchronisation
+    instead of the spin on the pinned page (SGX_ACQ_SPIN=0), the fine search on the pass-per-radix transform
+    (SGX_ACQ_FINE_V1=1), the round-1 correlation that mixes every Doppler bin (SGX_ACQ_V1=1): same indices, same
+    frequencies, peak metrics equal to rounding."""
+    g = load_golden("acq_default.npz")
+    m = pkg()
+    s = m.Settings()
+    x = default_record[:int(g["n_samples"])]
+    ref = m.AcquisitionResult(s, device=0)
+    ref.acquire(x)
+    assert np.array_equal(ref.codePhase, g["codePhase"]) and np.array_equal(ref.carrFreq, g["carrFreq"])
+    for env in ({"SGX_ACQ_SPIN": "0"}, {"SGX_ACQ_FINE_V1": "1"}, {"SGX_ACQ_V1": "1"}):
+        os.environ.update(env)
+        try:
+            a = m.AcquisitionResult(s, device=0)
+            a.acquire(x)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        assert np.array_equal(a.codePhase, ref.codePhase) and np.array_equal(a.carrFreq, ref.carrFreq), env
+        assert np.array_equal(a.internals["freqBin"], ref.internals["freqBin"]), env
+        assert np.allclose(a.peakMetric, ref.peakMetric, rtol=1e-9, atol=0), env
+
+
 def _golden_tracker(m, g, ms=None, nch=4):
     s = m.Settings()
     s.numberOfChannels = nch
