@@ -665,9 +665,20 @@ __global__ __launch_bounds__(TPB) void fft4_cols_kernel(F4Args a) {
     cplx* __restrict__ buf = reinterpret_cast<cplx*>(f4_smem);   // [N1][C]
     cplx* __restrict__ twl = buf + N1 * C;                       // [N1]: W_N1^t
     const int tid = threadIdx.x;
-    lds_fill_twiddles<N1, TPB>(twl, a.tw_sub, tid);
+    // the sub-transform's twiddles: loaded now, stored to LDS after the tile's own loads are issued (loaded, waited for
+    // and stored first, the fill is one exposed memory round trip per workgroup)
+    static_assert(N1 <= TPB, "one staging register");
+    cplx tws = make_double2(0.0, 0.0);
+    if (tid < N1) tws = a.tw_sub[tid];
     const int c0 = blockIdx.x * C;
     const long long row = blockIdx.y;
+    // the output twiddles' table look-ups (four dependent-free global loads) are issued first: behind the passes they
+    // were one more exposed memory round trip per tile
+    static_assert(TPB % C == 0, "a thread keeps its column");
+    constexpr int STEP = TPB / C;
+    const int n2 = c0 + tid % C, k1b = tid / C;
+    const cplx tw_hi0 = a.tw_hi[((long long)n2 * k1b) >> a.lo_bits], tw_lo0 = a.tw_lo[((long long)n2 * k1b) & ((1ll << a.lo_bits) - 1)];
+    const cplx tw_hi1 = a.tw_hi[((long long)n2 * STEP) >> a.lo_bits], tw_lo1 = a.tw_lo[((long long)n2 * STEP) & ((1ll << a.lo_bits) - 1)];
     const cplx* __restrict__ in = a.in + row * a.n;
     const cplx* __restrict__ px = nullptr;
     const cplx* __restrict__ pf = nullptr;
@@ -709,6 +720,7 @@ __global__ __launch_bounds__(TPB) void fft4_cols_kernel(F4Args a) {
                 }
             }
         }
+        if (tid < N1) twl[tid] = tws;
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int e = tid + i * TPB;
@@ -729,12 +741,9 @@ __global__ __launch_bounds__(TPB) void fft4_cols_kernel(F4Args a) {
     else lds_radix_pass<N1, R2, R1, C, C, 1, TPB, true>(buf, tw, a.wr[1], tid);
     // element (k1, n2) times W_n^(n2 k1).  A thread keeps its column n2 and advances k1 by STEP: one table look-up for
     // its first element and one for the step factor W_n^(n2 STEP), the others by recurrence (<= 6 products: a few ulp)
-    static_assert(TPB % C == 0, "a thread keeps its column");
-    constexpr int STEP = TPB / C;
     cplx* __restrict__ out = a.out + row * a.n;
-    const int n2 = c0 + tid % C, k1b = tid / C;
-    cplx w = f4_twiddle(a, (long long)n2 * k1b);
-    const cplx ws = f4_twiddle(a, (long long)n2 * STEP);
+    cplx w = cmul(tw_hi0, tw_lo0);
+    const cplx ws = cmul(tw_hi1, tw_lo1);
 #pragma unroll
     for (int i = 0; i < (N1 + STEP - 1) / STEP; ++i) {
         const int k1 = k1b + i * STEP;
@@ -784,7 +793,10 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(F4_ROWS_WAV
     cplx* __restrict__ buf = reinterpret_cast<cplx*>(f4_smem);   // [CB][N2]
     cplx* __restrict__ twl = buf + CB * N2;                      // [N2]: W_N2^t
     const int tid = threadIdx.x;
-    lds_fill_twiddles<N2, TPB>(twl, a.tw_sub, tid);
+    static_assert(N2 <= 2 * TPB, "two staging registers");
+    cplx tws0 = make_double2(0.0, 0.0), tws1 = make_double2(0.0, 0.0);   // (as in the columns kernel)
+    if (tid < N2) tws0 = a.tw_sub[tid];
+    if (tid + TPB < N2) tws1 = a.tw_sub[tid + TPB];
     const int k10 = blockIdx.x * CB;
     const long long row = blockIdx.y;
     constexpr int E = CB * N2;
@@ -805,6 +817,10 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(F4_ROWS_WAV
             F4_LD(5, p5) F4_LD(6, p6) F4_LD(7, p7) F4_LD(8, p8) F4_LD(9, p9)
 #undef F4_LD
             if (b > 0) __syncthreads();
+            if (b == 0) {
+                if (tid < N2) twl[tid] = tws0;
+                if (tid + TPB < N2) twl[tid + TPB] = tws1;
+            }
 #define F4_ST(i, r) if (PER > i && tid + i * TPB < E) buf[tid + i * TPB] = r;
             F4_ST(0, p0) F4_ST(1, p1) F4_ST(2, p2) F4_ST(3, p3) F4_ST(4, p4)
             F4_ST(5, p5) F4_ST(6, p6) F4_ST(7, p7) F4_ST(8, p8) F4_ST(9, p9)
