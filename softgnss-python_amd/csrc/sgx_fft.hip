@@ -1054,7 +1054,8 @@ __global__ __launch_bounds__(FF_TPB) void fine_cols_kernel(FineArgs a) {
     cplx* __restrict__ buf = reinterpret_cast<cplx*>(f4_smem);   // [FF_N1][FF_C]
     cplx* __restrict__ twl = buf + FF_N1 * FF_C;                 // [FF_N1]
     const int tid = threadIdx.x;
-    lds_fill_twiddles<FF_N1, FF_TPB>(twl, a.tw_n1, tid);
+    static_assert(FF_N1 == 2 * FF_TPB, "two staging registers");
+    const cplx twa = a.tw_n1[tid], twb = a.tw_n1[tid + FF_TPB];   // (stored to LDS behind the input's loads)
     const int c0 = blockIdx.x * FF_C;
     const int r = blockIdx.y;
     const int d0 = 2 * r, d1 = 2 * r + 1;
@@ -1064,18 +1065,54 @@ __global__ __launch_bounds__(FF_TPB) void fine_cols_kernel(FineArgs a) {
     const long long pb = two ? a.det_phase[d1] : pa;
     const int8_t* __restrict__ cb = two ? a.codes + a.det_prn[d1] * 1023 : ca;
     const double mean = (a.x.f64 ? __longlong_as_double(a.d_sum[0]) : (double)a.d_sum[0]) / a.n_mean;
-    for (int e = tid; e < FF_N1 * FF_C; e += FF_TPB) {
-        const int n1 = e / FF_C, c = e % FF_C;
-        const long long i = (long long)n1 * FF_N2 + c0 + c;
-        cplx val = make_double2(0.0, 0.0);
-        if (i < a.len) {
-            const double v = floor((a.ts * (double)(i + 1)) / a.tc1);       // acquisition.py:172 (A9)
-            const int chip = (int)((long long)v % 1023);
-            const double va = (a.x.at(pa + i) - mean) * (double)ca[chip];
-            const double vb = two ? (a.x.at(pb + i) - mean) * (double)cb[chip] : 0.0;
-            val = make_double2(va, vb);
+    // Only the first len / FF_N2 (< 94 of 1024) rows of a column are non-zero: the rounds that can hold samples are
+    // unrolled with their loads in flight together, the rest is a zero fill.
+    constexpr int ROUNDS = FF_N1 * FF_C / FF_TPB;
+    const int live = (int)((a.len + FF_N2 - 1) / FF_N2) * FF_C;      // elements e < live may be non-zero
+    if (live <= 2 * FF_TPB) {
+        double xa[2], xb[2], sa[2], sb[2];
+        bool in_[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e = tid + k * FF_TPB;
+            const long long i = (long long)(e / FF_C) * FF_N2 + c0 + e % FF_C;
+            in_[k] = i < a.len;
+            xa[k] = xb[k] = sa[k] = sb[k] = 0.0;
+            if (in_[k]) {
+                const double v = floor((a.ts * (double)(i + 1)) / a.tc1);       // acquisition.py:172 (A9)
+                const int chip = (int)((long long)v % 1023);
+                xa[k] = a.x.at(pa + i);
+                sa[k] = (double)ca[chip];
+                if (two) {
+                    xb[k] = a.x.at(pb + i);
+                    sb[k] = (double)cb[chip];
+                }
+            }
         }
-        buf[e] = val;
+        twl[tid] = twa;
+        twl[tid + FF_TPB] = twb;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            buf[tid + k * FF_TPB] = in_[k] ? make_double2((xa[k] - mean) * sa[k], two ? (xb[k] - mean) * sb[k] : 0.0)
+                                           : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int k = 2; k < ROUNDS; ++k) buf[tid + k * FF_TPB] = make_double2(0.0, 0.0);
+    } else {
+        twl[tid] = twa;
+        twl[tid + FF_TPB] = twb;
+        for (int e = tid; e < FF_N1 * FF_C; e += FF_TPB) {
+            const int n1 = e / FF_C, c = e % FF_C;
+            const long long i = (long long)n1 * FF_N2 + c0 + c;
+            cplx val = make_double2(0.0, 0.0);
+            if (i < a.len) {
+                const double v = floor((a.ts * (double)(i + 1)) / a.tc1);       // acquisition.py:172 (A9)
+                const int chip = (int)((long long)v % 1023);
+                const double va = (a.x.at(pa + i) - mean) * (double)ca[chip];
+                const double vb = two ? (a.x.at(pb + i) - mean) * (double)cb[chip] : 0.0;
+                val = make_double2(va, vb);
+            }
+            buf[e] = val;
+        }
     }
     __syncthreads();
     const TwDirect tw{twl};
@@ -1106,9 +1143,11 @@ __global__ __launch_bounds__(FF_TPB) void fine_rows_kernel(FineArgs a) {
     cplx* __restrict__ thi = buf + 2 * FF_N2;                    // [64]
     cplx* __restrict__ tlo = thi + 64;                           // [64]
     const int tid = threadIdx.x;
+    // (loaded now, stored to LDS behind the rows' own loads: no memory round trip of its own)
+    cplx th0 = make_double2(0.0, 0.0), tl0 = make_double2(0.0, 0.0);
     if (tid < 64) {
-        thi[tid] = a.tw_n2_hi[tid];
-        tlo[tid] = a.tw_n2_lo[tid];
+        th0 = a.tw_n2_hi[tid];
+        tl0 = a.tw_n2_lo[tid];
     }
     const int bx = blockIdx.x;                 // 0: row 0 alone; FF_N1 / 2: row 512 alone; else rows bx and FF_N1 - bx
     const int r = blockIdx.y;
@@ -1124,6 +1163,10 @@ __global__ __launch_bounds__(FF_TPB) void fine_rows_kernel(FineArgs a) {
         for (int i = 0; i < PER; ++i) {
             ra[i] = in[(long long)rowA * FF_N2 + tid + i * FF_TPB];
             rb[i] = in[(long long)rowB * FF_N2 + tid + i * FF_TPB];
+        }
+        if (tid < 64) {
+            thi[tid] = th0;
+            tlo[tid] = tl0;
         }
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
