@@ -787,7 +787,9 @@ __device__ __forceinline__ void wg_argmax(double& best, int& arg, double* __rest
 #ifndef F4_ROWS_WAVES
 #define F4_ROWS_WAVES 3
 #endif
-template <int N1, int N2, int CB, int TPB, int R1, int R2, int R3, int MODE>
+// NB1: one input row per output row (known at compile time, the power accumulators are then not live across the
+// transform: no register spills at three waves per SIMD).
+template <int N1, int N2, int CB, int TPB, int R1, int R2, int R3, int MODE, bool NB1>
 __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(F4_ROWS_WAVES))) void fft4_rows_kernel(F4Args a) {
     extern __shared__ __attribute__((aligned(16))) char f4_smem[];
     cplx* __restrict__ buf = reinterpret_cast<cplx*>(f4_smem);   // [CB][N2]
@@ -804,7 +806,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(F4_ROWS_WAV
     double acc[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) acc[i] = 0.0;
-    const int nb = (MODE == 0 || a.sum_blocks < 1) ? 1 : a.sum_blocks;
+    const int nb = (NB1 || MODE == 0 || a.sum_blocks < 1) ? 1 : a.sum_blocks;
     for (int b = 0; b < nb; ++b) {
         const cplx* __restrict__ in = a.in + (row * nb + b) * a.n + (long long)k10 * N2;
         {
@@ -925,9 +927,9 @@ static void f4_launch_cols(const F4Args& a, int64_t rows, hipStream_t st) {
     kern<<<grid, F4_TPB, lds, st>>>(a);
 }
 
-template <int MODE>
-static void f4_launch_rows(const F4Args& a, int64_t rows, hipStream_t st) {
-    auto kern = fft4_rows_kernel<F4_N1, F4_N2, F4_CB, F4_TPB_ROWS, 16, 11, 1, MODE>;
+template <int MODE, bool NB1>
+static void f4_launch_rows_nb(const F4Args& a, int64_t rows, hipStream_t st) {
+    auto kern = fft4_rows_kernel<F4_N1, F4_N2, F4_CB, F4_TPB_ROWS, 16, 11, 1, MODE, NB1>;
     const size_t lds = sizeof(cplx) * (F4_CB * F4_N2 + F4_N2);
     static bool once = false;
     if (!once) {
@@ -936,6 +938,12 @@ static void f4_launch_rows(const F4Args& a, int64_t rows, hipStream_t st) {
     }
     dim3 grid(F4_N1 / F4_CB, (unsigned)rows);
     kern<<<grid, F4_TPB_ROWS, lds, st>>>(a);
+}
+
+template <int MODE>
+static void f4_launch_rows(const F4Args& a, int64_t rows, hipStream_t st) {
+    if (MODE == 0 || a.sum_blocks <= 1) f4_launch_rows_nb<MODE, true>(a, rows, st);
+    else f4_launch_rows_nb<MODE, false>(a, rows, st);
 }
 
 // Forward transform of `rows` rows through the four-step kernels.  `work` holds the intermediate; the result (natural

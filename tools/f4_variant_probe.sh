@@ -11,7 +11,7 @@ import glob, sqlite3
 db = glob.glob("gpurun_out/prof_var/*/*_results.db")[0]
 c = sqlite3.connect(db)
 out = []
-for pat in ("%fft4_cols_kernel%4, 1>%", "%fft4_rows_kernel%1, 2>%"):
+for pat in ("%fft4_cols_kernel%4, 1>%", "%fft4_rows_kernel%1, 2%"):
     r = list(c.execute("select duration from kernels where name like ? order by start", (pat,)))
     big = sorted(x[0] for x in r if x[0] > 100000)
     out.append(min(big) / 1e3 if big else -1)
