@@ -1176,6 +1176,13 @@ def test_track_int16_record_matches_reference():
     m = pkg()
     rec16 = (m.synth.generate(scene_from_json(g["scene"]), int(g["n_samples"])).astype(np.int16)
              * int(g["scale"])).astype("<i2")
+    # the reference's acquisition of the same int16 array (acquisition.py:55-59 takes whatever dtype it is handed)
+    sa = m.Settings()
+    sa.dataType = 'int16'
+    acq = m.AcquisitionResult(sa, device=0)
+    acq.acquire(rec16[:11 * 38192])
+    assert np.array_equal(acq.codePhase, g["codePhase"]) and np.array_equal(acq.carrFreq, g["carrFreq"])
+    assert np.allclose(acq.peakMetric, g["peakMetric"], rtol=1e-9, atol=0)
     for case in ("locked", "as_is"):
         want = g[case + "_series"]
         s, t = _int16_tracker(m, g, case)
