@@ -13,6 +13,7 @@
 
 #include <mutex>
 
+#include <atomic>
 #include "sgx_internal.h"
 
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) {
@@ -918,10 +919,13 @@ template <int MODE>
 static void f4_launch_cols(const F4Args& a, int64_t rows, hipStream_t st) {
     auto kern = fft4_cols_kernel<F4_N1, F4_N2, F4_C, F4_TPB, 7, 31, 4, MODE>;
     const size_t lds = sizeof(cplx) * (F4_N1 * F4_C + F4_N1);
-    static bool once = false;
-    if (!once) {
+    // (the attribute is per device: a process that drives several GPUs sets it on each)
+    static std::atomic<bool> once[SGX_MAX_DEVICES];
+    int dev_ = 0;
+    hipGetDevice(&dev_);
+    if (dev_ >= 0 && dev_ < SGX_MAX_DEVICES && !once[dev_].load()) {
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        once = true;
+        once[dev_].store(true);
     }
     dim3 grid(F4_N2 / F4_C, (unsigned)rows);
     kern<<<grid, F4_TPB, lds, st>>>(a);
@@ -931,10 +935,13 @@ template <int MODE, bool NB1>
 static void f4_launch_rows_nb(const F4Args& a, int64_t rows, hipStream_t st) {
     auto kern = fft4_rows_kernel<F4_N1, F4_N2, F4_CB, F4_TPB_ROWS, 16, 11, 1, MODE, NB1>;
     const size_t lds = sizeof(cplx) * (F4_CB * F4_N2 + F4_N2);
-    static bool once = false;
-    if (!once) {
+    // (the attribute is per device: a process that drives several GPUs sets it on each)
+    static std::atomic<bool> once[SGX_MAX_DEVICES];
+    int dev_ = 0;
+    hipGetDevice(&dev_);
+    if (dev_ >= 0 && dev_ < SGX_MAX_DEVICES && !once[dev_].load()) {
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        once = true;
+        once[dev_].store(true);
     }
     dim3 grid(F4_N1 / F4_CB, (unsigned)rows);
     kern<<<grid, F4_TPB_ROWS, lds, st>>>(a);
@@ -1316,11 +1323,11 @@ int sgx_fft_fine_search(const FftPlan* plan, SgxSig x, const int8_t* codes, cons
     const int n_rows = (n_det + 1) / 2;
     const size_t lds_c = sizeof(cplx) * (FF_N1 * FF_C + FF_N1);
     const size_t lds_r = sizeof(cplx) * (2 * FF_N2 + 128);
-    static bool once = false;
-    if (!once) {
+    static std::atomic<bool> once[SGX_MAX_DEVICES];
+    if (!once[dev].load()) {
         hipFuncSetAttribute((const void*)fine_cols_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
         hipFuncSetAttribute((const void*)fine_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
-        once = true;
+        once[dev].store(true);
     }
     fine_cols_kernel<<<dim3(FF_N2 / FF_C, (unsigned)n_rows), FF_TPB, lds_c, st>>>(a);
     fine_rows_kernel<<<dim3(FF_N1 / 2 + 1, (unsigned)n_rows), FF_TPB, lds_r, st>>>(a);
