@@ -1205,6 +1205,29 @@ def test_track_int16_record_matches_reference():
         assert np.array_equal(t2.series[:, 0], t.series[:, 0]) and _trk_err(t2.series, t.series) < 1e-9
 
 
+def test_track_int16_needs_the_one_unit_kernel_and_a_known_type():
+    """int16 records are tracked by the one-unit-per-workgroup kernel only: asking for the round-1 kernel, or for a
+    sample type the C-ABI does not know, is an argument error with a message, not a wrong result."""
+    g = load_golden("trk_int16.npz")
+    m = pkg()
+    rec16 = (m.synth.generate(scene_from_json(g["scene"]), int(g["n_samples"])).astype(np.int16)
+             * int(g["scale"])).astype("<i2")
+    s, t = _int16_tracker(m, g, "locked", ms=5)
+    ctx = m.engine.get_context(s, 0)
+    rec = ctx.upload_bytes(rec16)
+    chans = [(int(g["locked_PRN"][0]), float(g["locked_acquiredFreq"][0]), float(g["locked_codePhase"][0]))]
+    os.environ["SGX_TRK_V1"] = "1"
+    try:
+        with pytest.raises(m._native.SgxError, match="two-byte samples"):
+            ctx.track(rec, chans, 5, data_type=m._native.DT_INT16)
+    finally:
+        os.environ.pop("SGX_TRK_V1", None)
+    with pytest.raises(m._native.SgxError, match="data_type"):
+        ctx.track(rec, chans, 5, data_type=7)
+    ser, done = ctx.track(rec, chans, 5, rec_file_offset=0, data_type=m._native.DT_INT16)
+    assert ser.shape == (1, 13, 5)
+
+
 def test_track_int16_odd_start_byte_and_short_record():
     """A channel whose start byte skipNumberOfBytes + codePhase is odd reads int16 values that straddle the file's
     samples (the reference's fid.seek takes bytes, tracking.py:107) - followed as is, against the oracle; and the
