@@ -491,6 +491,10 @@ def acq_roofline(pkg, ctx, s, signal, local, n_code):
            "algorithmic_bytes_per_call": alg_bytes,
            "traffic": pm[0]["hbm_bytes_per_call"] if pm else None, "traffic_source": pm[1] if pm else None,
            "hbm_gbs_at_counter_traffic": (pm[0]["hbm_bytes_per_call"] / (t_ms * 1e-3) / 1e9) if pm else None}
+    if pm:
+        # the nearer roof since round 2: the correlation's intermediate crosses HBM once each way and dominates the call
+        out["hbm_frac_at_counter_traffic"] = out["hbm_gbs_at_counter_traffic"] / HBM_PEAK_GBS
+        out["nearer_roof"] = "hbm" if out["hbm_frac_at_counter_traffic"] > out["frac"] else "fp64 valu"
     return out
 
 
