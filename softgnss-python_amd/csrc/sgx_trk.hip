@@ -46,12 +46,14 @@
 void sgx_trk_tp_launch(int n_blocks, hipStream_t st, const int8_t* rec, const int8_t* codes, const void* chans,
                        double* out, int* done, const TrkConst& K, long long* prof, unsigned long long* xch, int* err);
 
-// sgx_trk2.hip: the round-2 latency-mode kernel (one unit per member, integer-atomic exchange, dedicated filter waves)
+// sgx_trk2.hip: the latency-mode kernel (one unit per member - or, arms = 1, one unit and one correlator arm per
+// member -, tagged-granule exchange, dedicated filter waves)
 void sgx_trk2_launch(int n_blocks, hipStream_t st, const int8_t* rec, const int8_t* codes, const TrkChan* chans,
                      double* out, int* done, const TrkConst& K, long long* prof, unsigned long long* xch, int* err,
-                     int sample_bytes);
+                     int sample_bytes, int arms, int lds_pad);
 #define T2_MAXP 16
 #define T2_XCH_STRIDE 256
+#define T2_PROF_STRIDE 192
 
 // sgx_trk_stream.hip: the cooperative kernel with watermark checks, for a record that is still streaming in
 void sgx_trk_stream_launch(int n_blocks, hipStream_t st, const int8_t* rec, const int8_t* codes, const TrkChan* chans,
@@ -198,7 +200,7 @@ static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
     const size_t xch_words = (2 * TRK_MAX_SPLIT * 12 + 16) > T2_XCH_STRIDE ? (2 * TRK_MAX_SPLIT * 12 + 16) : T2_XCH_STRIDE;
     const size_t xch_bytes = sizeof(unsigned long long) * (size_t)n_ch * xch_words;
     const size_t sz_xch = ((xch_bytes + 255) / 256) * 256;
-    const size_t sz_prof = sizeof(long long) * 64 * (size_t)n_ch;
+    const size_t sz_prof = sizeof(long long) * T2_PROF_STRIDE * (size_t)n_ch;
     const size_t need = sz_ch + sz_done + sz_xch + 256 + sz_prof;
     if (c->trk_aux_cap < need) {
         if (c->d_trk_aux) hipFree(c->d_trk_aux);
@@ -218,17 +220,32 @@ static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
     const char* pe = getenv("SGX_TRK_PROFILE");
     const bool want_prof = pe && pe[0] == '1';
     long long* d_prof = want_prof ? (long long*)(aux + sz_ch + sz_done + sz_xch + 256) : nullptr;
-    // The round-2 kernel (sgx_trk2.hip) gives every member exactly one unit: it runs when the CUs allow one workgroup
-    // per (channel, unit).  SGX_TRK_V1=1 (or an explicit SGX_TRK_SPLIT) keeps the round-1 cooperative kernel.
+    // The latency-mode kernel (sgx_trk2.hip) gives every member exactly one unit: it runs when the CUs allow one
+    // workgroup per (channel, unit) - and with one workgroup per (channel, unit, correlator arm) when they allow three
+    // times as many (SGX_TRK_ARMS=3 keeps one workgroup per unit).  SGX_TRK_V1=1 (or an explicit SGX_TRK_SPLIT) keeps
+    // the round-1 cooperative kernel.
     const char* v1 = getenv("SGX_TRK_V1");
     int cus_total = 0;
     SGX_HIP(hipDeviceGetAttribute(&cus_total, hipDeviceAttributeMultiprocessorCount, c->device));
     const int ch8 = ((n_ch + 7) / 8) * 8;
     bool use_v2 = !(v1 && v1[0] == '1') && !getenv("SGX_TRK_SPLIT") && !K.multi && K.n_units >= 2 && K.n_units <= T2_MAXP &&
                   ch8 * K.n_units <= cus_total;
+    const char* ae = getenv("SGX_TRK_ARMS");
+    const bool arm_split = use_v2 && 3 * ch8 * K.n_units <= cus_total && !(ae && ae[0] == '3');
+    const char* le = getenv("SGX_TRK_LDSPAD");   // dynamic LDS per workgroup (bytes); default: one workgroup per CU
+    const int lds_pad = le ? atoi(le) : 90112;
     const int split_v1 = K.split;
-    int reserved = 0;
+    // CUs claimed by a cooperative launch; given back on EVERY way out of this function
+    struct CuGuard {
+        int device, n;
+        ~CuGuard() { drop(); }
+        void drop() {
+            if (n) sgx_cu_release(device, n);
+            n = 0;
+        }
+    } reserved{c->device, 0};
     bool used_v2 = false;
+    int used_members = 0;
     hipError_t e = hipSuccess;
     int h_err = 0;
     // The cooperating workgroups of a channel wait for each other, so all of them must be resident at once.  If
@@ -243,22 +260,40 @@ static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
         const bool want_stream = r->loader && !r->load_done.load() && attempt == 0 && !(se2 && se2[0] == '0') && !K.multi &&
                                  !(split_v1 == 1 && n_ch > 128) && sample_bytes == 1;
         const bool v2 = use_v2 && attempt == 0 && !want_stream;
+        const int arms = (v2 && arm_split) ? 1 : 3;
         if (attempt == 0) K.split = v2 ? K.n_units : split_v1;
+        const int members = K.split * (arms == 1 ? 3 : 1);      // workgroups per channel
+        if (sample_bytes != 1 && !(v2 && K.split > 1)) {
+            if (attempt == 1)
+                sgx_set_error("tracking: channel %d timed out waiting for a cooperating workgroup; two-byte samples have "
+                              "no one-workgroup-per-channel kernel to fall back to", (h_err & 0xFFFF) - 1);
+            else
+                sgx_set_error("two-byte samples are tracked by the one-unit-per-workgroup kernel only: it needs %d free CUs "
+                              "(%d channels x %d units) and samplingFreq >= 16 x the chip rate", ch8 * K.n_units, ch8, K.n_units);
+            return attempt == 1 ? SGX_E_HIP : SGX_E_ARG;
+        }
         // Cooperating workgroups wait for each other, so all of a launch must be resident at once: one workgroup per CU
         // out of a per-device budget shared by every context of this process (a launch that does not fit the CUs left
         // by the others runs with one workgroup per channel, which needs no co-residency).
+        int arms_now = arms;
         if (K.split > 1) {
-            reserved = sgx_cu_reserve(c->device, cus_total, ch8 * K.split);
-            if (reserved == 0) {
+            reserved.n = sgx_cu_reserve(c->device, cus_total, ch8 * members);
+            if (reserved.n == 0 && arms == 1) {
+                arms_now = 3;                                    // the CUs left may still hold one workgroup per unit
+                reserved.n = sgx_cu_reserve(c->device, cus_total, ch8 * K.split);
+            }
+            if (reserved.n == 0) {
+                if (sample_bytes != 1) {
+                    sgx_set_error("two-byte samples are tracked by the one-unit-per-workgroup kernel only: it needs %d free "
+                                  "CUs (%d channels x %d units), other launches of this process hold them", ch8 * K.n_units,
+                                  ch8, K.n_units);
+                    return SGX_E_ARG;
+                }
                 K.split = 1;
             }
         }
-        if (sample_bytes != 1 && !(v2 && K.split > 1)) {
-            sgx_set_error("two-byte samples are tracked by the one-unit-per-workgroup kernel only: it needs %d free CUs "
-                          "(%d channels x %d units) and samplingFreq >= 16 x the chip rate", ch8 * K.n_units, ch8, K.n_units);
-            return SGX_E_ARG;
-        }
-        const int n_blocks = ch8 * K.split;
+        const int members_now = K.split * ((v2 && K.split > 1 && arms_now == 1) ? 3 : 1);
+        const int n_blocks = ch8 * members_now;
         // a record that is still streaming in: the cooperative kernel follows the device watermark; the other
         // kernels (and a repeated launch) first wait for the whole record
         const bool streaming = want_stream;
@@ -267,15 +302,17 @@ static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
             if (rq != SGX_OK) return rq;
         }
         K.mark = streaming ? r->d_mark : nullptr;
-        if (want_prof) SGX_HIP(hipMemsetAsync(d_prof, 0, sizeof(long long) * 64 * (size_t)n_ch, st));
+        if (want_prof) SGX_HIP(hipMemsetAsync(d_prof, 0, sz_prof, st));
         hipEventRecord(c->ev[3], st);
         if (streaming)
             sgx_trk_stream_launch(n_blocks, st, r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err);
         else if (v2 && K.split > 1) {
             const char* wh = getenv("SGX_TRK_TEST_WITHHOLD");   // test hook: launch without each channel's last member
             const int nb2 = (wh && wh[0] == '1') ? n_blocks - 8 : n_blocks;
-            sgx_trk2_launch(nb2, st, r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err, sample_bytes);
+            sgx_trk2_launch(nb2, st, r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err, sample_bytes, arms_now,
+                            lds_pad);
             used_v2 = true;
+            used_members = members_now;
         }
         else if (K.split == 1 && n_ch > 128)   // (general in the sampling rate: one lane per prompt chip)
             sgx_trk_tp_launch(n_blocks, st, r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err);
@@ -291,8 +328,7 @@ static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
         h_err = 0;
         if (e == hipSuccess) e = hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (reserved) sgx_cu_release(c->device, reserved);
-        reserved = 0;
+        reserved.drop();
         const char* th = getenv("SGX_TRK_TEST_TIMEOUT");   // test hook: treat the first attempt as timed out
         if (e == hipSuccess && th && th[0] == '1' && attempt == 0 && K.split > 1) h_err = 1;
         if (e == hipSuccess && (h_err & TRK_ERR_STREAM) && attempt == 0) {
@@ -310,22 +346,23 @@ static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
             return SGX_E_RANGE;
         }
         if (e != hipSuccess || h_err == 0 || K.split == 1) break;
-        fprintf(stderr, "[sgx] tracking: channel %d timed out waiting for a cooperating workgroup (split %d, are the "
-                        "CUs shared?); repeating the launch with one workgroup per channel\n", h_err - 1, K.split);
+        fprintf(stderr, "[sgx] tracking: channel %d timed out waiting for a cooperating workgroup (%d workgroups per "
+                        "channel, are the CUs shared?); repeating the launch with one workgroup per channel\n", h_err - 1,
+                members_now);
         K.split = 1;
     }
     if (e == hipSuccess && !direct) e = hipMemcpyAsync(out, d_out, elems * sizeof(double), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(ms_done, d_done, sizeof(int) * (size_t)n_ch, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (want_prof && e == hipSuccess) {
-        std::vector<long long> hp(64 * (size_t)n_ch);
+        std::vector<long long> hp(T2_PROF_STRIDE * (size_t)n_ch);
         hipMemcpy(hp.data(), d_prof, sizeof(long long) * hp.size(), hipMemcpyDeviceToHost);
         if (used_v2) {
             for (int i = 0; i < n_ch && i < 8; ++i)
-                for (int mm = 0; mm < K.split; mm += (i == 0 ? 1 : K.split - 1))
+                for (int mm = 0; mm < used_members; mm += (i == 0 ? 1 : used_members - 1))
                     fprintf(stderr, "[sgx trk2 profile] ch %d member %2d cycles/block: release->publish %.0f  publish->sums %.0f  "
-                                    "sums->release %.0f\n", i, mm, (double)hp[64 * i + mm] / ms,
-                            (double)hp[64 * i + 16 + mm] / ms, (double)hp[64 * i + 32 + mm] / ms);
+                                    "sums->release %.0f\n", i, mm, (double)hp[T2_PROF_STRIDE * i + mm] / ms,
+                            (double)hp[T2_PROF_STRIDE * i + 64 + mm] / ms, (double)hp[T2_PROF_STRIDE * i + 128 + mm] / ms);
         } else
         for (int i = 0; i < n_ch && i < 4; ++i)
             fprintf(stderr, "[sgx trk profile] ch %d cycles/block: map %.0f wait %.0f reduce %.0f filter %.0f\n", i,

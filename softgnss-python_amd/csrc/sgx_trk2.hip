@@ -1,35 +1,46 @@
-// TrackingResult.track on gfx950, latency-mode kernel of round 2 (reference tracking.py:13-295; SURVEY.md section 9
-// T1-T9).  Same decomposition as sgx_trk.hip - a channel's block is cut into units of 256 groups x 16 samples and
-// P workgroups (one unit each) cooperate on a channel - but the per-block dependency chain
+// TrackingResult.track on gfx950, latency-mode kernel (reference tracking.py:13-295).
+// A channel's block is cut into units of 256 groups x 16 samples and the workgroups of a channel (its MEMBERS)
+// cooperate on it.  The per-block dependency chain
 //     sums -> discriminators -> NCOs -> next block's parameters -> sums
-// is rebuilt around what each link really depends on:
+// is built around what each link really depends on and what each instruction on it costs (a lone wave issues one
+// fp64 / integer / DPP instruction every ~5.4 cycles whether or not it depends on the previous one, so the chain is
+// shortened by REMOVING INSTRUCTIONS from it and by moving work to other waves and other CUs):
 //
+//   members   ARMS = 1 (round 3, used when 3 x channels x units workgroups fit the CUs): a unit has THREE workgroups,
+//             one per correlator arm (early, prompt, late), on three CUs - a map lane then follows one code ramp,
+//             applies that arm's chips to the samples as sign flips (two FMAs per sample) and reduces two sums.
+//             ARMS = 3: one workgroup per unit follows all three ramps (the round-2 map; used when the CUs are scarce).
 //   roles     a workgroup has 7 waves: 4 MAP waves (256 lanes, one 16-sample group each), a PLL wave, a DLL wave and a
 //             RECORD wave.  One workgroup barrier per block hands the next block's parameters to the map waves.
-//   map       the 16 bytes of a lane are loaded and converted to fp64 one block ahead (the next block's first sample
-//             is known when the current block starts).  For each of the three code ramps the chip index at the group's
-//             first sample and the switch sample follow from ONE fused evaluation t0 = ilo*step + start and the distance
-//             to the next chip boundary in samples, u = (ceil(t0) - t0) / step: the reference's ramp
-//             t(i) = fl(fl(i*step)+start) differs from the real one by < 2.3e-13 chips, so ceil(t(i)) equals the real
+//   map       the 16 bytes of a lane are loaded and converted one block ahead (the next block's first sample is known
+//             when the current block starts).  The chip index at the group's first sample and the switch sample follow
+//             from ONE fused evaluation t0 = ilo*step + start and the distance to the next chip boundary in samples,
+//             u = (ceil(t0) - t0) / step, with step = codeFreq/fs: the reference's ramp t(i) = fl(fl(i*stp)+start)
+//             (stp = linspace's delta/blk) differs from that real ramp by < 1e-12 chips, so ceil(t(i)) equals the real
 //             ramp's for every sample of the group unless a boundary lies within that distance of a sample - excluded
 //             when frac(u) is outside [1e-7, 1 - 1e-7] samples (2.7e-9 chips).  A wave in which any lane fails the test
 //             (probability ~1e-5 per block; all of block 0, whose prompt ramp starts ON a boundary) takes the exact
-//             search of round 1 (ramp_setup).  Chip indices are therefore still bit-identical to
-//             code[int64(ceil(linspace(...)))] (tracking.py:166-188); the chips themselves are two bits of a packed
-//             sign table in LDS, read while the samples are accumulated.
-//   reduce    six fp64 partials per lane -> transposing DPP reduction inside each row of 16 lanes (no LDS) -> 2^-32
-//             fixed point -> integer LDS atomics (order-independent, hence deterministic) -> the wave that arrives last
-//             publishes the member's six sums with ONE 64-bit integer atomic per sum into the channel's exchange line
-//             in L2.  Every word carries an arrival count in its low 5 bits, lines are double-buffered by block parity
-//             and never reset (consumers difference against the previous value), so there is nothing to zero and no
-//             flag: the data is the flag.
-//   filter    the PLL and DLL waves of EVERY member poll the line (one 16-byte / two 16-byte L1-bypassing loads), turn
-//             the totals back into fp64 and run their half of the loop filter redundantly - bit-identical in all
-//             members, nothing to broadcast - with short-chain arithmetic (sgx_trk_math.h): reciprocal-based division
-//             and square root, a degree-8 Estrin atan on the locked range, Estrin sincos for the carrier tables, and
-//             a division-free ceil for the block length that falls back to the IEEE division when the quotient is
-//             within 4 ulp of an integer.  The end-of-block carrier phase and everything else that does not need the
-//             sums is computed while the wave waits.
+//             search (ramp_setup) with the exact linspace steps, which the DLL wave posts right after the barrier.
+//             Chip indices are therefore still bit-identical to code[int64(ceil(linspace(...)))] (tracking.py:166-188).
+//             ARMS = 1: the chips a lane can meet are an 8-bit window of the packed sign table held in a register.
+//   reduce    ARMS = 1: the lane's two sums go to fixed point (raw mantissa bits of fma(a, 2^28, 1.5 2^52): the bias
+//             cancels in the low 48 bits), a transposing DPP reduction with fused 64-bit integer adds leaves the row
+//             sums of I in the even and of Q in the odd lanes, and two lanes per row add them into one LDS word per sum
+//             whose high bits count the arrivals: the lane that sees 15 earlier arrivals holds the member's total and
+//             publishes it.  Integer adds are order-free, so the total is bit-identical whatever the arrival order.
+//             ARMS = 3: six fp64 partials, DPP row reduction, LDS slots, the wave that arrives last folds and publishes.
+//   exchange  one 8-byte granule per (sum, unit): {16-bit epoch tag | 48-bit two's-complement fixed point} written by
+//             ONE aligned store, double-buffered by block parity, never reset.  The PLL and DLL waves of EVERY member
+//             poll their part (L1-bypassing loads), add the payloads as integers and run their half of the loop filter
+//             redundantly - bit-identical in all members, nothing to broadcast.
+//   filter    only what the map waves need is on the chain.  DLL wave: discriminator, NCO, codeFreq/fs to 3 ulp, its
+//             reciprocal, and the block length by a guarded division-free ceil (the IEEE division decides when the
+//             quotient is within 6 ulp of an integer); the exact T1/T3/T4 arithmetic of the block (linspace steps, code
+//             phase and first sample of the next block) follows AFTER the barrier, off the chain.  PLL wave: a
+//             short-chain atan, NCO, and the carrier tables of the next block by ROTATION: the tables are computed in
+//             full (fp64 turns reduction + sincos) for the OLD rate while the wave waits for the sums, and the rate
+//             step dw turns each entry by exp(j dw m / fs), a degree-13 Taylor pair valid while |dw| m / fs <= 0.34 rad
+//             (~50 Hz of NCO step; beyond it the full evaluation runs on the chain).
 //   record    the 13 series values of a block are staged in LDS by member 0's filter waves and stored (to pinned host
 //             memory, directly) by the record wave one block later, so no wave on the chain ever waits for a store.
 //   abort     a poll that runs out of budget raises the channel's abort word; every member sees it in its next poll,
@@ -40,19 +51,22 @@
 
 #define T2_MAP 256                 // map lanes = groups per unit
 #define T2_THREADS 448             // 4 map waves + PLL wave (4) + DLL wave (5) + record wave (6)
-#define T2_MAXP 16                 // members per channel (arrival tag: 5 bits)
+#define T2_MAXP 16                 // units per channel
+#define T2_MAXM 48                 // members per channel (3 arms x 16 units)
 #define T2_XCH_STRIDE 256          // 64-bit words per channel in the exchange area:
-#define T2_XG 0                    //   [2 parities][6 words][16 members] granules
+#define T2_XG 0                    //   [2 parities][6 words][16 units] granules
 #define T2_XABORT 192              //   abort word
-#define T2_XPLACE 208              //   [16] placement granules
+#define T2_XPLACE 200              //   [48] placement granules
+#define T2_PROF_STRIDE 192         // profile words per channel: [3 phases][64 members]
 #define T2_FIX 268435456.0         // 2^28: fixed-point scale of a granule's 48-bit payload (member sums are < 2^19)
 #define T2_FIX16 524288.0          // 2^19: the same for two-byte samples (member sums are < 2^28)
 // SB = bytes per IF sample (1: int8, 2: int16).  Positions are counted in samples everywhere; only the loads, the
-// fixed-point scale and the reported file position (bytes, tracking.py:107 / fid.tell()) depend on it.
+// fixed-point scale and the reported file position (bytes, tracking.py:107 / fid.tell(), tracking.py:255) depend on it.
 template <int SB>
 __device__ __forceinline__ constexpr double t2_fix() { return SB == 1 ? T2_FIX : T2_FIX16; }
 #define T2_MAGIC 6755399441055744.0   // 1.5 * 2^52: fl(x + MAGIC) holds round(x) in its low mantissa bits
 #define T2_POLL_BUDGET (1 << 20)
+#define T2_ROT_MAX 0.34            // largest rotation angle (rad) the Taylor pair of t2_rot_small is good for
 
 // -DTRK_FINEPROF=1: time stamps at the natural synchronisation points only (poll exits, barriers) - undisturbed timing.
 // -DTRK_FINEPROF=2: every probe, each preceded by a full wait - attributes the time inside a role, inflates the total.
@@ -88,13 +102,16 @@ struct __attribute__((aligned(128))) T2Code {   // code side of a block's parame
     int blk;
     int stop;               // 1: the record ends inside this block (tracking.py:159-163); 2: a member gave up waiting;
                             // 3: the block does not fit the units of the launch
-    int pad0[2];
-    double step[3];         // ramp steps E, P, L (tracking.py:166-188)
-    double inv_step;        // 1 / codePhaseStep (distances to chip boundaries in samples)
+    double inv_step;        // ~1 / step (2^-48): distances to chip boundaries in samples
+    double step;            // codeFreq / fs to 3 ulp: the slope of the real ramps (the guard covers the difference)
     // early part: known one block earlier (written while the previous block is processed)
+    double start_arm;       // ramp start of this workgroup's arm (ARMS = 1; shares a 16-byte read with step)
+    double start[3];        // ramp starts E, P, L
     long long pos;          // record index of the block's first sample
-    long long pad1;
-    double start[4];        // ramp starts E, P, L
+    // exact part: posted right after the barrier that starts the block (the exact search needs it, ~1e-5 of the waves)
+    double stp[3];          // linspace steps E, P, L (tracking.py:166-188)
+    volatile int xflag;     // block number + 1 once stp[] is valid
+    int pad;
 };
 
 struct T2Carr {   // carrier side (PLL wave -> map waves), double-buffered: (cos, sin)(2 pi r m), r = turns per sample
@@ -128,8 +145,27 @@ __device__ __forceinline__ long long dpp_movl(long long v) {
     return ((long long)ohi << 32) | (unsigned)olo;
 }
 
-// chip (as the high dword of +-1.0) of extended-code index k, k in [-1, 1026]
-__device__ __forceinline__ unsigned chip_hi(const unsigned* s_chip, int k) { return s_chip[k + 1]; }
+// b + dpp(a) on 64-bit integers with the DPP source fused into the two adds (VOP2 DPP forms: two instructions per
+// step instead of two moves and two adds).  s_nop 1: a DPP source written by the previous VALU instruction needs two
+// wait states, which the assembler does not insert inside an asm block.
+#define T2_DPP_ADDL(NAME, CTRLSTR)                                                                                  \
+    __device__ __forceinline__ unsigned long long NAME(unsigned long long a, unsigned long long b) {               \
+        const unsigned alo = (unsigned)a, ahi = (unsigned)(a >> 32), blo = (unsigned)b, bhi = (unsigned)(b >> 32);  \
+        unsigned olo, ohi;                                                                                          \
+        asm volatile("s_nop 1\n\t"                                                                                  \
+                     "v_add_co_u32_dpp %0, vcc, %2, %4 " CTRLSTR " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"     \
+                     "v_addc_co_u32_dpp %1, vcc, %3, %5, vcc " CTRLSTR " row_mask:0xf bank_mask:0xf bound_ctrl:1"   \
+                     : "=&v"(olo), "=&v"(ohi)                                                                       \
+                     : "v"(alo), "v"(ahi), "v"(blo), "v"(bhi)                                                       \
+                     : "vcc");                                                                                      \
+        return ((unsigned long long)ohi << 32) | olo;                                                               \
+    }
+T2_DPP_ADDL(dpp_addl_xor1, "quad_perm:[1,0,3,2]")
+T2_DPP_ADDL(dpp_addl_xor2, "quad_perm:[2,3,0,1]")
+T2_DPP_ADDL(dpp_addl_ror4, "row_ror:4")
+T2_DPP_ADDL(dpp_addl_ror8, "row_ror:8")
+T2_DPP_ADDL(dpp_addl_hmir, "row_half_mirror")
+T2_DPP_ADDL(dpp_addl_mir, "row_mirror")
 
 // Sign bits of the extended code in LDS: bit k + 1 of the packed table is set where chip k is -1 (k in [-1, 1054]).
 // Two adjacent chips (k, k + 1) from one 8-byte read.
@@ -158,96 +194,49 @@ __device__ __forceinline__ void ramp_locate(double start, double step, double in
     isw = ilo + (int)fu + 1;
 }
 
-// Carrier phasor tables of a block with rate w (rad/s), start phase rc and `head` bytes between the 16-byte boundary and
-// the block's first sample (T5): one entry per lane, B | W1 | W2 | this member's W3 (lanes 48..63 all hold W3).
-__device__ __forceinline__ void t2_carr_tables(double inv_2pifs_hi, double inv_2pifs_lo, double inv_2pi, double w, double rc,
-                                               int head, int member, T2Carr& CN, int lane) {
+// ---- carrier tables (T5): entry `lane` of B | W1 | W2 | W3 (lanes 48..63 all hold this member's W3) ----
+// table index multiplier: the entry is the phasor of sample m of the block
+__device__ __forceinline__ int t2_carr_mult(int lane, int unit, int head) {
+    const int sel = lane >> 4, idx = lane & 15;
+    return (sel == 3) ? (TRK_UNIT * unit - head) : (idx << (4 * sel));
+}
+
+// (cos, sin)(w m / fs [+ rc for W3]) evaluated in full: fp64 "turns" reduction with w / (2 pi fs) as a double-double
+__device__ __forceinline__ void t2_carr_entry(double inv_2pifs_hi, double inv_2pifs_lo, double inv_2pi, double w, double rc,
+                                              int mi, bool w3, double& cs, double& sn) {
     const double r_hi = w * inv_2pifs_hi;
     const double r_lo = __builtin_fma(w, inv_2pifs_hi, -r_hi) + w * inv_2pifs_lo;
-    const int sel = lane >> 4, idx = lane & 15;
-    const int mi = (sel == 3) ? (TRK_UNIT * member - head) : (idx << (4 * sel));
     const double mult = (double)mi;
     const double pp = r_hi * mult;
     const double ee = __builtin_fma(r_hi, mult, -pp) + r_lo * mult;
     double u = (pp - floor(pp)) + ee;
     const double u3 = u + rc * inv_2pi;        // < 2
-    u = (sel == 3) ? (u3 - ((u3 >= 1.0) ? 1.0 : 0.0)) : u;
-    double sn, cs;
+    u = w3 ? (u3 - ((u3 >= 1.0) ? 1.0 : 0.0)) : u;
     sgx_sincos_turns_short(u, sn, cs);
-    // B, W1, W2 are consecutive 16-entry tables, W3 follows: lanes 48..63 all store the same W3
-    CN.T[lane < 48 ? lane : 48] = make_double2(cs, sn);
 }
 
-// DLL-wave constants and the loop state it carries in registers.  Lanes work in parallel on the three ramps:
-// lane & 3 = 0 early, 1 prompt, 2 late (3 repeats prompt); uniform results come from lane 1 / lane 0.
-struct T2DllConst {
-    double fs, inv_fs, code_len, spacing;
-    double inv_nb_lane;     // RN(1 / (nb_base + (lane & 7))): reciprocals of the plausible block lengths, one per lane
-    int nb_base;
-    long long rec_len;
-};
-
-struct T2DllState {      // everything about the block being processed that the DLL wave needs again
-    double rem;          // remCodePhase at the block's start
-    long long pos;       // its first sample
-    double step;         // codePhaseStep = codeFreq / fs (T1)
-    double stp;          // the lane's ramp step (lane & 3: E, P, L, P)
-    int blk;
-};
-
-// Chain part of the next block's parameters (T1, T3): block size and ramp steps from the new code frequency; the
-// block starts at pos_n with code phase rem_n.  Writes N's chain part; returns the new state.
-__device__ __forceinline__ T2DllState t2_code_chain(const T2DllConst& D, double codeFreq, double rem_n, long long pos_n,
-                                                    bool gave_up, int P, T2Code& N, int lane) {
-    const int l4 = lane & 3;
-    const double off = (l4 == 0) ? -D.spacing : ((l4 == 2) ? D.spacing : 0.0);   // rem - spc == rem + (-spc) exactly
-    const double step = div_rn(codeFreq, D.fs, D.inv_fs);                       // codeFreq / fs
-    const int blk = sgx_ceil_div(D.code_len - rem_n, step);
-    const double nb = (double)blk;
-    const double span = nb * step;                                              // blksize * codePhaseStep
-    const int ki = blk - D.nb_base;
-    const bool known = (ki >= 0 && ki < 8);
-    const int kq = __builtin_amdgcn_readfirstlane(ki) & 7;
-    const double ynb = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(D.inv_nb_lane), kq),
-                                        __builtin_amdgcn_readlane(__double2loint(D.inv_nb_lane), kq));
-    // np.linspace(start, stop, blk, endpoint=False): delta = stop - start; step = delta / blk
-    const double start = rem_n + off;
-    const double d = ((span + rem_n) + off) - start;
-    double stp;
-    if (__builtin_expect(known, 1)) stp = div_rn(d, nb, ynb);
-    else stp = d / nb;
-    if (lane < 3) N.step[lane] = stp;
-    if (lane == 0) {
-        const int stop = gave_up ? 2 : ((blk <= 0 || pos_n + blk > D.rec_len) ? 1 : ((blk + 15 > P * TRK_UNIT) ? 3 : 0));
-        *reinterpret_cast<int4*>(&N.blk) = make_int4(blk, stop, 0, 0);
-        N.inv_step = sgx_fast_rcp(step);
-    }
-    T2DllState st;
-    st.rem = rem_n;
-    st.pos = pos_n;
-    st.step = step;
-    st.stp = stp;
-    st.blk = blk;
-    return st;
-}
-
-// Code phase and first sample of the block after `st` (T4) and that block's ramp starts (its early part): nothing here
-// needs the sums of `st`.
-__device__ __forceinline__ void t2_code_late(const T2DllConst& D, const T2DllState& st, T2Code& N, int lane, double& rem_next,
-                                             long long& pos_next) {
-    const int l4 = lane & 3;
-    const double off = (l4 == 0) ? -D.spacing : ((l4 == 2) ? D.spacing : 0.0);
-    const double start = st.rem + off;
-    const double t_last = ramp_at(st.blk - 1, st.stp, start);
-    const double rn_lane = (t_last + st.step) - 1023.0;                         // T4 (meaningful in the prompt lane)
-    rem_next = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rn_lane), 1),
-                                __builtin_amdgcn_readlane(__double2loint(rn_lane), 1));
-    pos_next = st.pos + st.blk;
-    if (lane < 3) N.start[lane] = rem_next + off;
-    if (lane == 0) N.pos = pos_next;
+// sin and cos of a small angle, |ph| <= T2_ROT_MAX: Taylor to ph^13 / ph^12 (next terms 6e-20 / 3e-18), Estrin
+__device__ __forceinline__ void t2_rot_small(double ph, double& sn, double& cs) {
+    const double t = ph * ph;
+    const double t2 = t * t;
+    const double t4 = t2 * t2;
+    const double pt = ph * t;
+    const double s01 = __builtin_fma(8.3333333333333332e-03, t, -1.6666666666666666e-01);
+    const double s23 = __builtin_fma(2.7557319223985893e-06, t, -1.9841269841269841e-04);
+    const double s45 = __builtin_fma(1.6059043836821613e-10, t, -2.5052108385441720e-08);
+    const double c01 = __builtin_fma(4.1666666666666664e-02, t, -0.5);
+    const double c23 = __builtin_fma(2.4801587301587302e-05, t, -1.3888888888888889e-03);
+    const double c45 = __builtin_fma(2.0876756987868100e-09, t, -2.7557319223985888e-07);
+    const double sa = __builtin_fma(s23, t2, s01);
+    const double ca = __builtin_fma(c23, t2, c01);
+    const double ps = __builtin_fma(s45, t4, sa);
+    const double pc = __builtin_fma(c45, t4, ca);
+    sn = __builtin_fma(pt, ps, ph);
+    cs = __builtin_fma(t, pc, 1.0);
 }
 
 #define T2_PIN(x) asm volatile("" : "+v"(x))
+#define T2_USE(x) asm volatile("" : : "v"(x))   // the value is needed HERE: its load is not sunk below a later branch
 
 // Everything a role needs that lives in LDS.
 struct T2Shared {
@@ -255,8 +244,9 @@ struct T2Shared {
     unsigned cbits[40];             // the same as packed sign bits: bit k + 1 set where chip k is -1
     T2Code code[2];
     T2Carr carr[2];
-    double part[2][16][8];          // row sums of the map waves by block parity: [wave * 4 + row][word]
-    unsigned ticket[2][2];          // arrival ticket of the map waves, by block parity
+    double part[2][16][8];          // ARMS = 3: row sums of the map waves by block parity: [wave * 4 + row][word]
+    unsigned long long acc[2][2];   // ARMS = 1: {arrival count << 56 | 48-bit fixed-point sum} of I, Q by block parity
+    unsigned ticket[2][2];          // ARMS = 3: arrival ticket of the map waves, by block parity
     double rec[2][16];              // a block's 13 series values (member 0), stored one block later
     int flag[4];                    // [0] same-XCD placement, [1] abort seen by this workgroup
     int rflag[4];                   // [0] PLL wave, [1] DLL wave: number of blocks whose record values are in rec[]
@@ -293,40 +283,44 @@ __device__ __forceinline__ T2Raw<SB> t2_load(const int8_t* __restrict__ rec, lon
     return r;
 }
 
-// 16 int16 samples -> fp64, samples before the block's first one (i0 + b < 0) zeroed
-__device__ __forceinline__ void t2_convert(const T2Raw<2>& raw, int i0, double (&xd)[16]) {
-#define T2_CV(b, w, hi)                                                                          \
-    {                                                                                            \
-        const int xi_ = hi ? ((int)(w) >> 16) : (int)(short)((w) & 0xFFFF);                      \
-        xd[b] = (i0 + b >= 0) ? (double)xi_ : 0.0;                                               \
-    }
-    T2_CV(0, raw.a.x, 0) T2_CV(1, raw.a.x, 1) T2_CV(2, raw.a.y, 0) T2_CV(3, raw.a.y, 1)
-    T2_CV(4, raw.a.z, 0) T2_CV(5, raw.a.z, 1) T2_CV(6, raw.a.w, 0) T2_CV(7, raw.a.w, 1)
-    T2_CV(8, raw.b.x, 0) T2_CV(9, raw.b.x, 1) T2_CV(10, raw.b.y, 0) T2_CV(11, raw.b.y, 1)
-    T2_CV(12, raw.b.z, 0) T2_CV(13, raw.b.z, 1) T2_CV(14, raw.b.w, 0) T2_CV(15, raw.b.w, 1)
-#undef T2_CV
-}
-
-// 16 int8 samples -> fp64, samples before the block's first one (i0 + b < 0) zeroed
-__device__ __forceinline__ void t2_convert(const T2Raw<1>& raw1, int i0, double (&xd)[16]) {
-    const uint4& raw = raw1.a;
-#define T2_CV(b, w, sh)                                                                          \
-    {                                                                                            \
-        const int xi_ = (sh == 24) ? ((int)(w) >> 24) : (int)(signed char)(((w) >> sh) & 0xFF);  \
-        xd[b] = (i0 + b >= 0) ? (double)xi_ : 0.0;                                               \
-    }
-    T2_CV(0, raw.x, 0) T2_CV(1, raw.x, 8) T2_CV(2, raw.x, 16) T2_CV(3, raw.x, 24)
-    T2_CV(4, raw.y, 0) T2_CV(5, raw.y, 8) T2_CV(6, raw.y, 16) T2_CV(7, raw.y, 24)
-    T2_CV(8, raw.z, 0) T2_CV(9, raw.z, 8) T2_CV(10, raw.z, 16) T2_CV(11, raw.z, 24)
-    T2_CV(12, raw.w, 0) T2_CV(13, raw.w, 8) T2_CV(14, raw.w, 16) T2_CV(15, raw.w, 24)
-#undef T2_CV
-}
-
-// ================================ MAP (waves 0-3) ================================
+// sample b of a lane's 16 as an integer
 template <int SB>
-__device__ __forceinline__ int t2_map_role(T2Shared& S, const int8_t* __restrict__ rec, long long rec_alloc, int ms,
-                                           long long pos0, int member, int tid, unsigned long long* __restrict__ xbase,
-                                           bool fast, bool prof_on, bool prof_any) {
+__device__ __forceinline__ int t2_sample(const T2Raw<SB>& raw, int b) {
+    if constexpr (SB == 1) {
+        const unsigned w = (b < 4) ? raw.a.x : (b < 8) ? raw.a.y : (b < 12) ? raw.a.z : raw.a.w;
+        const int sh = 8 * (b & 3);
+        return (sh == 24) ? ((int)w >> 24) : (int)(signed char)((w >> sh) & 0xFF);
+    } else {
+        const uint4& q = (b < 8) ? raw.a : raw.b;
+        const int bb = b & 7;
+        const unsigned w = (bb < 2) ? q.x : (bb < 4) ? q.y : (bb < 6) ? q.z : q.w;
+        return (bb & 1) ? ((int)w >> 16) : (int)(short)(w & 0xFFFF);
+    }
+}
+
+// 16 samples -> fp64, samples before the block's first one (i0 + b < 0) zeroed
+template <int SB>
+__device__ __forceinline__ void t2_convert(const T2Raw<SB>& raw, int i0, double (&xd)[16]) {
+#pragma unroll
+    for (int b = 0; b < 16; ++b) xd[b] = (i0 + b >= 0) ? (double)t2_sample<SB>(raw, b) : 0.0;
+}
+
+// 16 samples -> the HIGH dwords of their fp64 values (small integers: the low dword is zero); samples outside the
+// block [0, cut) are zeroed
+template <int SB>
+__device__ __forceinline__ void t2_convert_hi(const T2Raw<SB>& raw, int i0, int cut, unsigned (&xh)[16]) {
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+        const unsigned hi = (unsigned)__double2hiint((double)t2_sample<SB>(raw, b));
+        xh[b] = ((unsigned)(i0 + b) < (unsigned)cut) ? hi : 0u;
+    }
+}
+
+// ================================ MAP (waves 0-3), one workgroup per unit: all three arms ================================
+template <int SB>
+__device__ __forceinline__ int t2_map3_role(T2Shared& S, const int8_t* __restrict__ rec, long long rec_alloc, int ms,
+                                            long long pos0, int member, int tid, unsigned long long* __restrict__ xbase,
+                                            bool fast, bool prof_on, bool prof_any) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const long long limit = rec_alloc - 16;                  // bytes: the last 16-byte word that may be loaded
@@ -359,7 +353,7 @@ __device__ __forceinline__ int t2_map_role(T2Shared& S, const int8_t* __restrict
         i0 = g * 16 - head_;                                                                                   \
         ilo = i0 < 0 ? 0 : i0;                                                                                 \
         ilod = (double)ilo;                                                                                    \
-        t2_convert(raw, i0, xd);                                                                               \
+        t2_convert<SB>(raw, i0, xd);                                                                           \
         blk_pred = (BLK_PRED);                                                                                 \
         T2_CUT(blk_pred);                                                                                      \
     } while (0)
@@ -371,8 +365,9 @@ __device__ __forceinline__ int t2_map_role(T2Shared& S, const int8_t* __restrict
         const int par = it & 1;
         const T2Code& C = S.code[par];
         // one batch of LDS reads: chain part, early part, the lane's carrier phasors
-        const int4 hd = *reinterpret_cast<const int4*>(&C.blk);      // blk, stop
-        const double stepE = C.step[0], stepP = C.step[1], stepL = C.step[2], inv_step = C.inv_step;
+        const int4 hd = *reinterpret_cast<const int4*>(&C.blk);      // blk, stop, inv_step
+        const double step = C.step;
+        const double inv_step = __hiloint2double(hd.w, hd.z);
         const double startE = C.start[0], startP = C.start[1], startL = C.start[2];
         const long long pos = C.pos;
         const T2Carr& CR = S.carr[par];
@@ -386,14 +381,18 @@ __device__ __forceinline__ int t2_map_role(T2Shared& S, const int8_t* __restrict
         T2PROBE(prof_on, 0);   // parameters read, next block's load issued
         int kE, kP, kL, swE, swP, swL;
         bool bad = false;
-        ramp_locate(startE, stepE, inv_step, ilod, ilo, kE, swE, bad);
-        ramp_locate(startP, stepP, inv_step, ilod, ilo, kP, swP, bad);
-        ramp_locate(startL, stepL, inv_step, ilod, ilo, kL, swL, bad);
+        ramp_locate(startE, step, inv_step, ilod, ilo, kE, swE, bad);
+        ramp_locate(startP, step, inv_step, ilod, ilo, kP, swP, bad);
+        ramp_locate(startL, step, inv_step, ilod, ilo, kL, swL, bad);
         if (__builtin_expect(__any(bad && i0 < blk), 0)) {
-            // a chip boundary within 1e-7 samples of a sample somewhere in this wave: exact search (round-1 path)
-            ramp_setup(startE, stepE, inv_step, ilo, kE, swE);
-            ramp_setup(startP, stepP, inv_step, ilo, kP, swP);
-            ramp_setup(startL, stepL, inv_step, ilo, kL, swL);
+            // a chip boundary within 1e-7 samples of a sample somewhere in this wave: exact search with the exact
+            // linspace steps (posted by the DLL wave right after the barrier)
+            int budget = 1 << 20;
+            while (C.xflag != it + 1 && --budget) __builtin_amdgcn_s_sleep(1);
+            const double stpE = C.stp[0], stpP = C.stp[1], stpL = C.stp[2];
+            ramp_setup(startE, stpE, inv_step, ilo, kE, swE);
+            ramp_setup(startP, stpP, inv_step, ilo, kP, swP);
+            ramp_setup(startL, stpL, inv_step, ilo, kL, swL);
         }
         // chips k1 and k1 + 1 of every ramp (two sign bits each); they are needed only after the accumulation
         const unsigned bE = chip_bits2(S.cbits, kE), bP = chip_bits2(S.cbits, kP), bL = chip_bits2(S.cbits, kL);
@@ -414,7 +413,7 @@ __device__ __forceinline__ int t2_map_role(T2Shared& S, const int8_t* __restrict
             // end convert their bytes again and cut them at the real length
             const int lo_ = blk < blk_pred ? blk : blk_pred, hi_ = blk < blk_pred ? blk_pred : blk;
             if (__any(i0 < hi_ && i0 + 16 > lo_)) {
-                t2_convert(raw, i0, xd);
+                t2_convert<SB>(raw, i0, xd);
                 T2_CUT(blk);
             }
         }
@@ -450,8 +449,7 @@ __device__ __forceinline__ int t2_map_role(T2Shared& S, const int8_t* __restrict
             }
         } else {
             // samples b >= bsw come after the switch.  The samples are small integers, so their fp64 low dword is zero
-            // and masking the HIGH dword alone zeroes one: xt_hi = xd_hi & ((b - bsw) >> 31 ? 0 : ~0) - plain integer
-            // VALU, no compare/select round trip through VCC per sample
+            // and masking the HIGH dword alone zeroes one
             int bsw = swmin - i0;
             bsw = bsw > 16 ? 16 : bsw;
             double Ac = 0.0, As = 0.0, Tc = 0.0, Ts = 0.0;
@@ -533,30 +531,200 @@ __device__ __forceinline__ int t2_map_role(T2Shared& S, const int8_t* __restrict
         raw = nraw;
         T2_PREPARE(pos_next, blk);
         T2STAMP(prof_on, 6);   // next block prepared
+        __builtin_amdgcn_sched_barrier(0);   // (the conversions above stay in the barrier's shadow)
         wg_barrier();
+        __builtin_amdgcn_sched_barrier(0);
         T2STAMP(prof_on, 7);   // waiting for the loop filter
     }
     T2_FP_PRINT(prof_on && lane == 0, 0, 8)
     return it;
+#undef T2_CUT
+#undef T2_PREPARE
+}
+
+// ================================ MAP (waves 0-3), one workgroup per (unit, arm) ================================
+// The lane follows ONE code ramp.  Its chips enter as sign flips of the samples: with c1 the chip at the group's first
+// sample and c2 the next one, sum_b c(b) x_b B_b = c1 * sum_b f_b x_b B_b, f_b = +1 before the switch sample and
+// c1 c2 after it; c1 goes onto the group phasor.  Two FMAs, one compare and one select per sample.
+template <int SB>
+__device__ __forceinline__ int t2_map1_role(T2Shared& S, const int8_t* __restrict__ rec, long long rec_alloc, int ms,
+                                            long long pos0, int unit, int arm, int tid,
+                                            unsigned long long* __restrict__ xbase, bool fast, double step_nom, double spacing,
+                                            bool prof_on, bool prof_any) {
+    const int lane = tid & 63;
+    const long long limit = rec_alloc - 16;                  // bytes: the last 16-byte word that may be loaded
+    const int g = (tid & 255) + unit * T2_MAP;               // the lane's group inside the block's aligned window
+    const long long lane_off = (long long)g * 16;
+    const int wbase = (arm == 1) ? 0 : ((arm == 0) ? 2 : 4); // exchange order I_P Q_P I_E Q_E I_L Q_L
+    T2_FP_DECL
+    (void)prof_on;
+    // The chips this lane can meet: the group's first sample sits at t0 = (16 g - head) step + rem + offset chips with
+    // head in [0, 15] and rem in [0, step), i.e. inside a 0.46-chip interval while the code NCO stays near its basis.
+    // Eight sign bits from chip `ws` on cover a code-rate error of 0.4 % (4 kHz); beyond that the wave reads LDS.
+    int ws;
+    unsigned win;
+    {
+        const double off = (arm == 0) ? -spacing : ((arm == 2) ? spacing : 0.0);
+        const int kb = (int)ceil((double)(16 * g - 15) * step_nom + off - 0.02);
+        ws = kb - 1 < -1 ? -1 : kb - 1;
+        const int bi = ws + 1;                               // bit k + 1 of the packed table is chip k
+        const unsigned lo = S.cbits[bi >> 5], hi = S.cbits[(bi >> 5) + 1];
+        win = (unsigned)((((unsigned long long)hi << 32) | lo) >> (bi & 31)) & 0xFFu;
+    }
+    // state prepared one block ahead
+    unsigned xh[16];                 // high dwords of the samples as fp64, zero outside the block
+    int i0, ilo;
+    double ilod;
+    T2Raw<SB> raw;
+    int blk_pred;                    // block length the prepared samples are cut for
+    long long pos = pos0;            // first sample of the current block
+    long long win_pred;              // first sample of this lane's window in the NEXT block if that block is blk_pred long
+
+#define T2_PREPARE1(BLK_PRED)                                                                                  \
+    do {                                                                                                       \
+        const int head_ = (int)(pos & 15);                                                                     \
+        i0 = g * 16 - head_;                                                                                   \
+        ilo = i0 < 0 ? 0 : i0;                                                                                 \
+        ilod = (double)ilo;                                                                                    \
+        blk_pred = (BLK_PRED);                                                                                 \
+        t2_convert_hi<SB>(raw, i0, blk_pred, xh);                                                              \
+        win_pred = ((pos + blk_pred) & ~15ll) + lane_off;                                                      \
+    } while (0)
+
+    raw = t2_load<SB>(rec, (pos0 & ~15ll) + lane_off, limit);
+    T2_PREPARE1(S.code[0].blk);
+    int it = 0;
+    for (; it < ms; ++it) {
+        const int par = it & 1;
+        const T2Code& C = S.code[par];
+        // one batch of LDS reads: chain part, this arm's ramp start, the lane's carrier phasors
+        const int4 hd = *reinterpret_cast<const int4*>(&C.blk);          // blk, stop, inv_step
+        const double2 sp = *reinterpret_cast<const double2*>(&C.step);   // step, start_arm
+        const T2Carr& CR = S.carr[par];
+        const double2 w1 = CR.T[T2_W1 + (tid & 15)], w2 = CR.T[T2_W2 + ((tid >> 4) & 15)], w3 = CR.T[T2_W3];
+        T2_USE(hd.z); T2_USE(sp.x); T2_USE(w1.x); T2_USE(w2.x); T2_USE(w3.x);   // one batch, one wait
+        if (hd.y) break;
+        T2_FP_TOP
+        __builtin_amdgcn_s_setprio(2);
+        const int blk = hd.x;
+        const double inv_step = __hiloint2double(hd.w, hd.z);
+        // next block's bytes: the address was prepared for the predicted length
+        long long nwin = win_pred;
+        if (__builtin_expect(blk != blk_pred, 0)) nwin = ((pos + blk) & ~15ll) + lane_off;
+        const T2Raw<SB> nraw = t2_load<SB>(rec, nwin, limit);
+        T2PROBE(prof_on, 0);   // parameters read, next block's load issued
+        int k1, isw;
+        bool bad = false;
+        ramp_locate(sp.y, sp.x, inv_step, ilod, ilo, k1, isw, bad);
+        int sh = k1 - ws;
+        unsigned bits;
+        if (__builtin_expect(__any(i0 < blk && (bad || (unsigned)sh > 6u)), 0)) {
+            // a chip boundary within 1e-7 samples of a sample somewhere in this wave (or a chip outside the window):
+            // exact search with the exact linspace step (posted by the DLL wave right after the barrier), chips from LDS
+            int budget = 1 << 20;
+            while (C.xflag != it + 1 && --budget) __builtin_amdgcn_s_sleep(1);
+            ramp_setup(sp.y, C.stp[arm], inv_step, ilo, k1, isw);
+            bits = chip_bits2(S.cbits, k1);
+        } else {
+            bits = (win >> (sh & 7)) & 3u;
+        }
+        // switch sample inside the group; a group whose two chips are equal has none
+        const unsigned flip = (bits ^ (bits >> 1)) & 1u;
+        int bsw = isw - i0;
+        bsw = flip ? bsw : 16;
+        const unsigned s1 = bits << 31;                       // sign of the first chip (bit set: -1)
+        if (__builtin_expect(blk != blk_pred, 0)) {
+            // the block is a sample longer or shorter than predicted (about one block in ten): the lanes around its
+            // end convert their bytes again and cut them at the real length
+            const int lo_ = blk < blk_pred ? blk : blk_pred, hi_ = blk < blk_pred ? blk_pred : blk;
+            if (__any(i0 < hi_ && i0 + 16 > lo_)) t2_convert_hi<SB>(raw, i0, blk, xh);
+        }
+        // group-start phasor G = W1[tid & 15] * W2[(tid >> 4) & 15] * W3, times the first chip
+        double gc, gs;
+        {
+            const double lc = __builtin_fma(w1.x, w2.x, -(w1.y * w2.y));
+            const double ls = __builtin_fma(w1.x, w2.y, w1.y * w2.x);
+            gc = __builtin_fma(lc, w3.x, -(ls * w3.y));
+            gs = __builtin_fma(lc, w3.y, ls * w3.x);
+            gc = __hiloint2double((int)((unsigned)__double2hiint(gc) ^ s1), __double2loint(gc));
+            gs = __hiloint2double((int)((unsigned)__double2hiint(gs) ^ s1), __double2loint(gs));
+        }
+        T2PROBE(prof_on, 1);   // switch sample resolved, group phasor
+        double Ac = 0.0, As = 0.0;
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            const double2 Bb = CR.T[T2_B + b];
+            const unsigned h = (b >= bsw) ? (xh[b] ^ 0x80000000u) : xh[b];
+            const double xs = __hiloint2double((int)h, 0);
+            Ac = __builtin_fma(xs, Bb.x, Ac);
+            As = __builtin_fma(xs, Bb.y, As);
+        }
+        T2PROBE(prof_on, 2);   // 16-sample accumulation
+        // rotate by the group phasor: cos part -> Q, sin part -> I (tracking.py:205-207)
+        const double aQ = __builtin_fma(gc, Ac, -(gs * As));
+        const double aI = __builtin_fma(gs, Ac, gc * As);
+        // fixed point: the raw bits of fma(a, 2^28, 1.5 2^52) are bias + round(a 2^28); sums of them carry the sum of
+        // the integers in their low 48 bits whatever the bias adds up to
+        const unsigned long long qI = (unsigned long long)__double_as_longlong(__builtin_fma(aI, t2_fix<SB>(), T2_MAGIC));
+        const unsigned long long qQ = (unsigned long long)__double_as_longlong(__builtin_fma(aQ, t2_fix<SB>(), T2_MAGIC));
+        T2PROBE(prof_on, 3);   // group finalisation
+        // transposing reduction inside each row of 16 lanes: even lanes end with the row's I, odd lanes with its Q
+        const bool b0 = (lane & 1) != 0;
+        unsigned long long v = dpp_addl_xor1(b0 ? qI : qQ, b0 ? qQ : qI);
+        v = dpp_addl_xor2(v, v);
+        v = dpp_addl_ror4(v, v);
+        v = dpp_addl_ror8(v, v);
+        T2PROBE(prof_on, 4);   // row reduction
+        if ((lane & 15) < 2) {
+            const unsigned long long mine = (v & 0xFFFFFFFFFFFFull) | (1ull << 56);
+            const unsigned long long prev = atomicAdd(&S.acc[par][lane & 1], mine);
+            if ((prev >> 56) == 15ull) {
+                // the sixteenth arrival (4 waves x 4 rows): this lane holds the member's total
+                const unsigned long long tot = prev + mine;
+                S.acc[par][lane & 1] = 0ull;
+                const unsigned long long gran = ((unsigned long long)((unsigned)(it + 1) & 0xFFFFu) << 48) | (tot & 0xFFFFFFFFFFFFull);
+                granule_store(xbase + T2_XG + par * 96 + (wbase + (lane & 1)) * 16 + unit, gran, fast);
+                if (prof_any && (lane & 1) == 0) S.tpub[par] = (long long)__builtin_amdgcn_s_memtime();
+            }
+        }
+        T2STAMP(prof_on, 5);   // published (or handed to the lane that publishes)
+        // ---- shadow: prepare the next block with this block's length ----
+        __builtin_amdgcn_s_setprio(0);
+        raw = nraw;
+        pos += blk;
+        T2_PREPARE1(blk);
+        T2STAMP(prof_on, 6);   // next block prepared
+        __builtin_amdgcn_sched_barrier(0);   // (the conversions above stay in the barrier's shadow)
+        wg_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        T2STAMP(prof_on, 7);   // waiting for the loop filter
+    }
+    T2_FP_PRINT(prof_on && lane == 0, 0, 8)
+    return it;
+#undef T2_PREPARE1
 }
 
 // ================================ PLL (wave 4) ================================
 template <int SB>
-__device__ __forceinline__ int t2_pll_role(T2Shared& S, const TrkConst& K, const TrkChan& cc, int member, int lane, int P,
-                                           int ch, unsigned long long* __restrict__ xbase, int* __restrict__ err,
-                                           bool prof_on, long long* __restrict__ prof) {
+__device__ __forceinline__ int t2_pll_role(T2Shared& S, const TrkConst& K, const TrkChan& cc, int unit, int mslot, bool owner,
+                                           int lane, int P, int ch, unsigned long long* __restrict__ xbase,
+                                           int* __restrict__ err, bool prof_on, long long* __restrict__ prof) {
     // tracking.py:123-130
     long long acc_map = 0, acc_xch = 0, acc_flt = 0, t_top = 0, t_arr = 0;   // SGX_TRK_PROFILE=1: per-member phase times
     double carrBasis = cc.acquiredFreq;
     double remCarr = 0.0, w_cur = (cc.acquiredFreq * 2.0) * M_PI, oldCarrNco = 0.0, oldCarrErr = 0.0;
     const double two_pi = 2 * M_PI;
     // constants of the call in registers (kernel arguments would be re-fetched through the scalar cache on the chain)
-    double k_a = K.k_carr_a, k_b = K.k_carr_b, inv_pi = K.inv_pi, inv_2pi = K.inv_2pi, c_hi = K.inv_2pifs_hi,
-           c_lo = K.inv_2pifs_lo, inv_fs = K.inv_fs, fs = K.fs;
-    T2_PIN(k_a); T2_PIN(k_b); T2_PIN(inv_pi); T2_PIN(inv_2pi); T2_PIN(c_hi); T2_PIN(c_lo); T2_PIN(inv_fs); T2_PIN(carrBasis);
+    double k_a = K.k_carr_a, k_b = K.k_carr_b, inv_2pi = K.inv_2pi, c_hi = K.inv_2pifs_hi, c_lo = K.inv_2pifs_lo,
+           inv_fs = K.inv_fs, fs = K.fs;
+    T2_PIN(k_a); T2_PIN(k_b); T2_PIN(inv_2pi); T2_PIN(c_hi); T2_PIN(c_lo); T2_PIN(inv_fs); T2_PIN(carrBasis);
     T2_PIN(fs);
+    // the largest rate step the rotation takes: the farthest table entry is sample P * UNIT of the block
+    double dw_max = T2_ROT_MAX / ((double)(P * TRK_UNIT) * K.inv_fs);
+    T2_PIN(dw_max);
     const int ms = K.ms;
-    // lane = 16 word + member polls that member's granule of I_P (word 0, row 0) / Q_P (word 1, row 1)
+    const bool w3 = lane >= 48;
+    // lane = 16 word + unit polls that unit's granule of I_P (word 0, row 0) / Q_P (word 1, row 1)
     const bool mine = (lane < 32) && ((lane & 15) < P);
     unsigned long long* const xabort = xbase + T2_XABORT;
     // record values of the block just finished (member 0), posted after the barrier: carrFreq I_P Q_P pllDiscr pllDiscrFilt
@@ -570,7 +738,7 @@ __device__ __forceinline__ int t2_pll_role(T2Shared& S, const TrkConst& K, const
         const T2Code& C = S.code[par];
         const int4 hd = *reinterpret_cast<const int4*>(&C.blk);
         const long long pos = C.pos;
-        if (member == 0 && it > 0) {
+        if (owner && it > 0) {
             if (lane == 0) {
                 double* R = S.rec[par ^ 1];      // T9 record (tracking.py:255-275) of block it - 1, stored by the record wave
                 R[2] = r_cf;
@@ -585,7 +753,8 @@ __device__ __forceinline__ int t2_pll_role(T2Shared& S, const TrkConst& K, const
         if (hd.y) break;
         T2_FP_TOP
         if (prof) t_top = (long long)__builtin_amdgcn_s_memtime();
-        // before the sums arrive: carrier phase at the end of this block (T5), exact remainder by FMA
+        // ---- before the sums arrive ----
+        // carrier phase at the end of this block (T5), exact remainder by FMA
         const int blk = hd.x;
         const int head_next = (int)((pos + blk) & 15);
         double rc;
@@ -596,7 +765,12 @@ __device__ __forceinline__ int t2_pll_role(T2Shared& S, const TrkConst& K, const
             if (rc < 0.0) rc += two_pi;
             if (rc >= two_pi) rc -= two_pi;
         }
-        T2_PIN(rc);   // (keeps the block-end phase computation ahead of the wait)
+        // the next block's table entry of this lane at the CURRENT rate, in full; the sums then only turn it
+        const int mi = t2_carr_mult(lane, unit, head_next);
+        double mf = (double)mi * inv_fs;             // m / fs: the rate step dw turns the entry by dw * mf radians
+        double cs_p, sn_p;
+        t2_carr_entry(c_hi, c_lo, inv_2pi, w_cur, rc, mi, w3, cs_p, sn_p);
+        T2_PIN(cs_p); T2_PIN(sn_p); T2_PIN(mf); T2_PIN(rc);   // (keeps all of this ahead of the wait)
         __builtin_amdgcn_s_setprio(3);
         const unsigned long long* gp = xbase + T2_XG + par * 96 + (lane & 31);
         const unsigned long long tag = (unsigned long long)((unsigned)(it + 1) & 0xFFFFu);
@@ -620,27 +794,40 @@ __device__ __forceinline__ int t2_pll_role(T2Shared& S, const TrkConst& K, const
             acc_map += tp - t_top;       // barrier release -> this member's publish
             acc_xch += t_arr - tp;       // this member's publish -> every member's sums visible
         }
-        // sum of the members' payloads (integers: exact, order-free), rows of 16 lanes
-        long long q = mine ? ((long long)(x << 16) >> 16) : 0ll;
-        q += dpp_movl<0xB1>(q);
-        q += dpp_movl<0x4E>(q);
-        q += dpp_movl<0x141>(q);
-        q += dpp_movl<0x140>(q);
-        const double v = (double)q * (1.0 / t2_fix<SB>());
+        // sum of the units' payloads (integers: exact, order-free), rows of 16 lanes
+        unsigned long long q = mine ? (unsigned long long)((long long)(x << 16) >> 16) : 0ull;
+        q = dpp_addl_xor1(q, q);
+        q = dpp_addl_xor2(q, q);
+        q = dpp_addl_hmir(q, q);
+        q = dpp_addl_mir(q, q);
+        const double v = (double)(long long)q * (1.0 / t2_fix<SB>());
         const double I_P = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 0),
                                             __builtin_amdgcn_readlane(__double2loint(v), 0));
         const double Q_P = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16),
                                             __builtin_amdgcn_readlane(__double2loint(v), 16));
-        // T7 PLL (tracking.py:223-235)
-        const double carrError = sgx_div_with_rcp(sgx_atan_ratio(Q_P, I_P) * 0.5, M_PI, inv_pi);   // atan(Q/I) / 2 / pi
+        // T7 PLL (tracking.py:223-235); atan(Q/I) / 2 / pi as one multiplication by RN(1 / (2 pi)) (1.5 ulp)
+        const double carrError = sgx_atan_ratio(Q_P, I_P) * inv_2pi;
         const double carrNco = oldCarrNco + k_a * (carrError - oldCarrErr) + carrError * k_b;
         const double carrFreq = carrBasis + carrNco;
         const double w_new = (carrFreq * 2.0) * M_PI;
         oldCarrNco = carrNco;
         oldCarrErr = carrError;
         T2PROBE(prof_on, 9);   // discriminator + NCO
-        // carrier tables of the next block
-        if (it + 1 < ms) t2_carr_tables(c_hi, c_lo, inv_2pi, w_new, rc, head_next, member, S.carr[par ^ 1], lane);
+        // carrier tables of the next block: the prepared entry turned by the rate step (exact: w_new - w_cur is)
+        if (it + 1 < ms) {
+            const double dw = w_new - w_cur;
+            double cs, sn;
+            if (__builtin_expect(fabs(dw) <= dw_max, 1)) {
+                double es, ec;
+                t2_rot_small(dw * mf, es, ec);
+                cs = __builtin_fma(cs_p, ec, -(sn_p * es));
+                sn = __builtin_fma(cs_p, es, sn_p * ec);
+            } else {
+                t2_carr_entry(c_hi, c_lo, inv_2pi, w_new, rc, mi, w3, cs, sn);
+            }
+            // B, W1, W2 are consecutive 16-entry tables, W3 follows: lanes 48..63 all store the same W3
+            S.carr[par ^ 1].T[lane < 48 ? lane : 48] = make_double2(cs, sn);
+        }
         w_cur = w_new;
         remCarr = rc;
         r_cf = carrFreq;
@@ -650,7 +837,7 @@ __device__ __forceinline__ int t2_pll_role(T2Shared& S, const TrkConst& K, const
         r_nco = carrNco;
         if (gave_up && lane == 0) {
             S.flag[1] = 1;
-            atomicExch(err, 1 + ch);
+            atomicCAS(err, 0, 1 + ch);
             __hip_atomic_store(xabort, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         T2STAMP(prof_on, 10);  // carrier tables
@@ -659,7 +846,7 @@ __device__ __forceinline__ int t2_pll_role(T2Shared& S, const TrkConst& K, const
         if (prof) acc_flt += (long long)__builtin_amdgcn_s_memtime() - t_arr;   // sums visible -> barrier released (both filter waves done)
         T2STAMP(prof_on, 11);
     }
-    if (member == 0 && it > 0 && it == ms) {
+    if (owner && it > 0 && it == ms) {
         // (when the loop ran out of blocks, the last block's record values are still in registers)
         if (lane == 0) {
             double* R = S.rec[(it - 1) & 1];
@@ -673,26 +860,61 @@ __device__ __forceinline__ int t2_pll_role(T2Shared& S, const TrkConst& K, const
         if (lane == 0) *(volatile int*)&S.rflag[0] = it;
     }
     if (prof && lane == 0) {
-        prof[ch * 64 + member] = acc_map;
-        prof[ch * 64 + 16 + member] = acc_xch;
-        prof[ch * 64 + 32 + member] = acc_flt;
+        prof[ch * T2_PROF_STRIDE + mslot] = acc_map;
+        prof[ch * T2_PROF_STRIDE + 64 + mslot] = acc_xch;
+        prof[ch * T2_PROF_STRIDE + 128 + mslot] = acc_flt;
     }
     T2_FP_PRINT(prof_on && lane == 0, 8, 12)
     return it;
 }
 
 // ================================ DLL (wave 5) ================================
-template <int SB>
-__device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const T2DllConst& D, T2DllState st, int member,
-                                           int lane, int P, int ch, unsigned long long* __restrict__ xbase,
-                                           int* __restrict__ err, bool prof_on, long long file_off) {
-    // tracking.py:114-121; `st` describes block 0 (its chain and early parts are posted)
+// Lanes work in parallel on the three ramps: lane & 3 = 0 early, 1 prompt, 2 late (3 repeats prompt); uniform results
+// come from lane 1 / lane 0.
+struct T2DllConst {
+    double fs, inv_fs, code_len, spacing;
+    double inv_nb_lane;     // RN(1 / (nb_base + (lane & 7))): reciprocals of the plausible block lengths, one per lane
+    int nb_base;
+    long long rec_len;
+};
+
+// Chain part of a block's parameters from the new code frequency (T1): the block length - ceil((1023 - rem) / step)
+// with step = RN(codeFreq / fs) in the reference - without a division on the chain.  step_a = codeFreq * RN(1/fs) is
+// within 3 ulp of that step, the corrected reciprocal quotient within 1 ulp of a / step_a, so the quotient is within
+// 6 ulp of the reference's and ceil() of it is the reference's block length unless it lies that close to an integer;
+// then (probability ~1e-10 per block, and block 0, whose quotient IS an integer) the exact arithmetic decides.
+__device__ __forceinline__ int t2_block_length(const T2DllConst& D, double codeFreq, double a, double& step_a, double& inv_step) {
+    step_a = codeFreq * D.inv_fs;
+    double y = SGX_RCP_SEED(step_a);
+    y = __builtin_fma(y, __builtin_fma(-step_a, y, 1.0), y);
+    const double q0 = a * y;
+    const double q = __builtin_fma(__builtin_fma(-q0, step_a, a), y, q0);
+    inv_step = y;
+    const double c = ceil(q);
+    const double lo = q - c + 1.0;                         // distance above the integer below (exact near it)
+    const double tol = q * 1.4e-15;
+    if (__builtin_expect(c - q < tol || lo < tol, 0)) return (int)ceil(a / div_rn(codeFreq, D.fs, D.inv_fs));
+    return (int)c;
+}
+
+template <int SB, int ARMS>
+__device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const T2DllConst& D, long long pos0, int blk0,
+                                           int stop0, int arm, bool owner, int lane, int P, int ch,
+                                           unsigned long long* __restrict__ xbase, int* __restrict__ err, bool prof_on,
+                                           long long file_off) {
+    // tracking.py:114-121; block 0's chain part and ramp starts were posted before the loop
     double oldCodeNco = 0.0, oldCodeErr = 0.0;
     double k_a = K.k_code_a, k_b = K.k_code_b, basis = K.code_basis;
     T2_PIN(k_a); T2_PIN(k_b); T2_PIN(basis);
     const int ms = K.ms;
-    // lane = 16 row + member polls that member's granule of word 2 + row: rows I_E, Q_E, I_L, Q_L
+    // the block being processed: code phase at its start, first sample, code frequency, length
+    double rem = 0.0, cf = K.code_basis;
+    long long pos = pos0;
+    int blk = blk0, stop = stop0;
     const int l4 = lane & 3;
+    const double off = (l4 == 0) ? -D.spacing : ((l4 == 2) ? D.spacing : 0.0);   // rem - spc == rem + (-spc) exactly
+    const int lim3 = P * TRK_UNIT - 15;                    // the longest block the units of the launch hold
+    // lane = 16 row + unit polls that unit's granule of word 2 + row: rows I_E, Q_E, I_L, Q_L
     const bool mine = (lane & 15) < P;
     unsigned long long* const xabort = xbase + T2_XABORT;
     // record values of the block just finished (member 0), posted after the barrier
@@ -704,13 +926,13 @@ __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const
     for (; it < ms; ++it) {
         const int par = it & 1;
         T2Code& C = S.code[par];
-        const int stop = C.stop;
-        if (member == 0 && it > 0) {
+        T2Code& N = S.code[par ^ 1];
+        if (owner && it > 0) {
             double* R = S.rec[par ^ 1];
             // I_E -> 4, Q_E -> 6, I_L -> 5, Q_L -> 8 (series order of _native.SERIES)
             if (lane < 4) R[lane == 0 ? 4 : (lane == 1 ? 6 : (lane == 2 ? 5 : 8))] = r_v;
             if (lane == 0) {
-                R[0] = (double)(st.pos * SB + file_off);   // position after block it - 1 = first sample of block it
+                R[0] = (double)(pos * SB + file_off);   // position after block it - 1 = first sample of block it
                 R[1] = r_cf;
                 R[9] = r_err;
                 R[10] = r_nco;
@@ -720,10 +942,38 @@ __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const
         }
         if (stop) break;
         T2_FP_TOP
-        // late part of this block and early part of the next (nothing here needs the sums)
-        double rem_next;
-        long long pos_next;
-        t2_code_late(D, st, S.code[par ^ 1], lane, rem_next, pos_next);
+        // ---- before the sums arrive: the exact arithmetic of this block (T1, T3), which only the exact search reads
+        const double step = div_rn(cf, D.fs, D.inv_fs);                             // codeFreq / fs
+        const double nb = (double)blk;
+        const double span = nb * step;                                              // blksize * codePhaseStep
+        const int ki = blk - D.nb_base;
+        const bool known = (ki >= 0 && ki < 8);
+        const int kq = __builtin_amdgcn_readfirstlane(ki) & 7;
+        const double ynb = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(D.inv_nb_lane), kq),
+                                            __builtin_amdgcn_readlane(__double2loint(D.inv_nb_lane), kq));
+        // np.linspace(start, stop, blk, endpoint=False): delta = stop - start; step = delta / blk
+        const double start = rem + off;
+        const double d = ((span + rem) + off) - start;
+        double stp;
+        if (__builtin_expect(known, 1)) stp = div_rn(d, nb, ynb);
+        else stp = d / nb;
+        if (lane < 3) C.stp[lane] = stp;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        if (lane == 0) C.xflag = it + 1;
+        // code phase and first sample of the next block (T4) and that block's ramp starts
+        const double t_last = ramp_at(blk - 1, stp, start);
+        const double rn_lane = (t_last + step) - 1023.0;                            // meaningful in the prompt lane
+        const double rem_next = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rn_lane), 1),
+                                                 __builtin_amdgcn_readlane(__double2loint(rn_lane), 1));
+        const long long pos_next = pos + blk;
+        if (lane < 3) N.start[lane] = rem_next + off;
+        if (ARMS == 1 && lane == arm) N.start_arm = rem_next + off;
+        if (lane == 0) N.pos = pos_next;
+        double a_next = D.code_len - rem_next;                                      // (1023 - rem) of T1
+        // the longest next block the record still holds (stop 1 beyond it)
+        const long long room = D.rec_len - pos_next;
+        int lim1 = room > (long long)0x3FFFFFFF ? 0x3FFFFFFF : (int)room;
+        T2_PIN(a_next); T2_PIN(lim1);
         __builtin_amdgcn_s_setprio(3);
         const unsigned long long* gp = xbase + T2_XG + par * 96 + 32 + lane;
         const unsigned long long tag = (unsigned long long)((unsigned)(it + 1) & 0xFFFFu);
@@ -742,14 +992,14 @@ __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const
             }
         }
         T2STAMP(prof_on, 12);  // waiting for the sums
-        // T8 DLL (tracking.py:238-251).  Row r of the wave holds the members' payloads of I_E | Q_E | I_L | Q_L: integer
+        // T8 DLL (tracking.py:238-251).  Row r of the wave holds the units' payloads of I_E | Q_E | I_L | Q_L: integer
         // row sums (exact, order-free), then lanes 0..3 of every quad take the four totals: v = I_E | Q_E | I_L | Q_L
-        long long q = mine ? ((long long)(x << 16) >> 16) : 0ll;
-        q += dpp_movl<0xB1>(q);
-        q += dpp_movl<0x4E>(q);
-        q += dpp_movl<0x141>(q);
-        q += dpp_movl<0x140>(q);
-        const double vr = (double)q * (1.0 / t2_fix<SB>());
+        unsigned long long q = mine ? (unsigned long long)((long long)(x << 16) >> 16) : 0ull;
+        q = dpp_addl_xor1(q, q);
+        q = dpp_addl_xor2(q, q);
+        q = dpp_addl_hmir(q, q);
+        q = dpp_addl_mir(q, q);
+        const double vr = (double)(long long)q * (1.0 / t2_fix<SB>());
         const int vh = __double2hiint(vr), vl = __double2loint(vr);
         const int h0 = __builtin_amdgcn_readlane(vh, 0), l0 = __builtin_amdgcn_readlane(vl, 0);
         const int h1 = __builtin_amdgcn_readlane(vh, 16), l1 = __builtin_amdgcn_readlane(vl, 16);
@@ -769,10 +1019,20 @@ __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const
         oldCodeNco = codeNco;
         oldCodeErr = codeError;
         T2PROBE(prof_on, 13);  // discriminator + NCO
-        // T1, T3: block size and ramp steps of the next block
-        const T2DllState nx = t2_code_chain(D, cf_new, rem_next, pos_next, gave_up, P, S.code[par ^ 1], lane);
-        if (lane == 0 && nx.blk + 15 > P * TRK_UNIT && !gave_up) atomicExch(err, TRK_ERR_RANGE | (1 + ch));
-        st = nx;
+        // chain part of the next block: its length, the ramps' slope and the slope's reciprocal
+        double step_a, inv_step;
+        const int blk_n = t2_block_length(D, cf_new, a_next, step_a, inv_step);
+        const int stop_n = gave_up ? 2 : ((blk_n <= 0 || blk_n > lim1) ? 1 : ((blk_n > lim3) ? 3 : 0));
+        if (lane == 0) {
+            *reinterpret_cast<int4*>(&N.blk) = make_int4(blk_n, stop_n, __double2loint(inv_step), __double2hiint(inv_step));
+            N.step = step_a;
+            if (blk_n > lim3 && !gave_up) atomicExch(err, TRK_ERR_RANGE | (1 + ch));
+        }
+        rem = rem_next;
+        pos = pos_next;
+        cf = cf_new;
+        blk = blk_n;
+        stop = stop_n;
         r_v = v;
         r_cf = cf_new;
         r_err = codeError;
@@ -780,7 +1040,7 @@ __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const
         if (gave_up && lane == 0) {
             S.flag[1] = 1;
             if (xa == 0) {
-                atomicExch(err, 1 + ch);
+                atomicCAS(err, 0, 1 + ch);
                 __hip_atomic_store(xabort, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
@@ -789,11 +1049,11 @@ __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const
         __builtin_amdgcn_s_setprio(0);
         T2STAMP(prof_on, 15);
     }
-    if (member == 0 && it > 0 && it == ms) {
+    if (owner && it > 0 && it == ms) {
         double* R = S.rec[(it - 1) & 1];
         if (lane < 4) R[lane == 0 ? 4 : (lane == 1 ? 6 : (lane == 2 ? 5 : 8))] = r_v;
         if (lane == 0) {
-            R[0] = (double)(st.pos * SB + file_off);
+            R[0] = (double)(pos * SB + file_off);
             R[1] = r_cf;
             R[9] = r_err;
             R[10] = r_nco;
@@ -813,19 +1073,20 @@ __device__ __forceinline__ void t2_rec_store(T2Shared& S, int k, long long m, in
     if (lane < SGX_NUM_SERIES) o[lane * m + k] = S.rec[k & 1][lane];
 }
 
-__device__ __forceinline__ int t2_rec_role(T2Shared& S, int ms, int member, int lane, double* __restrict__ o) {
+__device__ __forceinline__ int t2_rec_role(T2Shared& S, int ms, bool owner, int lane, double* __restrict__ o) {
     const long long m = ms;
     int it = 0;
     for (; it < ms; ++it) {
         const int par = it & 1;
         if (S.code[par].stop) break;
-        if (member == 0 && it > 0) t2_rec_store(S, it - 1, m, lane, o);
+        if (owner && it > 0) t2_rec_store(S, it - 1, m, lane, o);
         wg_barrier();
     }
     return it;
 }
 
-template <int SB>
+// ARMS = 1: a channel has 3 P members, member m = arm * P + unit; ARMS = 3: P members, member = unit.
+template <int SB, int ARMS>
 __global__ __launch_bounds__(T2_THREADS) void trk2_kernel(const int8_t* __restrict__ rec, const int8_t* __restrict__ codes,
                                                           const TrkChan* __restrict__ chans, double* __restrict__ out,
                                                           int* __restrict__ ms_done, TrkConst K,
@@ -833,26 +1094,35 @@ __global__ __launch_bounds__(T2_THREADS) void trk2_kernel(const int8_t* __restri
                                                           unsigned long long* __restrict__ xch, int* __restrict__ err) {
     __shared__ T2Shared S;
     const int P = K.split;
+    const int PM = (ARMS == 1) ? 3 * P : P;
     const int bq = blockIdx.x >> 3, br = blockIdx.x & 7;
-    const int ch = br + 8 * (bq / P);
-    const int member = bq % P;
+    const int ch = br + 8 * (bq / PM);
+    const int member = bq % PM;
+    const int unit = member % P;
+    const int arm = (ARMS == 1) ? member / P : 1;
+    const bool owner = member == 0;            // the member that records the channel's series
     if (ch >= K.n_ch) return;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const TrkChan cc = chans[ch];
     if (cc.prn == 0) {
-        if (tid == 0 && member == 0) ms_done[ch] = 0;
+        if (tid == 0 && owner) ms_done[ch] = 0;
         return;
     }
     unsigned long long* __restrict__ xbase = xch + (long long)ch * T2_XCH_STRIDE;   // granules, abort word, placement granules
     unsigned long long* const xabort = xbase + T2_XABORT;
-    const bool prof_on = (member == 0 && ch == 0 && prof != nullptr && (wave == 0 || wave == 4 || wave == 5));
+    const bool prof_on = (owner && ch == 0 && prof != nullptr && (wave == 0 || wave == 4 || wave == 5));
 
     // ---- placement: are all members of the channel on one XCD (one L2)?  Then the exchange may stay in that L2.
     if (tid < 4) {
         S.flag[tid] = 0;
         S.rflag[tid] = 0;
         S.ticket[tid >> 1][tid & 1] = 0;
+        S.acc[tid >> 1][tid & 1] = 0ull;
+    }
+    if (tid < 2) {
+        S.code[tid].xflag = 0;
+        S.code[tid].start_arm = 0.0;
     }
     __syncthreads();
     if (wave == 4) {
@@ -863,8 +1133,8 @@ __global__ __launch_bounds__(T2_THREADS) void trk2_kernel(const int8_t* __restri
         int budget = T2_POLL_BUDGET;
         bool gave_up = false;
         for (;;) {
-            if (lane < P) x = __hip_atomic_load(pl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const bool ok = lane >= P || (x >> 48) == 0xC0DE;
+            if (lane < PM) x = __hip_atomic_load(pl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool ok = lane >= PM || (x >> 48) == 0xC0DE;
             if (__all(ok)) break;
             if (--budget == 0) {
                 gave_up = true;
@@ -872,12 +1142,12 @@ __global__ __launch_bounds__(T2_THREADS) void trk2_kernel(const int8_t* __restri
             }
             __builtin_amdgcn_s_sleep(1);
         }
-        const bool same = __all(lane >= P || (unsigned)(x & 0xF) == me);
+        const bool same = __all(lane >= PM || (unsigned)(x & 0xF) == me);
         if (lane == 0) {
             S.flag[0] = (same && !gave_up && K.fast_xcd != 0) ? 1 : 0;
             if (gave_up) {   // a member is not resident: give the channel up at once (the host repeats with split 1)
                 S.flag[1] = 1;
-                atomicExch(err, 1 + ch);
+                atomicCAS(err, 0, 1 + ch);
                 __hip_atomic_store(xabort, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
@@ -900,14 +1170,9 @@ __global__ __launch_bounds__(T2_THREADS) void trk2_kernel(const int8_t* __restri
     const bool fast = S.flag[0] != 0;
     const bool dead = S.flag[1] != 0;
 
-    // block 0 parameters (tracking.py:114-130): chain part and early part
+    // block 0 parameters (tracking.py:114-130): chain part and ramp starts
     T2DllConst D;
-    T2DllState st0;
-    st0.rem = 0.0;
-    st0.pos = cc.pos0;
-    st0.step = 0.0;
-    st0.stp = 0.0;
-    st0.blk = 0;
+    int blk0 = 0, stop0 = 0;
     if (wave == 5) {
         D.fs = K.fs;
         D.inv_fs = K.inv_fs;
@@ -916,38 +1181,69 @@ __global__ __launch_bounds__(T2_THREADS) void trk2_kernel(const int8_t* __restri
         D.inv_nb_lane = 1.0 / (double)(K.nb_base + (lane & 7));
         D.nb_base = K.nb_base;
         D.rec_len = (K.rec_len - cc.pad) / SB;      // samples on the channel's grid (cc.pad: its byte shift, SB = 2 only)
-        st0 = t2_code_chain(D, K.code_basis, 0.0, cc.pos0, false, P, S.code[0], lane);
+        double step_a, inv_step;
+        blk0 = t2_block_length(D, K.code_basis, K.code_len - 0.0, step_a, inv_step);
+        const int lim3 = P * TRK_UNIT - 15;
+        stop0 = dead ? 2 : ((blk0 <= 0 || cc.pos0 + blk0 > D.rec_len) ? 1 : ((blk0 > lim3) ? 3 : 0));
         const double off = ((lane & 3) == 0) ? -K.spacing : (((lane & 3) == 2) ? K.spacing : 0.0);
         if (lane < 3) S.code[0].start[lane] = 0.0 + off;
+        if (ARMS == 1 && lane == arm) S.code[0].start_arm = 0.0 + off;
         if (lane == 0) {
+            *reinterpret_cast<int4*>(&S.code[0].blk) = make_int4(blk0, stop0, __double2loint(inv_step), __double2hiint(inv_step));
+            S.code[0].step = step_a;
             S.code[0].pos = cc.pos0;
-            if (st0.blk + 15 > P * TRK_UNIT) atomicExch(err, TRK_ERR_RANGE | (1 + ch));
+            if (blk0 > lim3) atomicExch(err, TRK_ERR_RANGE | (1 + ch));
         }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        if (lane == 0 && dead) S.code[0].stop = 2;
     }
-    if (wave == 4)
-        t2_carr_tables(K.inv_2pifs_hi, K.inv_2pifs_lo, K.inv_2pi, (cc.acquiredFreq * 2.0) * M_PI, 0.0, (int)(cc.pos0 & 15),
-                       member, S.carr[0], lane);
+    if (wave == 4) {
+        double cs, sn;
+        t2_carr_entry(K.inv_2pifs_hi, K.inv_2pifs_lo, K.inv_2pi, (cc.acquiredFreq * 2.0) * M_PI, 0.0,
+                      t2_carr_mult(lane, unit, (int)(cc.pos0 & 15)), lane >= 48, cs, sn);
+        S.carr[0].T[lane < 48 ? lane : 48] = make_double2(cs, sn);
+    }
     __syncthreads();
 
     double* __restrict__ o = out + (long long)ch * SGX_NUM_SERIES * K.ms;
     int done;
-    if (wave < 4) done = t2_map_role<SB>(S, rec + cc.pad, K.rec_alloc, K.ms, cc.pos0, member, tid, xbase, fast, prof_on, prof != nullptr);
-    else if (wave == 4) done = t2_pll_role<SB>(S, K, cc, member, lane, P, ch, xbase, err, prof_on, prof);
-    else if (wave == 5) done = t2_dll_role<SB>(S, K, D, st0, member, lane, P, ch, xbase, err, prof_on, K.file_off + cc.pad);
-    else done = t2_rec_role(S, K.ms, member, lane, o);
+    if (wave < 4) {
+        if constexpr (ARMS == 1)
+            done = t2_map1_role<SB>(S, rec + cc.pad, K.rec_alloc, K.ms, cc.pos0, unit, arm, tid, xbase, fast,
+                                    K.code_basis / K.fs, K.spacing, prof_on, prof != nullptr);
+        else
+            done = t2_map3_role<SB>(S, rec + cc.pad, K.rec_alloc, K.ms, cc.pos0, unit, tid, xbase, fast, prof_on, prof != nullptr);
+    } else if (wave == 4)
+        done = t2_pll_role<SB>(S, K, cc, unit, member, owner, lane, P, ch, xbase, err, prof_on, prof);
+    else if (wave == 5)
+        done = t2_dll_role<SB, ARMS>(S, K, D, cc.pos0, blk0, stop0, arm, owner, lane, P, ch, xbase, err, prof_on, K.file_off + cc.pad);
+    else
+        done = t2_rec_role(S, K.ms, owner, lane, o);
 
     // a channel that was given up reports the blocks completed before the abort
     const bool aborted = S.code[done & 1].stop == 2;
-    if (wave == 6 && member == 0 && done > 0 && !aborted) t2_rec_store(S, done - 1, (long long)K.ms, lane, o);
+    if (wave == 6 && owner && done > 0 && !aborted) t2_rec_store(S, done - 1, (long long)K.ms, lane, o);
     if (aborted && done > 0) done -= 1;
-    if (tid == 0 && member == 0) ms_done[ch] = done;
+    if (tid == 0 && owner) ms_done[ch] = done;
 }
 
+// arms = 1: 3 * split members per channel (n_blocks = 8-padded channels x 3 x split); arms = 3: split members.
+// lds_pad: extra dynamic LDS per workgroup, so that a CU holds ONE workgroup of the launch (members must not share
+// a CU: they would share its issue ports).
 void sgx_trk2_launch(int n_blocks, hipStream_t st, const int8_t* rec, const int8_t* codes, const TrkChan* chans,
                      double* out, int* done, const TrkConst& K, long long* prof, unsigned long long* xch, int* err,
-                     int sample_bytes) {
-    if (sample_bytes == 2) trk2_kernel<2><<<n_blocks, T2_THREADS, 0, st>>>(rec, codes, chans, out, done, K, prof, xch, err);
-    else trk2_kernel<1><<<n_blocks, T2_THREADS, 0, st>>>(rec, codes, chans, out, done, K, prof, xch, err);
+                     int sample_bytes, int arms, int lds_pad) {
+#define T2_LAUNCH(SBV, ARMSV)                                                                                          \
+    do {                                                                                                               \
+        if (lds_pad > 0)                                                                                               \
+            (void)hipFuncSetAttribute((const void*)trk2_kernel<SBV, ARMSV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      lds_pad);                                                                        \
+        trk2_kernel<SBV, ARMSV><<<n_blocks, T2_THREADS, (size_t)(lds_pad > 0 ? lds_pad : 0), st>>>(rec, codes, chans, out, done, K, prof, xch, err); \
+    } while (0)
+    if (sample_bytes == 2) {
+        if (arms == 1) T2_LAUNCH(2, 1);
+        else T2_LAUNCH(2, 3);
+    } else {
+        if (arms == 1) T2_LAUNCH(1, 1);
+        else T2_LAUNCH(1, 3);
+    }
+#undef T2_LAUNCH
 }

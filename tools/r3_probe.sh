@@ -1,0 +1,16 @@
+#!/bin/bash
+# (round 3 diagnosis) quick correctness + timing of the tracking kernel variants on the GPU box
+cd "$(dirname "$0")/.."
+out=gpurun_out/r3_probe
+mkdir -p $out
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "track_golden or track_device_file or replicated or full_length or split_variants or kernels_agree" > $out/pytest1.log 2>&1
+echo "pytest rc $?" >> $out/pytest1.log
+tail -5 $out/pytest1.log
+for v in "" "SGX_TRK_ARMS=3" "SGX_TRK_LDSPAD=0" "SGX_TRK_ARMS=3 SGX_TRK_LDSPAD=0"; do
+  echo "== variant [$v]"
+  env $v SGX_TRK_PROFILE=1 timeout 300 python tools/step_profile.py 4000 2>&1 | grep -v "^ \|^$\|function calls\|Ordered by\|ncalls" | head -40
+  env $v timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --many-channels 0 --concurrent 0 --no-config4 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('track_kernel_ms %.3f  us/period %.4f  acquire_ms %.3f  x_realtime %.1f' % (d['track_kernel_ms'], d['us_per_code_period'], d['acquire_ms'], d['x_realtime']))"
+done 2>&1 | tee $out/variants.log
