@@ -521,8 +521,17 @@ extern "C" int sgx_if_download(sgx_ctx* c, const sgx_if* r, size_t offset, size_
 }
 
 extern "C" int sgx_trk_math_eval(int32_t fn, double a, double b, double* out) {
-    SGX_CHECK_ARG(out && fn >= 0 && fn <= 5);
+    SGX_CHECK_ARG(out && fn >= 0 && fn <= 10);
     switch (fn) {
+        case 6: out[0] = sgx_div1(a, b); break;
+        case 7: out[0] = sgx_sqrt1(a); break;
+        case 8: out[0] = sgx_atan_ratio_k(a, b, sgx_atan_coef()); break;
+        case 9: sgx_rot_small(a, sgx_rot_coef(), out[0], out[1]); break;
+        case 10: {   // a = 1023 - rem, b = codeFreq, at fs = 38.192 MHz: block length, and step_a in out[1]
+            double inv_step;
+            out[0] = (double)sgx_block_length(a, b, 38192000.0, 1.0 / 38192000.0, out[1], inv_step);
+            break;
+        }
         case 0: out[0] = sgx_fast_rcp(a); break;
         case 1: out[0] = sgx_fast_div(a, b); break;
         case 2: out[0] = sgx_fast_sqrt(a); break;

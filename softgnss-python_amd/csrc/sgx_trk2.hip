@@ -66,7 +66,6 @@ template <int SB>
 __device__ __forceinline__ constexpr double t2_fix() { return SB == 1 ? T2_FIX : T2_FIX16; }
 #define T2_MAGIC 6755399441055744.0   // 1.5 * 2^52: fl(x + MAGIC) holds round(x) in its low mantissa bits
 #define T2_POLL_BUDGET (1 << 20)
-#define T2_ROT_MAX 0.34            // largest rotation angle (rad) the Taylor pair of t2_rot_small is good for
 
 // -DTRK_FINEPROF=1: time stamps at the natural synchronisation points only (poll exits, barriers) - undisturbed timing.
 // -DTRK_FINEPROF=2: every probe, each preceded by a full wait - attributes the time inside a role, inflates the total.
@@ -134,6 +133,15 @@ __device__ __forceinline__ double dpp_mov(double v) {
     const int lo = __double2loint(v), hi = __double2hiint(v);
     const int olo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
     const int ohi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(ohi, olo);
+}
+
+// row_bcast:15 (lane 15 of every row to the next row) / row_bcast:31 (lane 31 to rows 2 and 3); other rows get 0
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double dpp_bcast(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int olo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWS, 0xF, false);
+    const int ohi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWS, 0xF, false);
     return __hiloint2double(ohi, olo);
 }
 
@@ -213,26 +221,6 @@ __device__ __forceinline__ void t2_carr_entry(double inv_2pifs_hi, double inv_2p
     const double u3 = u + rc * inv_2pi;        // < 2
     u = w3 ? (u3 - ((u3 >= 1.0) ? 1.0 : 0.0)) : u;
     sgx_sincos_turns_short(u, sn, cs);
-}
-
-// sin and cos of a small angle, |ph| <= T2_ROT_MAX: Taylor to ph^13 / ph^12 (next terms 6e-20 / 3e-18), Estrin
-__device__ __forceinline__ void t2_rot_small(double ph, double& sn, double& cs) {
-    const double t = ph * ph;
-    const double t2 = t * t;
-    const double t4 = t2 * t2;
-    const double pt = ph * t;
-    const double s01 = __builtin_fma(8.3333333333333332e-03, t, -1.6666666666666666e-01);
-    const double s23 = __builtin_fma(2.7557319223985893e-06, t, -1.9841269841269841e-04);
-    const double s45 = __builtin_fma(1.6059043836821613e-10, t, -2.5052108385441720e-08);
-    const double c01 = __builtin_fma(4.1666666666666664e-02, t, -0.5);
-    const double c23 = __builtin_fma(2.4801587301587302e-05, t, -1.3888888888888889e-03);
-    const double c45 = __builtin_fma(2.0876756987868100e-09, t, -2.7557319223985888e-07);
-    const double sa = __builtin_fma(s23, t2, s01);
-    const double ca = __builtin_fma(c23, t2, c01);
-    const double ps = __builtin_fma(s45, t4, sa);
-    const double pc = __builtin_fma(c45, t4, ca);
-    sn = __builtin_fma(pt, ps, ph);
-    cs = __builtin_fma(t, pc, 1.0);
 }
 
 #define T2_PIN(x) asm volatile("" : "+v"(x))
@@ -720,9 +708,20 @@ __device__ __forceinline__ int t2_pll_role(T2Shared& S, const TrkConst& K, const
     T2_PIN(k_a); T2_PIN(k_b); T2_PIN(inv_2pi); T2_PIN(c_hi); T2_PIN(c_lo); T2_PIN(inv_fs); T2_PIN(carrBasis);
     T2_PIN(fs);
     // the largest rate step the rotation takes: the farthest table entry is sample P * UNIT of the block
-    double dw_max = T2_ROT_MAX / ((double)(P * TRK_UNIT) * K.inv_fs);
+    double dw_max = SGX_ROT_MAX / ((double)(P * TRK_UNIT) * K.inv_fs);
     T2_PIN(dw_max);
     const int ms = K.ms;
+    // polynomial coefficients in registers (a constant the compiler materialises in front of every use is an
+    // instruction on the chain)
+    SgxAtanCoef ak = sgx_atan_coef();
+    SgxRotCoef rk = sgx_rot_coef();
+    T2_PIN(ak.c0); T2_PIN(ak.c1); T2_PIN(ak.c2); T2_PIN(ak.c3); T2_PIN(ak.c4); T2_PIN(ak.c5); T2_PIN(ak.c6); T2_PIN(ak.c7); T2_PIN(ak.c8);
+    T2_PIN(rk.s0); T2_PIN(rk.s1); T2_PIN(rk.s2); T2_PIN(rk.s3); T2_PIN(rk.s4); T2_PIN(rk.s5);
+    T2_PIN(rk.c0); T2_PIN(rk.c1); T2_PIN(rk.c2); T2_PIN(rk.c3); T2_PIN(rk.c4); T2_PIN(rk.c5);
+    // lane 0 of a row adds the bits of 1.5 2^52 to its payload: the row's integer sum then IS the double 1.5 2^52 + sum
+    const int bias_hi = ((lane & 15) == 0) ? 0x43380000 : 0;
+    double unfix = 1.0 / t2_fix<SB>();
+    T2_PIN(unfix);
     const bool w3 = lane >= 48;
     // lane = 16 word + unit polls that unit's granule of I_P (word 0, row 0) / Q_P (word 1, row 1)
     const bool mine = (lane < 32) && ((lane & 15) < P);
@@ -794,19 +793,19 @@ __device__ __forceinline__ int t2_pll_role(T2Shared& S, const TrkConst& K, const
             acc_map += tp - t_top;       // barrier release -> this member's publish
             acc_xch += t_arr - tp;       // this member's publish -> every member's sums visible
         }
-        // sum of the units' payloads (integers: exact, order-free), rows of 16 lanes
-        unsigned long long q = mine ? (unsigned long long)((long long)(x << 16) >> 16) : 0ull;
+        // sum of the units' payloads (integers: exact, order-free), rows of 16 lanes; lanes that poll nothing hold 0
+        unsigned long long q = ((unsigned long long)(unsigned)((int)(short)(unsigned short)(x >> 32) + bias_hi) << 32) | (unsigned)x;
         q = dpp_addl_xor1(q, q);
         q = dpp_addl_xor2(q, q);
         q = dpp_addl_hmir(q, q);
         q = dpp_addl_mir(q, q);
-        const double v = (double)(long long)q * (1.0 / t2_fix<SB>());
+        const double v = (__longlong_as_double((long long)q) - T2_MAGIC) * unfix;
         const double I_P = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 0),
                                             __builtin_amdgcn_readlane(__double2loint(v), 0));
         const double Q_P = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16),
                                             __builtin_amdgcn_readlane(__double2loint(v), 16));
         // T7 PLL (tracking.py:223-235); atan(Q/I) / 2 / pi as one multiplication by RN(1 / (2 pi)) (1.5 ulp)
-        const double carrError = sgx_atan_ratio(Q_P, I_P) * inv_2pi;
+        const double carrError = sgx_atan_ratio_k(Q_P, I_P, ak) * inv_2pi;
         const double carrNco = oldCarrNco + k_a * (carrError - oldCarrErr) + carrError * k_b;
         const double carrFreq = carrBasis + carrNco;
         const double w_new = (carrFreq * 2.0) * M_PI;
@@ -819,7 +818,7 @@ __device__ __forceinline__ int t2_pll_role(T2Shared& S, const TrkConst& K, const
             double cs, sn;
             if (__builtin_expect(fabs(dw) <= dw_max, 1)) {
                 double es, ec;
-                t2_rot_small(dw * mf, es, ec);
+                sgx_rot_small(dw * mf, rk, es, ec);
                 cs = __builtin_fma(cs_p, ec, -(sn_p * es));
                 sn = __builtin_fma(cs_p, es, sn_p * ec);
             } else {
@@ -878,25 +877,6 @@ struct T2DllConst {
     long long rec_len;
 };
 
-// Chain part of a block's parameters from the new code frequency (T1): the block length - ceil((1023 - rem) / step)
-// with step = RN(codeFreq / fs) in the reference - without a division on the chain.  step_a = codeFreq * RN(1/fs) is
-// within 3 ulp of that step, the corrected reciprocal quotient within 1 ulp of a / step_a, so the quotient is within
-// 6 ulp of the reference's and ceil() of it is the reference's block length unless it lies that close to an integer;
-// then (probability ~1e-10 per block, and block 0, whose quotient IS an integer) the exact arithmetic decides.
-__device__ __forceinline__ int t2_block_length(const T2DllConst& D, double codeFreq, double a, double& step_a, double& inv_step) {
-    step_a = codeFreq * D.inv_fs;
-    double y = SGX_RCP_SEED(step_a);
-    y = __builtin_fma(y, __builtin_fma(-step_a, y, 1.0), y);
-    const double q0 = a * y;
-    const double q = __builtin_fma(__builtin_fma(-q0, step_a, a), y, q0);
-    inv_step = y;
-    const double c = ceil(q);
-    const double lo = q - c + 1.0;                         // distance above the integer below (exact near it)
-    const double tol = q * 1.4e-15;
-    if (__builtin_expect(c - q < tol || lo < tol, 0)) return (int)ceil(a / div_rn(codeFreq, D.fs, D.inv_fs));
-    return (int)c;
-}
-
 template <int SB, int ARMS>
 __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const T2DllConst& D, long long pos0, int blk0,
                                            int stop0, int arm, bool owner, int lane, int P, int ch,
@@ -914,6 +894,9 @@ __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const
     const int l4 = lane & 3;
     const double off = (l4 == 0) ? -D.spacing : ((l4 == 2) ? D.spacing : 0.0);   // rem - spc == rem + (-spc) exactly
     const int lim3 = P * TRK_UNIT - 15;                    // the longest block the units of the launch hold
+    const int bias_hi = ((lane & 15) == 0) ? 0x43380000 : 0;   // (see the PLL wave)
+    double unfix = 1.0 / t2_fix<SB>();
+    T2_PIN(unfix);
     // lane = 16 row + unit polls that unit's granule of word 2 + row: rows I_E, Q_E, I_L, Q_L
     const bool mine = (lane & 15) < P;
     unsigned long long* const xabort = xbase + T2_XABORT;
@@ -929,8 +912,8 @@ __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const
         T2Code& N = S.code[par ^ 1];
         if (owner && it > 0) {
             double* R = S.rec[par ^ 1];
-            // I_E -> 4, Q_E -> 6, I_L -> 5, Q_L -> 8 (series order of _native.SERIES)
-            if (lane < 4) R[lane == 0 ? 4 : (lane == 1 ? 6 : (lane == 2 ? 5 : 8))] = r_v;
+            // rows hold I_E | Q_E | I_L | Q_L -> series 4, 6, 5, 8 (order of _native.SERIES)
+            if ((lane & 15) == 0) R[lane == 0 ? 4 : (lane == 16 ? 6 : (lane == 32 ? 5 : 8))] = r_v;
             if (lane == 0) {
                 R[0] = (double)(pos * SB + file_off);   // position after block it - 1 = first sample of block it
                 R[1] = r_cf;
@@ -993,27 +976,21 @@ __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const
         }
         T2STAMP(prof_on, 12);  // waiting for the sums
         // T8 DLL (tracking.py:238-251).  Row r of the wave holds the units' payloads of I_E | Q_E | I_L | Q_L: integer
-        // row sums (exact, order-free), then lanes 0..3 of every quad take the four totals: v = I_E | Q_E | I_L | Q_L
-        unsigned long long q = mine ? (unsigned long long)((long long)(x << 16) >> 16) : 0ull;
+        // row sums (exact, order-free; lanes that poll nothing hold 0), every lane of a row then has its row's total.
+        // The discriminator runs on the rows as they are: no lane shuffles besides two row broadcasts.
+        unsigned long long q = ((unsigned long long)(unsigned)((int)(short)(unsigned short)(x >> 32) + bias_hi) << 32) | (unsigned)x;
         q = dpp_addl_xor1(q, q);
         q = dpp_addl_xor2(q, q);
         q = dpp_addl_hmir(q, q);
         q = dpp_addl_mir(q, q);
-        const double vr = (double)(long long)q * (1.0 / t2_fix<SB>());
-        const int vh = __double2hiint(vr), vl = __double2loint(vr);
-        const int h0 = __builtin_amdgcn_readlane(vh, 0), l0 = __builtin_amdgcn_readlane(vl, 0);
-        const int h1 = __builtin_amdgcn_readlane(vh, 16), l1 = __builtin_amdgcn_readlane(vl, 16);
-        const int h2 = __builtin_amdgcn_readlane(vh, 32), l2 = __builtin_amdgcn_readlane(vl, 32);
-        const int h3 = __builtin_amdgcn_readlane(vh, 48), l3 = __builtin_amdgcn_readlane(vl, 48);
-        const double v = __hiloint2double(l4 == 0 ? h0 : (l4 == 1 ? h1 : (l4 == 2 ? h2 : h3)),
-                                          l4 == 0 ? l0 : (l4 == 1 ? l1 : (l4 == 2 ? l2 : l3)));
+        const double v = (__longlong_as_double((long long)q) - T2_MAGIC) * unfix;   // I_E | Q_E | I_L | Q_L by row
         const double sq = v * v;
-        const double e2 = sq + dpp_mov<0xB1>(sq);            // lanes 0,1: I_E^2 + Q_E^2; lanes 2,3: I_L^2 + Q_L^2
-        const double mag = sgx_fast_sqrt(e2);                // E | E | L | L
-        const double oth = dpp_mov<0x4E>(mag);               // L | L | E | E
-        const double ce_lane = sgx_fast_div(mag - oth, mag + oth);   // lanes 0,1: (E - L) / (E + L)
-        const double codeError = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ce_lane), 0),
-                                                  __builtin_amdgcn_readlane(__double2loint(ce_lane), 0));
+        const double e2 = sq + dpp_bcast<0x142, 0xA>(sq);    // rows 1, 3: I_E^2 + Q_E^2, I_L^2 + Q_L^2
+        const double mag = sgx_sqrt1(e2);                    // rows 1, 3: E, L
+        const double oth = dpp_bcast<0x143, 0xC>(mag);       // rows 2, 3: E
+        const double ce_lane = sgx_div1(oth - mag, oth + mag);       // row 3: (E - L) / (E + L)
+        const double codeError = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ce_lane), 48),
+                                                  __builtin_amdgcn_readlane(__double2loint(ce_lane), 48));
         const double codeNco = oldCodeNco + k_a * (codeError - oldCodeErr) + codeError * k_b;
         const double cf_new = basis - codeNco;
         oldCodeNco = codeNco;
@@ -1021,7 +998,7 @@ __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const
         T2PROBE(prof_on, 13);  // discriminator + NCO
         // chain part of the next block: its length, the ramps' slope and the slope's reciprocal
         double step_a, inv_step;
-        const int blk_n = t2_block_length(D, cf_new, a_next, step_a, inv_step);
+        const int blk_n = sgx_block_length(a_next, cf_new, D.fs, D.inv_fs, step_a, inv_step);
         const int stop_n = gave_up ? 2 : ((blk_n <= 0 || blk_n > lim1) ? 1 : ((blk_n > lim3) ? 3 : 0));
         if (lane == 0) {
             *reinterpret_cast<int4*>(&N.blk) = make_int4(blk_n, stop_n, __double2loint(inv_step), __double2hiint(inv_step));
@@ -1051,7 +1028,7 @@ __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const
     }
     if (owner && it > 0 && it == ms) {
         double* R = S.rec[(it - 1) & 1];
-        if (lane < 4) R[lane == 0 ? 4 : (lane == 1 ? 6 : (lane == 2 ? 5 : 8))] = r_v;
+        if ((lane & 15) == 0) R[lane == 0 ? 4 : (lane == 16 ? 6 : (lane == 32 ? 5 : 8))] = r_v;
         if (lane == 0) {
             R[0] = (double)(pos * SB + file_off);
             R[1] = r_cf;
@@ -1182,7 +1159,7 @@ __global__ __launch_bounds__(T2_THREADS) void trk2_kernel(const int8_t* __restri
         D.nb_base = K.nb_base;
         D.rec_len = (K.rec_len - cc.pad) / SB;      // samples on the channel's grid (cc.pad: its byte shift, SB = 2 only)
         double step_a, inv_step;
-        blk0 = t2_block_length(D, K.code_basis, K.code_len - 0.0, step_a, inv_step);
+        blk0 = sgx_block_length(K.code_len - 0.0, K.code_basis, D.fs, D.inv_fs, step_a, inv_step);
         const int lim3 = P * TRK_UNIT - 15;
         stop0 = dead ? 2 : ((blk0 <= 0 || cc.pos0 + blk0 > D.rec_len) ? 1 : ((blk0 > lim3) ? 3 : 0));
         const double off = ((lane & 3) == 0) ? -K.spacing : (((lane & 3) == 2) ? K.spacing : 0.0);

@@ -441,6 +441,60 @@ def test_short_chain_loop_filter_arithmetic_ulp_bounds(built):
     assert math.isnan(_math_eval(3, 0.0, 0.0)[0])
 
 
+def test_one_step_division_sqrt_atan_and_small_rotation_ulp_bounds(built):
+    """Round 3's shorter chain arithmetic (csrc/sgx_trk_math.h): sgx_div1 / sgx_sqrt1 (one Newton step + one residual
+    step), the atan with the quotient by sgx_div1, and the Taylor pair that turns a carrier-table entry by the rate
+    step (|angle| <= 0.34 rad), against 50-digit arithmetic; host seeds are float precision (worse than the GPU's)."""
+    import math
+    import mpmath as mp
+    mp.mp.dps = 50
+    rng = np.random.default_rng(20261002)
+
+    def ulps(got, exact):
+        e = abs(mp.mpf(got) - exact)
+        return float(e / (mp.mpf(2) ** (math.frexp(float(exact))[1] - 53)))
+
+    worst = dict(div=0.0, sqrt=0.0, atan=0.0, rot=0.0)
+    for _ in range(4000):
+        a = float(rng.uniform(-1, 1) * 10.0 ** rng.uniform(-3, 7))
+        b = float(rng.choice([-1, 1]) * 10.0 ** rng.uniform(-3, 7))
+        worst["div"] = max(worst["div"], ulps(_math_eval(6, a, b)[0], mp.mpf(a) / mp.mpf(b)))
+        x = abs(a) ** 2
+        worst["sqrt"] = max(worst["sqrt"], ulps(_math_eval(7, x)[0], mp.sqrt(mp.mpf(x))))
+        q = float(rng.uniform(-1, 1) * 10.0 ** rng.uniform(-2, 5))
+        i = float(rng.choice([-1, 1]) * abs(q) * 10.0 ** rng.uniform(-1, 3))
+        worst["atan"] = max(worst["atan"], ulps(_math_eval(8, q, i)[0], mp.atan(mp.mpf(q) / mp.mpf(i))))
+        ph = float(rng.uniform(-0.34, 0.34) * 10.0 ** -rng.integers(0, 5))
+        sn, cs = _math_eval(9, ph)
+        err = max(abs(mp.mpf(sn) - mp.sin(mp.mpf(ph))), abs(mp.mpf(cs) - mp.cos(mp.mpf(ph))))
+        worst["rot"] = max(worst["rot"], float(err * 2 ** 53))     # phase error in units of 2^-53 rad
+    assert worst["div"] <= 1.5 and worst["sqrt"] <= 1.0 and worst["atan"] <= 2.5 and worst["rot"] <= 2.0, worst
+    assert _math_eval(7, 0.0)[0] == 0.0
+    assert _math_eval(8, 1.0, 0.0)[0] == math.atan(math.inf) and math.isnan(_math_eval(8, 0.0, 0.0)[0])
+
+
+def test_block_length_without_a_division_equals_the_reference(built):
+    """sgx_block_length == ceil((1023 - rem) / (codeFreq / fs)) as numpy evaluates tracking.py:148-151 (two correctly
+    rounded divisions), for code frequencies around the basis, including quotients that are integers or a few ulp off."""
+    import math
+    rng = np.random.default_rng(77)
+    fs = 38192000.0
+    assert int(_math_eval(10, 1023.0, 1023000.0)[0]) == 38192          # block 0: the quotient IS an integer
+    for k in range(20000):
+        cf = 1.023e6 + rng.normal(0, 5)
+        step = cf / fs
+        if k % 4 == 0:
+            n = int(rng.integers(38000, 38400))
+            a = n * step
+            for _ in range(int(rng.integers(0, 5))):
+                a = float(np.nextafter(a, a + rng.choice([-1.0, 1.0])))
+        else:
+            a = 1023.0 - rng.uniform(-0.05, 0.05)
+        got, step_a = _math_eval(10, a, cf)
+        assert int(got) == math.ceil(a / step), (a, cf)
+        assert abs(step_a - step) <= 3 * np.spacing(step)
+
+
 def test_division_free_ceil_equals_ieee_ceil(built):
     """sgx_ceil_div(a, b) == ceil(a / b) for the block-length computation blksize = ceil((1023 - rem) / step)
     (tracking.py:148-151), including quotients that are exact integers or within a few ulp of one."""

@@ -3,12 +3,12 @@
 cd "$(dirname "$0")/.."
 out=gpurun_out/r3_probe
 mkdir -p $out
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "track_golden or track_device_file or replicated or full_length or split_variants or kernels_agree" > $out/pytest1.log 2>&1
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "${R3_TESTS:-track_golden or track_device_file or replicated or full_length or split_variants or kernels_agree}" > $out/pytest1.log 2>&1
 echo "pytest rc $?" >> $out/pytest1.log
 tail -5 $out/pytest1.log
-for v in "" "SGX_TRK_ARMS=3" "SGX_TRK_LDSPAD=0" "SGX_TRK_ARMS=3 SGX_TRK_LDSPAD=0"; do
+for v in "${@:-X=1}"; do
   echo "== variant [$v]"
-  env $v SGX_TRK_PROFILE=1 timeout 300 python tools/step_profile.py 4000 2>&1 | grep -v "^ \|^$\|function calls\|Ordered by\|ncalls" | head -40
+  env $v SGX_TRK_PROFILE=1 timeout 300 python tools/step_profile.py 4000 2>&1 | grep "profile\] ch 0 member\|^step" | awk 'NR<=4 || /member  *(9|10|19|29) / || /^step/' | head -12
   env $v timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --many-channels 0 --concurrent 0 --no-config4 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
