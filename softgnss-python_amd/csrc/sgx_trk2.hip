@@ -652,9 +652,12 @@ __device__ __forceinline__ int t2_map1_role(T2Shared& S, const int8_t* __restric
         const double aQ = __builtin_fma(gc, Ac, -(gs * As));
         const double aI = __builtin_fma(gs, Ac, gc * As);
         // fixed point: the raw bits of fma(a, 2^28, 1.5 2^52) are bias + round(a 2^28); sums of them carry the sum of
-        // the integers in their low 48 bits whatever the bias adds up to
-        const unsigned long long qI = (unsigned long long)__double_as_longlong(__builtin_fma(aI, t2_fix<SB>(), T2_MAGIC));
-        const unsigned long long qQ = (unsigned long long)__double_as_longlong(__builtin_fma(aQ, t2_fix<SB>(), T2_MAGIC));
+        // the integers in their low 48 bits whatever the bias adds up to (sixteen biases leave the low 52 bits alone).
+        // Two-byte samples: 2^24 in the lanes (a member's total needs 52 bits), rounded to the granule's 2^19 once.
+        constexpr double lane_fix = (SB == 1) ? T2_FIX : T2_FIX16 * 32.0;
+        constexpr unsigned long long res_mask = (SB == 1) ? 0xFFFFFFFFFFFFull : 0xFFFFFFFFFFFFFull;
+        const unsigned long long qI = (unsigned long long)__double_as_longlong(__builtin_fma(aI, lane_fix, T2_MAGIC));
+        const unsigned long long qQ = (unsigned long long)__double_as_longlong(__builtin_fma(aQ, lane_fix, T2_MAGIC));
         T2PROBE(prof_on, 3);   // group finalisation
         // transposing reduction inside each row of 16 lanes: even lanes end with the row's I, odd lanes with its Q
         const bool b0 = (lane & 1) != 0;
@@ -664,11 +667,12 @@ __device__ __forceinline__ int t2_map1_role(T2Shared& S, const int8_t* __restric
         v = dpp_addl_ror8(v, v);
         T2PROBE(prof_on, 4);   // row reduction
         if ((lane & 15) < 2) {
-            const unsigned long long mine = (v & 0xFFFFFFFFFFFFull) | (1ull << 56);
+            const unsigned long long mine = (v & res_mask) | (1ull << 56);
             const unsigned long long prev = atomicAdd(&S.acc[par][lane & 1], mine);
             if ((prev >> 56) == 15ull) {
                 // the sixteenth arrival (4 waves x 4 rows): this lane holds the member's total
-                const unsigned long long tot = prev + mine;
+                unsigned long long tot = prev + mine;
+                if constexpr (SB == 2) tot = (unsigned long long)((((long long)(tot << 12) >> 12) + 16) >> 5);
                 S.acc[par][lane & 1] = 0ull;
                 const unsigned long long gran = ((unsigned long long)((unsigned)(it + 1) & 0xFFFFu) << 48) | (tot & 0xFFFFFFFFFFFFull);
                 granule_store(xbase + T2_XG + par * 96 + (wbase + (lane & 1)) * 16 + unit, gran, fast);
