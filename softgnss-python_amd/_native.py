@@ -54,7 +54,8 @@ class Scene(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [("acquire_ms", C.c_float), ("acq_coarse_ms", C.c_float), ("acq_fine_ms", C.c_float),
-                ("track_ms", C.c_float), ("synth_ms", C.c_float), ("reserved", C.c_float * 3)]
+                ("track_ms", C.c_float), ("synth_ms", C.c_float), ("track_kernel", C.c_float),
+                ("track_members", C.c_float), ("track_streamed", C.c_float)]
 
 
 # every symbol include/sgx.h declares: name -> (restype, argtypes)
@@ -284,7 +285,8 @@ class Context(object):
         t = Timing()
         check(lib().sgx_get_timing(self._h, C.byref(t)))
         return dict(acquire_ms=t.acquire_ms, acq_coarse_ms=t.acq_coarse_ms, acq_fine_ms=t.acq_fine_ms,
-                    track_ms=t.track_ms, synth_ms=t.synth_ms)
+                    track_ms=t.track_ms, synth_ms=t.synth_ms, track_kernel=int(t.track_kernel),
+                    track_members=int(t.track_members), track_streamed=int(t.track_streamed))
 
     def stream_rates(self, nbytes=1 << 30, reps=5):
         """(read GB/s, copy GB/s) measured on this device: the practical HBM roof next to the 8 TB/s datasheet peak."""

@@ -296,7 +296,138 @@ extern "C" int sgx_if_upload(sgx_ctx* c, const int8_t* host, size_t n, sgx_if** 
     return SGX_OK;
 }
 
-// Streaming ingest: pread() into one pinned buffer while the other is in flight.
+// ---- file -> HBM pipeline ------------------------------------------------------
+// np.fromfile copies the file through the page cache into a pageable array and hipMemcpy then stages that array once
+// more.  Here READERS threads pread() alternate 16 MiB chunks straight into a ring of four pinned slots while the
+// issuing thread queues the slots' H2D copies in file order on one stream; a slot is read into again once the copy that
+// last used it has completed.  One pread() stream moves ~21 GB/s out of the page cache (it is a CPU memcpy), three keep
+// ahead of the PCIe link.
+__global__ void if_mark_kernel(unsigned long long* mark, unsigned long long value) {
+    __hip_atomic_store(mark, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+#define SGX_STAGE_BYTES (32u << 20)   // a pinned staging buffer: two slots
+#define SGX_SLOT_BYTES (16u << 20)    // a multiple of every cache-line size: a line is never fetched half written
+#define SGX_PIPE_SLOTS 4
+#define SGX_PIPE_READERS 3
+
+struct FilePipe {
+    int fd = -1;
+    uint64_t file_offset = 0;
+    size_t n = 0;                         // bytes to move
+    int8_t* dst = nullptr;                // device
+    int device = 0;
+    hipStream_t stream = nullptr;
+    char* slot[SGX_PIPE_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[SGX_PIPE_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned long long* d_mark = nullptr; // device watermark advanced in stream order after every chunk, or null
+    std::atomic<size_t>* host_mark = nullptr;   // bytes whose copy is known to have completed, or null
+    std::vector<std::atomic<int>> read_ok;      // per chunk: 1 read, -1 read error
+    std::atomic<long> issued{0};          // chunks whose copy and event have been queued
+    std::atomic<bool> stop{false};
+    std::atomic<int> err_no{0};
+    std::atomic<size_t> err_off{0};
+    explicit FilePipe(size_t chunks) : read_ok(chunks) {
+        for (auto& f : read_ok) f.store(0);
+    }
+};
+
+static void pipe_reader(FilePipe* P, int t) {
+    (void)hipSetDevice(P->device);
+    const long chunks = (long)P->read_ok.size();
+    for (long i = t; i < chunks && !P->stop.load(); i += SGX_PIPE_READERS) {
+        const int sl = (int)(i % SGX_PIPE_SLOTS);
+        if (i >= SGX_PIPE_SLOTS) {
+            // the slot's previous chunk: its copy must have been queued, then completed
+            while (P->issued.load() <= i - SGX_PIPE_SLOTS && !P->stop.load()) std::this_thread::sleep_for(std::chrono::microseconds(20));
+            if (P->stop.load()) break;
+            if (hipEventSynchronize(P->ev[sl]) != hipSuccess) {
+                P->read_ok[(size_t)i].store(-1);
+                break;
+            }
+            if (P->host_mark) {
+                const size_t end = (size_t)(i - SGX_PIPE_SLOTS + 1) * SGX_SLOT_BYTES;
+                size_t cur = P->host_mark->load();
+                while (end > cur && !P->host_mark->compare_exchange_weak(cur, end)) {
+                }
+            }
+        }
+        const size_t off = (size_t)i * SGX_SLOT_BYTES;
+        const size_t len = (P->n - off < SGX_SLOT_BYTES) ? (P->n - off) : SGX_SLOT_BYTES;
+        size_t got = 0;
+        bool bad = false;
+        while (got < len) {
+            const ssize_t m = pread(P->fd, P->slot[sl] + got, len - got, (off_t)(P->file_offset + off + got));
+            if (m <= 0) {
+                bad = true;
+                P->err_no.store(errno);
+                P->err_off.store(off + got);
+                break;
+            }
+            got += (size_t)m;
+        }
+        P->read_ok[(size_t)i].store(bad ? -1 : 1);
+        if (bad) break;
+    }
+}
+
+// Runs the pipeline to completion on the calling thread (which issues the copies).  Returns hipSuccess and *io_fail.
+static hipError_t pipe_run(FilePipe* P, bool* io_fail) {
+    *io_fail = false;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < SGX_PIPE_SLOTS && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&P->ev[i], hipEventDisableTiming);
+    std::vector<std::thread> readers;
+    const long chunks = (long)P->read_ok.size();
+    if (e == hipSuccess)
+        for (int t = 0; t < SGX_PIPE_READERS && t < chunks; ++t) readers.emplace_back(pipe_reader, P, t);
+    for (long i = 0; i < chunks && e == hipSuccess; ++i) {
+        int st;
+        while ((st = P->read_ok[(size_t)i].load()) == 0) std::this_thread::sleep_for(std::chrono::microseconds(10));
+        if (st < 0) {
+            *io_fail = true;
+            break;
+        }
+        const int sl = (int)(i % SGX_PIPE_SLOTS);
+        const size_t off = (size_t)i * SGX_SLOT_BYTES;
+        const size_t len = (P->n - off < SGX_SLOT_BYTES) ? (P->n - off) : SGX_SLOT_BYTES;
+        e = hipMemcpyAsync(P->dst + off, P->slot[sl], len, hipMemcpyHostToDevice, P->stream);
+        if (e == hipSuccess && P->d_mark) if_mark_kernel<<<1, 1, 0, P->stream>>>(P->d_mark, (unsigned long long)(off + len));
+        if (e == hipSuccess) e = hipEventRecord(P->ev[sl], P->stream);
+        P->issued.store(i + 1);
+    }
+    if (e != hipSuccess || *io_fail) P->stop.store(true);
+    for (auto& t : readers) t.join();
+    if (e == hipSuccess) e = hipStreamSynchronize(P->stream);
+    for (int i = 0; i < SGX_PIPE_SLOTS; ++i)
+        if (P->ev[i]) hipEventDestroy(P->ev[i]);
+    return e;
+}
+
+// the context's two pinned staging buffers (kept between calls: pinning 64 MiB costs ~15 ms), reserved for one user
+static bool stage_acquire(sgx_ctx* c) {
+    bool expected = false;
+    if (!c->stage_busy.compare_exchange_strong(expected, true)) return false;
+    for (int i = 0; i < 2; ++i)
+        if (!c->stage[i] && hipHostMalloc(&c->stage[i], SGX_STAGE_BYTES, hipHostMallocDefault) != hipSuccess) c->stage[i] = nullptr;
+    if (c->stage[0] && c->stage[1]) return true;
+    c->stage_busy.store(false);
+    return false;
+}
+
+static bool pipe_slots(FilePipe* P, sgx_ctx* owner, void* own[2]) {
+    own[0] = own[1] = nullptr;
+    for (int i = 0; i < 2; ++i) {
+        void* buf = owner ? owner->stage[i] : nullptr;
+        if (!buf) {
+            if (hipHostMalloc(&own[i], SGX_STAGE_BYTES, hipHostMallocDefault) != hipSuccess) return false;
+            buf = own[i];
+        }
+        P->slot[2 * i] = (char*)buf;
+        P->slot[2 * i + 1] = (char*)buf + SGX_SLOT_BYTES;
+    }
+    return true;
+}
+
 extern "C" int sgx_if_upload_file(sgx_ctx* c, const char* path, uint64_t file_offset, size_t n, sgx_if** out) {
     SGX_CHECK_ARG(c && path && out);
     SGX_HIP(hipSetDevice(c->device));
@@ -319,46 +450,26 @@ extern "C" int sgx_if_upload_file(sgx_ctx* c, const char* path, uint64_t file_of
         close(fd);
         return rc;
     }
-    const size_t chunk = 32u << 20;
-    void* stage[2] = {nullptr, nullptr};
-    hipEvent_t done[2] = {nullptr, nullptr};
-    hipError_t e = hipSuccess;
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
-        e = hipHostMalloc(&stage[i], chunk, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
-    }
-    size_t off = 0;
-    int k = 0;
+    FilePipe P((avail + SGX_SLOT_BYTES - 1) / SGX_SLOT_BYTES);
+    P.fd = fd;
+    P.file_offset = file_offset;
+    P.n = avail;
+    P.dst = r->d;
+    P.device = c->device;
+    P.stream = c->stream;
+    sgx_ctx* owner = stage_acquire(c) ? c : nullptr;
+    void* own[2];
     bool io_fail = false;
-    while (e == hipSuccess && off < avail) {
-        const size_t len = (avail - off < chunk) ? (avail - off) : chunk;
-        e = hipEventSynchronize(done[k]);   // the copy that last used this staging buffer has finished
-        if (e != hipSuccess) break;
-        size_t got = 0;
-        while (got < len) {
-            const ssize_t m = pread(fd, (char*)stage[k] + got, len - got, (off_t)(file_offset + off + got));
-            if (m <= 0) {
-                io_fail = true;
-                break;
-            }
-            got += (size_t)m;
-        }
-        if (io_fail) break;
-        e = hipMemcpyAsync(r->d + off, stage[k], len, hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) e = hipEventRecord(done[k], c->stream);
-        off += len;
-        k ^= 1;
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    for (int i = 0; i < 2; ++i) {
-        if (done[i]) hipEventDestroy(done[i]);
-        if (stage[i]) hipHostFree(stage[i]);
-    }
+    hipError_t e = pipe_slots(&P, owner, own) ? pipe_run(&P, &io_fail) : hipErrorOutOfMemory;
+    for (int i = 0; i < 2; ++i)
+        if (own[i]) hipHostFree(own[i]);
+    if (owner) owner->stage_busy.store(false);
     close(fd);
     if (e != hipSuccess || io_fail) {
         sgx_if_free(c, r);
         if (io_fail)
-            sgx_set_error("read error on %s at byte %llu: %s", path, (unsigned long long)(file_offset + off), strerror(errno));
+            sgx_set_error("read error on %s at byte %llu: %s", path, (unsigned long long)(file_offset + P.err_off.load()),
+                          strerror(P.err_no.load()));
         else
             sgx_set_error("streaming upload of %s failed: %s", path, hipGetErrorString(e));
         return io_fail ? SGX_E_ARG : SGX_E_HIP;
@@ -368,54 +479,24 @@ extern "C" int sgx_if_upload_file(sgx_ctx* c, const char* path, uint64_t file_of
 }
 
 // ---- background streaming: the record fills in file order while acquisition and tracking already run ----------
-__global__ void if_mark_kernel(unsigned long long* mark, unsigned long long value) {
-    __hip_atomic_store(mark, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-#define SGX_STAGE_BYTES (32u << 20)   // a multiple of every cache-line size: a line is never half written
-
 static void if_loader_main(sgx_if* r, int fd, uint64_t file_offset, std::string path, sgx_ctx* owner) {
-    const size_t chunk = SGX_STAGE_BYTES;
-    // staging buffers: the context's (owner != null: reserved for this loader by sgx_if_open_file) or private ones
-    void* stage[2] = {owner ? owner->stage[0] : nullptr, owner ? owner->stage[1] : nullptr};
-    hipEvent_t done[2] = {nullptr, nullptr};
-    size_t end_of[2] = {0, 0};
     hipError_t e = hipSetDevice(r->device);
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
-        if (!owner) e = hipHostMalloc(&stage[i], chunk, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
-    }
-    size_t off = 0;
-    int k = 0;
+    FilePipe P((r->n + SGX_SLOT_BYTES - 1) / SGX_SLOT_BYTES);
+    P.fd = fd;
+    P.file_offset = file_offset;
+    P.n = r->n;
+    P.dst = r->d;
+    P.device = r->device;
+    P.stream = r->copy_stream;
+    P.d_mark = r->d_mark;
+    P.host_mark = &r->host_mark;
+    void* own[2] = {nullptr, nullptr};
     bool io_fail = false;
-    while (e == hipSuccess && off < r->n) {
-        const size_t len = (r->n - off < chunk) ? (r->n - off) : chunk;
-        e = hipEventSynchronize(done[k]);   // the copy that last used this staging buffer has finished
-        if (e != hipSuccess) break;
-        if (end_of[k] > r->host_mark.load()) r->host_mark.store(end_of[k]);
-        size_t got = 0;
-        while (got < len) {
-            const ssize_t m = pread(fd, (char*)stage[k] + got, len - got, (off_t)(file_offset + off + got));
-            if (m <= 0) {
-                io_fail = true;
-                break;
-            }
-            got += (size_t)m;
-        }
-        if (io_fail) break;
-        e = hipMemcpyAsync(r->d + off, stage[k], len, hipMemcpyHostToDevice, r->copy_stream);
-        off += len;
-        if (e == hipSuccess) {
-            if_mark_kernel<<<1, 1, 0, r->copy_stream>>>(r->d_mark, (unsigned long long)off);
-            e = hipEventRecord(done[k], r->copy_stream);
-        }
-        end_of[k] = off;
-        k ^= 1;
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(r->copy_stream);
+    if (e == hipSuccess) e = pipe_slots(&P, owner, own) ? pipe_run(&P, &io_fail) : hipErrorOutOfMemory;
     if (e != hipSuccess || io_fail) {
         snprintf(r->load_err, sizeof(r->load_err), io_fail ? "read error on %s at byte %llu: %s" : "streaming %s failed at byte %llu: %s",
-                 path.c_str(), (unsigned long long)(file_offset + off), io_fail ? strerror(errno) : hipGetErrorString(e));
+                 path.c_str(), (unsigned long long)(file_offset + P.err_off.load()),
+                 io_fail ? strerror(P.err_no.load()) : hipGetErrorString(e));
         r->load_rc.store(io_fail ? SGX_E_ARG : SGX_E_HIP);
     } else {
         r->host_mark.store(r->n);
@@ -423,10 +504,8 @@ static void if_loader_main(sgx_if* r, int fd, uint64_t file_offset, std::string 
     // whatever happened, nobody may wait for the watermark any longer
     if_mark_kernel<<<1, 1, 0, r->copy_stream>>>(r->d_mark, 0x7FFFFFFFFFFFFFFFull);
     hipStreamSynchronize(r->copy_stream);
-    for (int i = 0; i < 2; ++i) {
-        if (done[i]) hipEventDestroy(done[i]);
-        if (!owner && stage[i]) hipHostFree(stage[i]);
-    }
+    for (int i = 0; i < 2; ++i)
+        if (own[i]) hipHostFree(own[i]);
     if (owner) owner->stage_busy.store(false);
     close(fd);
     r->load_done.store(true);
@@ -487,16 +566,7 @@ extern "C" int sgx_if_open_file(sgx_ctx* c, const char* path, uint64_t file_offs
         return SGX_E_HIP;
     }
     // reserve the context's pinned staging buffers for this loader if nobody else is streaming
-    sgx_ctx* owner = nullptr;
-    bool expected = false;
-    if (c->stage_busy.compare_exchange_strong(expected, true)) {
-        for (int i = 0; i < 2; ++i)
-            if (!c->stage[i] && hipHostMalloc(&c->stage[i], SGX_STAGE_BYTES, hipHostMallocDefault) != hipSuccess) c->stage[i] = nullptr;
-        if (c->stage[0] && c->stage[1])
-            owner = c;
-        else
-            c->stage_busy.store(false);
-    }
+    sgx_ctx* owner = stage_acquire(c) ? c : nullptr;
     r->loader = new std::thread(if_loader_main, r, fd, file_offset, std::string(path), owner);
     *out = r;
     return SGX_OK;

@@ -55,11 +55,6 @@ void sgx_trk2_launch(int n_blocks, hipStream_t st, const int8_t* rec, const int8
 #define T2_XCH_STRIDE 256
 #define T2_PROF_STRIDE 192
 
-// sgx_trk_stream.hip: the cooperative kernel with watermark checks, for a record that is still streaming in
-void sgx_trk_stream_launch(int n_blocks, hipStream_t st, const int8_t* rec, const int8_t* codes, const TrkChan* chans,
-                           double* out, int* done, const TrkConst& K, long long* prof, unsigned long long* xch,
-                           int* err);
-
 // sgx_trk_multi.hip: the cooperative kernel with a per-sample replica lookup, for low sampling rates
 void sgx_trk_multi_launch(int n_blocks, hipStream_t st, const int8_t* rec, const int8_t* codes, const TrkChan* chans,
                           double* out, int* done, const TrkConst& K, long long* prof, unsigned long long* xch,
@@ -244,7 +239,7 @@ static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
             n = 0;
         }
     } reserved{c->device, 0};
-    bool used_v2 = false;
+    bool used_v2 = false, retry_resident = false;
     int used_members = 0;
     hipError_t e = hipSuccess;
     int h_err = 0;
@@ -255,11 +250,11 @@ static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
         SGX_HIP(hipMemcpyAsync(d_ch, hc.data(), sizeof(TrkChan) * (size_t)n_ch, hipMemcpyHostToDevice, st));
         SGX_HIP(hipMemsetAsync(aux + sz_ch, 0, sz_done + sz_xch + 256, st));   // done, every polled word, err
         if (!direct) trk_fill_kernel<<<(unsigned)((elems + 255) / 256), 256, 0, st>>>(d_out, ms, (long long)elems);
-        // a record that is still streaming in is followed by the round-1 kernel's watermark variant
+        // a record that is still streaming in is followed by the latency-mode kernel (its record wave watches the
+        // device watermark); the other kernels, and a repeated launch, first wait for the whole record
         const char* se2 = getenv("SGX_TRK_STREAM");
-        const bool want_stream = r->loader && !r->load_done.load() && attempt == 0 && !(se2 && se2[0] == '0') && !K.multi &&
-                                 !(split_v1 == 1 && n_ch > 128) && sample_bytes == 1;
-        const bool v2 = use_v2 && attempt == 0 && !want_stream;
+        const bool v2 = use_v2 && (attempt == 0 || retry_resident);
+        const bool want_stream = r->loader && !r->load_done.load() && attempt == 0 && !(se2 && se2[0] == '0') && v2;
         const int arms = (v2 && arm_split) ? 1 : 3;
         if (attempt == 0) K.split = v2 ? K.n_units : split_v1;
         const int members = K.split * (arms == 1 ? 3 : 1);      // workgroups per channel
@@ -294,9 +289,7 @@ static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
         }
         const int members_now = K.split * ((v2 && K.split > 1 && arms_now == 1) ? 3 : 1);
         const int n_blocks = ch8 * members_now;
-        // a record that is still streaming in: the cooperative kernel follows the device watermark; the other
-        // kernels (and a repeated launch) first wait for the whole record
-        const bool streaming = want_stream;
+        const bool streaming = want_stream && K.split > 1;
         if (!streaming) {
             const int rq = sgx_if_require(r, r->n);
             if (rq != SGX_OK) return rq;
@@ -304,30 +297,35 @@ static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
         K.mark = streaming ? r->d_mark : nullptr;
         if (want_prof) SGX_HIP(hipMemsetAsync(d_prof, 0, sz_prof, st));
         hipEventRecord(c->ev[3], st);
-        if (streaming)
-            sgx_trk_stream_launch(n_blocks, st, r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err);
-        else if (v2 && K.split > 1) {
+        if (v2 && K.split > 1) {
             const char* wh = getenv("SGX_TRK_TEST_WITHHOLD");   // test hook: launch without each channel's last member
             const int nb2 = (wh && wh[0] == '1') ? n_blocks - 8 : n_blocks;
             sgx_trk2_launch(nb2, st, r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err, sample_bytes, arms_now,
                             lds_pad);
             used_v2 = true;
             used_members = members_now;
+            c->timing.track_kernel = 2.f;
         }
-        else if (K.split == 1 && n_ch > 128)   // (general in the sampling rate: one lane per prompt chip)
+        else if (K.split == 1 && n_ch > 128) {   // (general in the sampling rate: one lane per prompt chip)
             sgx_trk_tp_launch(n_blocks, st, r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err);
-        else if (K.multi)
+            c->timing.track_kernel = 3.f;
+        } else if (K.multi) {
             sgx_trk_multi_launch(n_blocks, st, r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err);
-        else {
+            c->timing.track_kernel = 4.f;
+        } else {
+            c->timing.track_kernel = 1.f;
             const char* wh = getenv("SGX_TRK_TEST_WITHHOLD");   // (the same test hook for the round-1 cooperative kernel)
             const int nb1 = (wh && wh[0] == '1' && K.split > 1) ? n_blocks - 8 : n_blocks;
             trk_kernel<<<nb1, TRK_THREADS, 0, st>>>(r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err);
         }
         hipEventRecord(c->ev[4], st);
+        c->timing.track_members = (float)members_now;
+        c->timing.track_streamed = streaming ? 1.f : 0.f;
         e = hipGetLastError();
-        h_err = 0;
-        if (e == hipSuccess) e = hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, st);
+        int h_err2[2] = {0, 0};   // [0] flags | 1 + channel of a timeout; [1] 1 + channel of a block beyond the units
+        if (e == hipSuccess) e = hipMemcpyAsync(h_err2, d_err, 2 * sizeof(int), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
+        h_err = h_err2[0];
         reserved.drop();
         const char* th = getenv("SGX_TRK_TEST_TIMEOUT");   // test hook: treat the first attempt as timed out
         if (e == hipSuccess && th && th[0] == '1' && attempt == 0 && K.split > 1) h_err = 1;
@@ -336,13 +334,15 @@ static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
             // with the same decomposition once the whole record is resident
             fprintf(stderr, "[sgx] tracking: the record did not stream in beside the kernel; repeating the launch "
                             "on the resident record\n");
+            retry_resident = true;
             continue;
         }
         h_err &= ~TRK_ERR_STREAM;
+        if (e == hipSuccess && (h_err & TRK_ERR_RANGE) == 0) h_err &= 0xFFFF;
         if (e == hipSuccess && (h_err & TRK_ERR_RANGE)) {
             sgx_set_error("tracking: channel %d reached a block longer than the %d units of %d samples the kernel "
                           "provides (the code NCO left its plausible range; dllNoiseBandwidth %g)",
-                          (h_err & 0xFFFF) - 1, K.n_units, TRK_UNIT, S.dllNoiseBandwidth);
+                          (h_err2[1] ? h_err2[1] : (h_err & 0xFFFF)) - 1, K.n_units, TRK_UNIT, S.dllNoiseBandwidth);
             return SGX_E_RANGE;
         }
         if (e != hipSuccess || h_err == 0 || K.split == 1) break;

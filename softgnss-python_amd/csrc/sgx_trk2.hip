@@ -1007,7 +1007,10 @@ __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const
         if (lane == 0) {
             *reinterpret_cast<int4*>(&N.blk) = make_int4(blk_n, stop_n, __double2loint(inv_step), __double2hiint(inv_step));
             N.step = step_a;
-            if (blk_n > lim3 && !gave_up) atomicExch(err, TRK_ERR_RANGE | (1 + ch));
+            if (blk_n > lim3 && !gave_up) {
+                atomicOr(err, TRK_ERR_RANGE);
+                atomicCAS(err + 1, 0, 1 + ch);
+            }
         }
         rem = rem_next;
         pos = pos_next;
@@ -1054,13 +1057,27 @@ __device__ __forceinline__ void t2_rec_store(T2Shared& S, int k, long long m, in
     if (lane < SGX_NUM_SERIES) o[lane * m + k] = S.rec[k & 1][lane];
 }
 
-__device__ __forceinline__ int t2_rec_role(T2Shared& S, int ms, bool owner, int lane, double* __restrict__ o) {
-    const long long m = ms;
+// A record that is still streaming in from a file (K.mark: the device-side watermark, bytes resident so far, advanced in
+// copy-stream order): while block `it` is processed, everything block it + 1 can touch - its own samples and the
+// prefetch of the block after it - must be resident.  This wave, idle otherwise, checks that one block ahead, before
+// it arrives at the barrier that starts block it + 1.  Copies advance in 32 MiB steps (a multiple of every cache-line
+// size), so no line is ever fetched half written; the watermark is cached in a register, so the uncached load is
+// issued once per ~900 blocks.
+template <int SB>
+__device__ __forceinline__ int t2_rec_role(T2Shared& S, const TrkConst& K, int pad, int P, int ch, bool owner, int lane,
+                                           double* __restrict__ o, int* __restrict__ err, unsigned long long mark_seen) {
+    const long long m = K.ms;
+    const int ms = K.ms;
+    const long long span = (2ll * P * TRK_UNIT + 64) * SB;    // bytes: a block and the window of the prefetch behind it
     int it = 0;
     for (; it < ms; ++it) {
         const int par = it & 1;
         if (S.code[par].stop) break;
         if (owner && it > 0) t2_rec_store(S, it - 1, m, lane, o);
+        {   // (a resident record: mark_seen is all ones and this returns at once)
+            const long long need = S.code[par].pos * SB + pad + 3 * span;
+            wait_mark(K.mark, need < K.rec_len ? need : K.rec_len, mark_seen, err, ch);
+        }
         wg_barrier();
     }
     return it;
@@ -1173,7 +1190,10 @@ __global__ __launch_bounds__(T2_THREADS) void trk2_kernel(const int8_t* __restri
             *reinterpret_cast<int4*>(&S.code[0].blk) = make_int4(blk0, stop0, __double2loint(inv_step), __double2hiint(inv_step));
             S.code[0].step = step_a;
             S.code[0].pos = cc.pos0;
-            if (blk0 > lim3) atomicExch(err, TRK_ERR_RANGE | (1 + ch));
+            if (blk0 > lim3) {
+                atomicOr(err, TRK_ERR_RANGE);
+                atomicCAS(err + 1, 0, 1 + ch);
+            }
         }
     }
     if (wave == 4) {
@@ -1181,6 +1201,12 @@ __global__ __launch_bounds__(T2_THREADS) void trk2_kernel(const int8_t* __restri
         t2_carr_entry(K.inv_2pifs_hi, K.inv_2pifs_lo, K.inv_2pi, (cc.acquiredFreq * 2.0) * M_PI, 0.0,
                       t2_carr_mult(lane, unit, (int)(cc.pos0 & 15)), lane >= 48, cs, sn);
         S.carr[0].T[lane < 48 ? lane : 48] = make_double2(cs, sn);
+    }
+    // a streaming record: block 0 and the prefetch of block 1 must be resident before the first loads
+    unsigned long long mark_seen = K.mark ? 0ull : ~0ull;
+    if (wave == 6 && K.mark) {
+        const long long need = cc.pos0 * SB + cc.pad + 3 * (2ll * P * TRK_UNIT + 64) * SB;
+        wait_mark(K.mark, need < K.rec_len ? need : K.rec_len, mark_seen, err, ch);
     }
     __syncthreads();
 
@@ -1197,7 +1223,7 @@ __global__ __launch_bounds__(T2_THREADS) void trk2_kernel(const int8_t* __restri
     else if (wave == 5)
         done = t2_dll_role<SB, ARMS>(S, K, D, cc.pos0, blk0, stop0, arm, owner, lane, P, ch, xbase, err, prof_on, K.file_off + cc.pad);
     else
-        done = t2_rec_role(S, K.ms, owner, lane, o);
+        done = t2_rec_role<SB>(S, K, cc.pad, P, ch, owner, lane, o, err, mark_seen);
 
     // a channel that was given up reports the blocks completed before the abort
     const bool aborted = S.code[done & 1].stop == 2;

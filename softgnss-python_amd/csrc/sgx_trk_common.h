@@ -1,5 +1,4 @@
-// Device helpers shared by the two tracking kernels (sgx_trk.hip: cooperative kernel, sgx_trk_spec.hip:
-// speculative pipeline).  Everything here follows the reference's fp64 operation order where an integer
+// Device helpers shared by the tracking kernels (sgx_trk.hip, sgx_trk2.hip, sgx_trk_tp.hip).  Everything here follows the reference's fp64 operation order where an integer
 // rounding follows; both files are built with -ffp-contract=off.
 #pragma once
 #include <math.h>
@@ -273,7 +272,8 @@ __device__ __forceinline__ void wait_mark(const unsigned long long* mark, long l
         if (seen >= (unsigned long long)need) break;
         if (--budget == 0) {
             // give up for good (the host repeats the launch once the whole record is resident): no further waits
-            atomicExch(err, TRK_ERR_STREAM | (1 + ch));
+            atomicOr(err, TRK_ERR_STREAM);
+            (void)ch;
             seen = ~0ull;
             break;
         }
