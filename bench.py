@@ -10,7 +10,9 @@ in HBM: AcquisitionResult.acquire (32 PRNs, 2 x 1 ms coherent blocks, 29 Doppler
 N > 1 runs one process per GPU.  Either the driver starts the ranks (`python -m torch.distributed.run
 --nproc-per-node N ... bench.py --gpus N`: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the
 environment), or - when WORLD_SIZE is not set - this script starts them itself, as children, before it
-touches the GPU (`launch_ranks`), and exits non-zero when the node has fewer than N devices.  Every rank
+touches the GPU (`launch_ranks`), and exits non-zero when the node has fewer than N devices.  The ranks meet over
+a socket rendezvous of their own (softgnss-python_amd/rendezvous.py: barrier, max over ranks, the RCCL unique id);
+PyTorch is not imported.  Every rank
 tracks its own 8 channels on its own copy of the record (weak scaling, BASELINE.json config 5) and
 searches 32/N of the PRNs, the peaks being all-gathered with RCCL (config 4's exchange).  The
 `acq_config4` leg reports BASELINE.json config 4 itself: 32 PRNs x 10 ms non-coherent, PRNs sharded over
@@ -34,6 +36,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md)
 FP64_PEAK_TFLOPS = 78.6  # MI355X vector fp64 datasheet peak (256 CUs x 4 SIMDs x 16 FMA lanes x 2 x 2.4 GHz)
 REALTIME_MSPS = 38.192
+PKG_NAME = os.environ.get("SGX_BENCH_PKG", "softgnss-python_amd")   # (the CPU test of the N > 1 plumbing names a stand-in)
 
 
 def parse():
@@ -67,7 +70,7 @@ def count_devices_in_child():
     """Number of HIP devices, asked in a child process: the launcher itself must stay clear of the GPU runtime
     (it goes on to start other programs)."""
     code = ("import importlib,sys; sys.path.insert(0, %r); "
-            "print(importlib.import_module('softgnss-python_amd')._native.device_count())" % ROOT)
+            "print(importlib.import_module(%r)._native.device_count())" % (ROOT, PKG_NAME))
     try:
         r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
         return int(r.stdout.decode().strip().splitlines()[-1])
@@ -90,15 +93,41 @@ def launch_ranks(n, argv):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode(errors="replace"))
-    sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        sys.stderr.write("[bench] ranks failed: %s\n" % bad)
-        return 1
-    return 0
+    # Watch ALL ranks: the first one that fails ends the others (they would wait for it at the next barrier), and
+    # nothing waits longer than the overall limit.
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("SGX_BENCH_TIMEOUT", "3600"))
+    codes = [None] * n
+    failed = False
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+        if any(c not in (None, 0) for c in codes) or time.time() > deadline:
+            failed = True
+            break
+        time.sleep(0.05)
+    if failed:
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                p.terminate()
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                try:
+                    codes[r] = p.wait(10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    codes[r] = p.wait()
+    reader.join(10)
+    if not failed:
+        sys.stdout.write((out0[0] if out0 else b"").decode(errors="replace"))
+        sys.stdout.flush()
+        return 0
+    sys.stderr.write("[bench] ranks failed or timed out (exit codes %s); the others were stopped\n" % codes)
+    return 1
 
 
 # ---- CPU baseline (numpy oracle; runs before this process touches the GPU) ---------------------------
@@ -249,6 +278,25 @@ def pmc_file(suffix, match):
     return best
 
 
+def trace_avg_ms(kernel_prefix):
+    """Average duration (ms) of a kernel in the newest committed `profiles/*_kernel_trace_stats.csv` (rocprofv3
+    --kernel-trace --stats of this command at its headline workload): the figure the live HIP-event time must agree with."""
+    pdir = os.path.join(ROOT, "profiles")
+    best = None
+    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if name.endswith("_kernel_trace_stats.csv"):
+            try:
+                with open(os.path.join(pdir, name)) as f:
+                    for line in f:
+                        if line.startswith('"') and kernel_prefix in line.split('"')[1]:
+                            cols = line.rsplit('"', 1)[1].split(",")
+                            best = (float(cols[3]) / 1e3, "profiles/" + name)
+                            break
+            except (OSError, ValueError, IndexError):
+                continue
+    return best
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -261,8 +309,9 @@ def main():
             args.gpus = world
         else:
             raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is 1" % args.gpus)
-    pkg = importlib.import_module("softgnss-python_amd")
+    pkg = importlib.import_module(PKG_NAME)
     shard = importlib.import_module("softgnss-python_amd.shard")
+    rendezvous = importlib.import_module("softgnss-python_amd.rendezvous")
 
     s = pkg.Settings()
     s.msToProcess = float(args.ms)
@@ -276,11 +325,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         cpu = leg("cpu_baseline", cpu_baseline, pkg, scene, n_code, args, float(rec_len), args.channels, args.ms)
 
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    group = rendezvous.HostGroup(rank, world)
     if pkg._native.device_count() < max(1, local + 1):
         raise SystemExit("bench.py needs an MI355X per rank (rank %d wants device %d): libsgx has no CPU path"
                          % (rank, local))
@@ -290,42 +335,25 @@ def main():
     gather = shard.LocalGather()
     if world > 1:
         try:
-            uid = [pkg._native.Comm.unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            gather = shard.RcclGather(pkg._native.Comm(ctx, world, rank, uid[0]))
+            uid = group.broadcast(pkg._native.Comm.unique_id() if rank == 0 else None)
+            gather = shard.RcclGather(pkg._native.Comm(ctx, world, rank, uid))
             gather.allgather(shard.pack_peaks([], dict(), 1))   # warm the communicator
         except Exception as e:   # flagged, never silent
             sys.stderr.write("[bench] rank %d: RCCL gather unavailable (%s); using host gather\n" % (rank, e))
-            gather = shard.HostGather(dist)
-        names = [None] * world
-        dist.all_gather_object(names, gather.name)
+            gather = shard.HostGather(group)
+        names = group.gather(gather.name)
         if len(set(names)) != 1:   # a mixed transport would deadlock: everybody falls back, and says so
-            gather = shard.HostGather(dist)
+            gather = shard.HostGather(group)
 
     # ---- synthetic record, generated in HBM (bit-identical to softgnss-python_amd/synth.py) --------
     rec = ctx.synth(scene, rec_len)
     signal = pkg.DeviceSignal(rec, 0, 11 * n_code)
 
     def device_sync():
-        ctx.sync()
-        try:
-            import torch
-            if torch.cuda.is_available():
-                torch.cuda.synchronize()
-        except ImportError:
-            pass
+        ctx.sync()   # everything this rank queued runs on its context's stream
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
-    def max_over_ranks(x):
-        if dist is None:
-            return x
-        import torch
-        t = torch.tensor([x], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t[0])
+    barrier = group.barrier
+    max_over_ranks = group.max
 
     # result buffers live in pinned host memory (the kernel writes its per-millisecond records straight into
     # them); pinning is slow, so the two buffers the steady state alternates between are created during setup
@@ -362,7 +390,12 @@ def main():
         acq_ms.append(last["acquire_ms"])
     device_sync()
     barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
+    elapsed_own = time.perf_counter() - t0
+    elapsed = max_over_ranks(elapsed_own)
+    # what every rank measured on its own GPU (rank 0 reports the extremes next to the max-over-ranks figure)
+    per_rank = group.gather({"rank": rank, "device": local, "step_ms": elapsed_own / args.steps * 1e3,
+                             "track_kernel_ms": float(np.mean(trk_kernel_ms)), "acquire_ms": float(np.mean(acq_ms)),
+                             "peak_gather": gather.name})
 
     # ---- BASELINE.json config 4: 32 PRNs x 10 ms non-coherent, PRNs sharded, RCCL gather included ----------
     cfg4 = None
@@ -421,6 +454,7 @@ def main():
 
     if rank == 0:
         traffic = pmc_file("_pmc_trk_kernel.json", {"channels": args.channels, "ms": args.ms})
+        prof_avg = trace_avg_ms("trk2_kernel") if (args.channels, args.ms) == (8, 37000) else None
         read_gbs, copy_gbs = ctx.stream_rates(1 << 30, 5)
         out = {
             "metric": "IF Msamples/s through acquisition + tracking (x real-time = value / 38.192)",
@@ -436,16 +470,21 @@ def main():
                        "peak_gather": gather.name},
             "acquire_ms": float(np.mean(acq_ms)), "track_kernel_ms": k_ms,
             "us_per_code_period": k_ms * 1e3 / args.ms,
+            "per_rank": {k: {"min": min(r[k] for r in per_rank), "max": max(r[k] for r in per_rank)}
+                         for k in ("step_ms", "track_kernel_ms", "acquire_ms")},
+            "per_rank_peak_gather": sorted(set(r["peak_gather"] for r in per_rank)),
             "roofline": {"kernel": "trk2_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic[0]["hbm_bytes_per_launch"] if traffic else None,
                          "traffic_source": (traffic[1] + " (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes of this "
                                             "command; FETCH_SIZE x2, gfx950 correction)") if traffic else None,
                          "algorithmic_bytes_per_launch": b_trk,
+                         "kernel_avg_ms": k_ms, "kernel_avg_ms_profile": prof_avg[0] if prof_avg else None,
+                         "kernel_avg_ms_profile_source": prof_avg[1] if prof_avg else None,
                          "measured_stream_read_gbs": read_gbs, "measured_stream_copy_gbs": copy_gbs,
                          "frac_of_measured_read": achieved / read_gbs,
-                         "note": "37 000 dependent steps per channel; 8 channels x 10 cooperating CUs = 80 of 256 "
-                                 "CUs busy: latency-bound, not bandwidth-bound (DESIGN.md section 4.1)"},
+                         "note": "37 000 dependent steps per channel; 8 channels x 10 units x 3 correlator arms = 240 of "
+                                 "256 CUs busy, each on a latency-bound chain: not bandwidth-bound (DESIGN.md section 4.1)"},
         }
         if cfg4 is not None:
             out["acq_config4"] = cfg4
@@ -460,9 +499,8 @@ def main():
             out["cpu_baseline"] = cpu
         print(json.dumps(out))
         sys.stdout.flush()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    group.barrier()
+    group.close()
     ctx.sync()
 
 

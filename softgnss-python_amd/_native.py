@@ -194,7 +194,7 @@ class _Pinned(object):
 
 
 _pinned_pool = []   # pinning is slow (ms per 30 MB): allocations whose arrays have died are reused
-_pinned_lock = threading.Lock()
+_pinned_lock = threading.RLock()   # re-entrant: a finalizer may run (cyclic GC) while pinned_empty() holds it
 
 
 def _pinned_release(own):

@@ -3,8 +3,9 @@
 Acquisition shards PRN indices, tracking shards channels; both are embarrassingly parallel.
 The only exchange on the path is the acquisition peak gather: every rank contributes
 (carrFreq, codePhase, peakMetric, freqBin, fineIdx) of its PRNs - 32 bytes per PRN - through
-one ncclAllGather issued by libsgx (RCCL over xGMI).  A host gather over torch.distributed
-(gloo) is provided for CPU tests and as a flagged fallback.
+one ncclAllGather issued by libsgx (RCCL over xGMI).  A host gather - over the ranks' socket
+rendezvous (rendezvous.HostGroup) or any object with torch.distributed's all_gather_object, e.g. the
+gloo backend in the CPU tests - is the flagged fallback.
 """
 import numpy as np
 
@@ -51,19 +52,18 @@ def merge_peaks(gathered):
 
 
 class HostGather(object):
-    """Peak gather over torch.distributed (gloo / any backend with CPU tensors)."""
-    name = "gloo-host"
+    """Peak gather through the host: `group` is a rendezvous.HostGroup, or anything else that offers
+    get_world_size() and all_gather_object(out_list, obj) (torch.distributed with a CPU backend does)."""
 
-    def __init__(self, dist):
-        self.dist = dist
+    def __init__(self, group):
+        self.group = group
+        self.name = getattr(group, "name", "host")
 
     def allgather(self, buf):
-        import torch
-        world = self.dist.get_world_size()
-        send = torch.from_numpy(np.ascontiguousarray(buf).view(np.uint8).copy())
-        recv = [torch.empty_like(send) for _ in range(world)]
-        self.dist.all_gather(recv, send)
-        return np.stack([r.numpy() for r in recv]).view(PEAK_DTYPE).reshape(world, -1)
+        world = self.group.get_world_size()
+        recv = [None] * world
+        self.group.all_gather_object(recv, np.ascontiguousarray(buf).view(np.uint8).tobytes())
+        return np.stack([np.frombuffer(r, dtype=np.uint8) for r in recv]).view(PEAK_DTYPE).reshape(world, -1)
 
 
 class RcclGather(object):

@@ -582,6 +582,8 @@ def main():
         if os.environ.get("SGX_GOLDEN_FIX", "1") == "1":
             golden_fix(tmp, initialize, acquisition, tracking)
 
+        golden_int16(tmp, initialize, acquisition, tracking)   # (part of the full run: every fixture is rewritten)
+
         trk2 = tracking.TrackingResult(acq_t)
         short = as_file(tmp, "short.bin", rec[:100 * n])
         with Quiet():

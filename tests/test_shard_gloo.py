@@ -143,3 +143,87 @@ def test_bench_launcher_starts_one_child_per_rank(tmp_path, monkeypatch):
     monkeypatch.setenv("FAIL_RANK", "2")
     assert bench.launch_ranks(3, []) == 1
     assert bench.launch_ranks(5, []) == 3   # more ranks than devices
+
+
+def _rdv_worker(rank, world, key, q):
+    sys.path.insert(0, ROOT)
+    rv = importlib.import_module("softgnss-python_amd.rendezvous")
+    g = rv.HostGroup(rank, world, key=key, timeout=60)
+    try:
+        got = g.gather({"rank": rank, "blob": bytes([rank]) * 1000})
+        g.barrier()
+        q.put((rank, [x["rank"] for x in got], g.max(10.0 + rank), g.broadcast("id" if rank == 0 else None),
+               all(x["blob"] == bytes([x["rank"]]) * 1000 for x in got)))
+    finally:
+        g.close()
+
+
+def test_socket_rendezvous_world_size_3():
+    """softgnss-python_amd/rendezvous.py: what bench.py uses between the ranks instead of torch.distributed."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    key = "t%d" % os.getpid()
+    procs = [ctx.Process(target=_rdv_worker, args=(r, 3, key, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=10) for _ in range(3))
+    assert [g[0] for g in got] == [0, 1, 2]
+    for g in got:
+        assert g[1] == [0, 1, 2] and g[2] == 12.0 and g[3] == "id" and g[4]
+
+
+def _stub_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["SGX_BENCH_PKG"] = "bench_stub"
+    env["PYTHONPATH"] = os.path.join(ROOT, "tests") + os.pathsep + env.get("PYTHONPATH", "")
+    return env
+
+
+def test_bench_two_ranks_end_to_end_against_a_stand_in_package():
+    """`bench.py --gpus 2` from the self-launch to the JSON line, with tests/bench_stub.py answering for the GPU
+    package: two ranks rendezvous, search 16 PRNs each, the RCCL transport is refused (the stand-in has none) so
+    both fall back to the host gather AND SAY SO, rank 0 reports the max over ranks, per-rank extremes and the
+    config-4 leg; PyTorch is never imported."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--ms", "50", "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=_stub_env(), timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["config"]["prns_per_gpu"] == 16 and d["config"]["peak_gather"] == "host-socket"
+    assert d["per_rank_peak_gather"] == ["host-socket"] and set(d["per_rank"]) == {"step_ms", "track_kernel_ms", "acquire_ms"}
+    assert d["per_rank"]["step_ms"]["max"] >= d["per_rank"]["step_ms"]["min"] > 0
+    assert abs(d["ms_per_step"] - d["per_rank"]["step_ms"]["max"]) < 1e-9          # the max over ranks is the figure
+    assert d["acq_config4"]["sharded_result_equals_single_gpu"] is True
+    assert d["value"] == pytest.approx(2 * d["config"]["record_samples"] / (d["ms_per_step"] * 1e-3) / 1e6)
+    assert b"using host gather" in r.stderr
+    # the same command under an external launcher's environment (one process, WORLD_SIZE=1) still prints its line
+    code = "import sys; sys.argv=['bench.py','--steps','1','--warmup','0','--ms','50','--no-cpu-baseline']; import runpy; " \
+           "runpy.run_path(%r, run_name='__main__'); assert 'torch' not in sys.modules" % os.path.join(ROOT, "bench.py")
+    r1 = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=_stub_env(),
+                        timeout=300)
+    assert r1.returncode == 0, r1.stderr.decode()
+    assert json.loads([ln for ln in r1.stdout.decode().splitlines() if ln.startswith("{")][0])["n_gpus"] == 1
+
+
+def test_bench_launcher_stops_the_other_ranks_when_one_dies():
+    """A rank that exits early (no device, RCCL failure) must not leave the others waiting at a barrier: the launcher
+    sees the first non-zero exit, stops the rest and returns non-zero - quickly, and without a JSON line."""
+    import subprocess
+    import time
+    env = _stub_env()
+    env["SGX_STUB_FAIL_RANK"] = "1"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--ms", "50", "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env,
+                       timeout=300)
+    assert r.returncode != 0 and b"n_gpus" not in r.stdout
+    assert b"ranks failed" in r.stderr and time.time() - t0 < 60
