@@ -5,6 +5,7 @@
 #include <stdlib.h>
 
 #include "sgx_internal.h"
+#include "sgx_trk_math.h"
 
 #define TRK_THREADS 256
 #define TRK_UNIT (TRK_THREADS * 16)          // samples per unit (a power of two)
@@ -117,7 +118,7 @@ __device__ __forceinline__ void ramp_setup(double start, double step, double inv
 __device__ __forceinline__ void prep_code(const TrkConst& K, double codeFreq, double rem, long long pos, TrkState& s,
                                           TrkBlock& b, bool writer) {
     const double step = div_rn(codeFreq, K.fs, K.inv_fs);                    // T1: codeFreq / fs
-    const int blk = (int)ceil((K.code_len - rem) / step);
+    const int blk = sgx_ceil_div(K.code_len - rem, step);                    // == (int)ceil((1023 - rem) / step), always
     const double nb = (double)blk;
     const double span = nb * step;                                           // blksize * codePhaseStep
     // T3: np.linspace(start, stop, blk, endpoint=False): delta = stop - start; stepL = delta / blk

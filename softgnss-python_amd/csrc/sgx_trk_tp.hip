@@ -7,14 +7,29 @@
 //   ends found with the exact reference arithmetic (estimate from 1/step plus two exact probes).  The prompt
 //   code is constant there, and the early and late ramps (spanning < 1 chip) switch at most once each, at
 //   eE and eL (normally the same sample, mid-chip).  So the lane's ~37 samples are a HEAD run [s0, e1) and a
-//   TAIL run [e2, s1) with all three codes constant in each: per sample only int8 -> fp64 and two FMAs into
-//   the run's accumulator (phasor table B_k in registers), no per-sample selects.  Bytes are fetched at
-//   dword alignment and realigned with v_alignbyte; bytes past a run's end are masked once per run.
-//   Runs are rotated by the run-start phasor (four small tables + one table lookup) and the code signs are
-//   applied once per lane.  A chip whose early and late switches differ (fp64 rounding exactly at a boundary)
-//   or whose runs exceed 20 samples takes an exact per-sample loop.
-//   ~320 instructions per 37 samples instead of ~300 per 16 in the group kernel.
+//   TAIL run [e2, s1) with all three codes constant in each, so a run needs sum_k x_k B_k only (B_k: the phasor of
+//   sample k of a run, a per-block table), rotated by the run-start phasor (four small tables + one table lookup),
+//   the code signs applied once per lane.
+//   THE SAMPLES ARE NEVER CONVERTED (round 3).  B_k 2^30 is rounded to an integer and written in four signed
+//   radix-256 digits; digit l of four consecutive k is one dword, so v_dot4_i32_i8 of a dword of the record with it
+//   adds four samples' products exactly: 8 dot products per 4 samples (4 digits x cos, sin) instead of 4 byte
+//   extractions, 4 conversions and 8 fp64 FMAs, and the 40 weight dwords live in registers for the whole block (no
+//   LDS read per sample).  The four int32 digit sums of a run are put together in fp64 (exact).  The table's
+//   rounding (2^-31 per entry, random in sign) moves a block's sums by ~1e-6 of 1e5: 1e-11 relative.
+//   Bytes are fetched at their byte address (the hardware takes unaligned loads); bytes past a run's end are masked
+//   once per run.  A chip whose early and late switches differ (fp64 rounding exactly at a boundary) or whose runs
+//   exceed 20 samples takes an exact per-sample loop.
 #include "sgx_trk_common.h"
+#include "sgx_trk_math.h"
+
+// Threads per workgroup (one channel) and workgroups per CU the register budget is cut for.  Measured on 2048 channels
+// x 500 ms: 256 x 2 13.8 ms; 256 x 3 (168 registers, spills) 15.3 ms; 128 x 4 (both waves busy in every phase) 15.4 ms.
+#ifndef TP_THREADS
+#define TP_THREADS 256
+#endif
+#ifndef TP_OCC
+#define TP_OCC 2
+#endif
 
 // first sample above thr from real arithmetic; `near` is raised when a sample lies within 1e-7 samples of the boundary
 __device__ __forceinline__ int tp_bound(double start, double inv_step, double thr, bool& near) {
@@ -25,11 +40,69 @@ __device__ __forceinline__ int tp_bound(double start, double inv_step, double th
     return (int)f + 1;
 }
 
-// 20 bytes starting at record byte `addr` (any alignment; the hardware takes unaligned 16-byte loads), bytes >= len
-// zeroed: five dwords
-__device__ __forceinline__ void load_run_u(const int8_t* __restrict__ rec, long long addr, long long limit, int len,
-                                           unsigned (&w)[5]) {
-    if (addr > limit) addr = limit;
+struct TpRamps {
+    double startE, stepE, startP, stepP, startL, stepL, inv_step;
+};
+struct TpChip {
+    int s0, s1, eE, eL;   // the chip's samples [s0, s1) and the early / late switch samples, clamped to s1
+};
+
+// Sample range of prompt chip c and the switch samples of the early and late ramps inside it.  Boundaries from one
+// multiply each, u = (thr - start) / step in real arithmetic: the reference's ramp fl(fl(i step) + start) lies within
+// 1e-11 samples of the real one, so floor(u) + 1 is the first sample above thr unless u is within 1e-7 of an integer -
+// then (any lane of the wave) the exact probes decide.
+__device__ __forceinline__ TpChip tp_chip_bounds(const TpRamps& R, int c, int c_first, int c_last, int blk) {
+    bool near = false;
+    int s0 = (c == c_first) ? 0 : tp_bound(R.startP, R.inv_step, (double)(c - 1), near);
+    int s1 = (c == c_last) ? blk : tp_bound(R.startP, R.inv_step, (double)c, near);
+    if (__builtin_expect(__any(near), 0)) {
+        s0 = (c == c_first) ? 0 : first_above(R.startP, R.stepP, R.inv_step, (double)(c - 1));
+        s1 = (c == c_last) ? blk : first_above(R.startP, R.stepP, R.inv_step, (double)c);
+    }
+    s0 = s0 < 0 ? 0 : s0;
+    s1 = s1 > blk ? blk : s1;
+    const int kE = (int)ceil(ramp_at(s0, R.stepE, R.startE));
+    const int kL = (int)ceil(ramp_at(s0, R.stepL, R.startL));
+    near = false;
+    int eE = tp_bound(R.startE, R.inv_step, (double)kE, near);
+    int eL = tp_bound(R.startL, R.inv_step, (double)kL, near);
+    if (__builtin_expect(__any(near), 0)) {
+        eE = first_above(R.startE, R.stepE, R.inv_step, (double)kE);
+        eL = first_above(R.startL, R.stepL, R.inv_step, (double)kL);
+    }
+    TpChip o;
+    o.s0 = s0;
+    o.s1 = s1;
+    o.eE = eE > s1 ? s1 : eE;
+    o.eL = eL > s1 ? s1 : eL;
+    return o;
+}
+
+// The same for a chip in the interior of the block when dllCorrelatorSpacing lies in [step, 1 - step]: at the chip's first
+// sample the early ramp's index is c - 1 and the late ramp's is c (tP in (c - 1, c - 1 + step] there), so all four
+// boundaries are floors of (thr - start) / step for known thresholds - no ramp evaluation, one guard for the four.
+// `ok` is cleared when a boundary lies within 1e-7 samples of a sample (the wave then takes tp_chip_bounds).
+__device__ __forceinline__ TpChip tp_chip_bounds_inner(const TpRamps& R, int c, int blk, bool& ok) {
+    const double cm1 = (double)(c - 1);
+    const double u0 = (cm1 - R.startP) * R.inv_step;
+    const double u1 = u0 + R.inv_step;                         // (c - startP) / step to 1e-12 samples
+    const double uE = (cm1 - R.startE) * R.inv_step;
+    const double uL = ((cm1 + 1.0) - R.startL) * R.inv_step;
+    const double f0 = floor(u0), f1 = floor(u1), fE = floor(uE), fL = floor(uL);
+    const double d0 = fabs((u0 - f0) - 0.5), d1 = fabs((u1 - f1) - 0.5), dE = fabs((uE - fE) - 0.5), dL = fabs((uL - fL) - 0.5);
+    ok = ok && fmax(fmax(d0, d1), fmax(dE, dL)) < 0.5 - 1e-7;
+    TpChip o;
+    const int s0 = (int)f0 + 1, s1 = (int)f1 + 1;
+    o.s0 = s0 < 0 ? 0 : (s0 > blk ? blk : s0);              // (never outside the block, whatever the parameters)
+    o.s1 = s1 < 0 ? 0 : (s1 > blk ? blk : s1);
+    const int eE = (int)fE + 1, eL = (int)fL + 1;
+    o.eE = eE > o.s1 ? o.s1 : eE;
+    o.eL = eL > o.s1 ? o.s1 : eL;
+    return o;
+}
+
+// 20 bytes starting at record byte `addr` (any alignment; the hardware takes unaligned 16-byte loads): five dwords
+__device__ __forceinline__ void tp_load_raw(const int8_t* __restrict__ rec, long long addr, unsigned (&w)[5]) {
     const U4a q = *reinterpret_cast<const U4a*>(rec + addr);
     const unsigned q4 = reinterpret_cast<const U2a*>(rec + addr + 16)->x;
     w[0] = q.x;
@@ -37,6 +110,10 @@ __device__ __forceinline__ void load_run_u(const int8_t* __restrict__ rec, long 
     w[2] = q.z;
     w[3] = q.w;
     w[4] = q4;
+}
+
+// bytes >= len zeroed
+__device__ __forceinline__ void tp_mask_run(int len, unsigned (&w)[5]) {
 #pragma unroll
     for (int d = 0; d < 5; ++d) {
         int keep = len - 4 * d;                      // bytes of this dword inside the run
@@ -45,7 +122,91 @@ __device__ __forceinline__ void load_run_u(const int8_t* __restrict__ rec, long 
     }
 }
 
-__global__ __launch_bounds__(TRK_THREADS, 3) void trk_kernel_tp(const int8_t* __restrict__ rec,
+// B_k 2^30 (k < 20) as four signed radix-256 digits, most significant first: lane = 20 comp + k
+__device__ __forceinline__ void tp_weight_digits(const TpCarr& t, signed char (&wq)[2][4][32], int lane) {
+    if (lane < 40) {
+        const int comp = lane / 20, k = lane - 20 * comp;
+        const double v = comp ? t.B[k].y : t.B[k].x;
+        int b = (int)rint(v * 1073741824.0);
+        const int d3 = (int)(signed char)(b & 0xFF);
+        b = (b - d3) >> 8;
+        const int d2 = (int)(signed char)(b & 0xFF);
+        b = (b - d2) >> 8;
+        const int d1 = (int)(signed char)(b & 0xFF);
+        b = (b - d1) >> 8;
+        wq[comp][0][k] = (signed char)b;
+        wq[comp][1][k] = (signed char)d1;
+        wq[comp][2][k] = (signed char)d2;
+        wq[comp][3][k] = (signed char)d3;
+    }
+}
+
+// the four digit sums of a run -> sum_k x_k B_k 2^30 (exact in fp64: < 2^45)
+__device__ __forceinline__ double tp_join(int a0, int a1, int a2, int a3) {
+    const int hi = a0 * 256 + a1, lo = a2 * 256 + a3;       // |a_l| < 20 * 127 * 128: both fit 32 bits
+    return __builtin_fma((double)hi, 65536.0, (double)lo);
+}
+
+__device__ __forceinline__ int tp_dot4_first(int x, int w) {
+    int d;
+    asm("v_dot4_i32_i8 %0, %1, %2, 0" : "=v"(d) : "v"(x), "v"(w));
+    return d;
+}
+
+// Head and tail run of a chip (bytes beyond the runs already zero): sum_k x_k B_k of each by int8 dot products against
+// the digit dwords, the runs rotated by their start phasors, the three codes applied.
+__device__ __forceinline__ void tp_runs(const signed char (&wq)[2][4][32], const TpCarr& car, double2 gh, int tail_off,
+                                        const unsigned (&wh)[5], const unsigned (&wt)[5], bool e_switched, bool l_switched,
+                                        double cP, double cEh, double cEn, double cLh, double cLn, double& aIE, double& aQE,
+                                        double& aIP, double& aQP, double& aIL, double& aQL) {
+    const double2 gt = cmul2(gh, car.B[tail_off]);
+    // weight dwords [cos, sin][digit][d]: dword d holds the digits of k = 4 d .. 4 d + 3 (broadcast LDS reads)
+    int hc[4], hs[4], tc[4], ts[4];
+    const int* w32 = reinterpret_cast<const int*>(&wq[0][0][0]);
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        const int4 wc = *reinterpret_cast<const int4*>(w32 + l * 8), ws = *reinterpret_cast<const int4*>(w32 + (4 + l) * 8);
+        const int wc4 = w32[l * 8 + 4], ws4 = w32[(4 + l) * 8 + 4];
+        // (the three-address form with a literal zero: the accumulating v_dot4c would want sixteen zeroed registers)
+        int a = tp_dot4_first((int)wh[0], wc.x);
+        int b = tp_dot4_first((int)wh[0], ws.x);
+        int e = tp_dot4_first((int)wt[0], wc.x);
+        int f = tp_dot4_first((int)wt[0], ws.x);
+        a = __builtin_amdgcn_sdot4((int)wh[1], wc.y, a, false);
+        b = __builtin_amdgcn_sdot4((int)wh[1], ws.y, b, false);
+        e = __builtin_amdgcn_sdot4((int)wt[1], wc.y, e, false);
+        f = __builtin_amdgcn_sdot4((int)wt[1], ws.y, f, false);
+        a = __builtin_amdgcn_sdot4((int)wh[2], wc.z, a, false);
+        b = __builtin_amdgcn_sdot4((int)wh[2], ws.z, b, false);
+        e = __builtin_amdgcn_sdot4((int)wt[2], wc.z, e, false);
+        f = __builtin_amdgcn_sdot4((int)wt[2], ws.z, f, false);
+        a = __builtin_amdgcn_sdot4((int)wh[3], wc.w, a, false);
+        b = __builtin_amdgcn_sdot4((int)wh[3], ws.w, b, false);
+        e = __builtin_amdgcn_sdot4((int)wt[3], wc.w, e, false);
+        f = __builtin_amdgcn_sdot4((int)wt[3], ws.w, f, false);
+        hc[l] = __builtin_amdgcn_sdot4((int)wh[4], wc4, a, false);
+        hs[l] = __builtin_amdgcn_sdot4((int)wh[4], ws4, b, false);
+        tc[l] = __builtin_amdgcn_sdot4((int)wt[4], wc4, e, false);
+        ts[l] = __builtin_amdgcn_sdot4((int)wt[4], ws4, f, false);
+    }
+    // (the 2^-30 of the digit scale rides on gh)
+    const double Hc = tp_join(hc[0], hc[1], hc[2], hc[3]), Hs = tp_join(hs[0], hs[1], hs[2], hs[3]);
+    const double Tc = tp_join(tc[0], tc[1], tc[2], tc[3]), Ts = tp_join(ts[0], ts[1], ts[2], ts[3]);
+    // rotate the runs by their start phasors: cos part -> Q, sin part -> I (tracking.py:205-207)
+    const double hQ = __builtin_fma(gh.x, Hc, -(gh.y * Hs)), hI = __builtin_fma(gh.y, Hc, gh.x * Hs);
+    const double tQ = __builtin_fma(gt.x, Tc, -(gt.y * Ts)), tI = __builtin_fma(gt.y, Tc, gt.x * Ts);
+    // code of the tail: switched iff the ramp's switch sample is the run boundary
+    const double cEt = e_switched ? cEn : cEh;
+    const double cLt = l_switched ? cLn : cLh;
+    aIE = __builtin_fma(cEt, tI, __builtin_fma(cEh, hI, aIE));
+    aQE = __builtin_fma(cEt, tQ, __builtin_fma(cEh, hQ, aQE));
+    aIP = __builtin_fma(cP, tI + hI, aIP);
+    aQP = __builtin_fma(cP, tQ + hQ, aQP);
+    aIL = __builtin_fma(cLt, tI, __builtin_fma(cLh, hI, aIL));
+    aQL = __builtin_fma(cLt, tQ, __builtin_fma(cLh, hQ, aQL));
+}
+
+__global__ __launch_bounds__(TP_THREADS, TP_OCC) void trk_kernel_tp(const int8_t* __restrict__ rec,
                                                                 const int8_t* __restrict__ codes,
                                                                 const TrkChan* __restrict__ chans,
                                                                 double* __restrict__ out, int* __restrict__ ms_done,
@@ -53,7 +214,8 @@ __global__ __launch_bounds__(TRK_THREADS, 3) void trk_kernel_tp(const int8_t* __
     __shared__ unsigned s_code_hi[1028];   // hi dword of +-1.0 for [c1022, c0..c1022, c0] (tracking.py:111)
     __shared__ TrkBlock s_blk;             // code part used; carrier part unused here
     __shared__ TpCarr s_car;
-    __shared__ double s_red[6][TRK_THREADS];
+    __shared__ __attribute__((aligned(16))) signed char s_wq[2][4][32];   // [cos, sin][digit, most significant first][k]: B_k 2^30 in radix 256
+    __shared__ double s_red[6][TP_THREADS];
     __shared__ double s_tot[6];
     __shared__ TrkState s_st;
 
@@ -66,7 +228,7 @@ __global__ __launch_bounds__(TRK_THREADS, 3) void trk_kernel_tp(const int8_t* __
         if (tid == 0) ms_done[ch] = 0;
         return;
     }
-    for (int i = tid; i < 1028; i += TRK_THREADS) {
+    for (int i = tid; i < 1028; i += TP_THREADS) {
         int j = i - 1;
         if (j < 0) j = 1022;
         if (j >= 1023) j -= 1023;
@@ -88,11 +250,12 @@ __global__ __launch_bounds__(TRK_THREADS, 3) void trk_kernel_tp(const int8_t* __
     if (wave == 0) {
         tp_tables(K, s_st.w, s_st.remCarr, s_car, lane, 0);
         tp_tables(K, s_st.w, s_st.remCarr, s_car, lane, 1);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        tp_weight_digits(s_car, s_wq, lane);
     }
     if (wave == 1) prep_code(K, s_st.codeFreq, s_st.remCode, s_st.pos, s_st, s_blk, lane == 0);
     __syncthreads();
 
-    const long long limit = K.rec_alloc - 24;
     double* __restrict__ o = out + (long long)ch * SGX_NUM_SERIES * K.ms;
     const long long m = K.ms;
     const double two_pi = 2 * M_PI;
@@ -109,93 +272,94 @@ __global__ __launch_bounds__(TRK_THREADS, 3) void trk_kernel_tp(const int8_t* __
         const int c_last = (int)ceil(ramp_at(blk - 1, stepP, startP));
 
         double aIE = 0.0, aQE = 0.0, aIP = 0.0, aQP = 0.0, aIL = 0.0, aQL = 0.0;
+        // A lane takes chips c_first + tid, + 256, ... (four or five per block).  The bytes of the NEXT chip are requested
+        // before the current one is worked on, so their latency hides behind ~200 instructions instead of stalling the
+        // wave in front of every chip.  (A lane without a next chip computes one for chip c_last: nothing is read beyond
+        // the block, no lane-dependent branch.)
+        const TpRamps R = {startE, stepE, startP, stepP, startL, stepL, inv_step};
+        // interior chips take the short boundary computation when the spacing allows it (see tp_chip_bounds_inner)
+        const bool inner_ok = (K.spacing >= stepP + 1e-6) && (K.spacing <= 1.0 - stepP - 1e-6);
+        auto bounds_of = [&](int cc_) -> TpChip {
+            bool ok = inner_ok && cc_ != c_first && cc_ != c_last;
+            TpChip o = tp_chip_bounds_inner(R, cc_, blk, ok);
+            if (__builtin_expect(!__all(ok), 0)) o = tp_chip_bounds(R, cc_, c_first, c_last, blk);
+            return o;
+        };
+        int c = c_first + tid;
+        bool have = c <= c_last;
+        TpChip cur = bounds_of(have ? c : c_last);
+        unsigned wh[5], wt[5];
+        tp_load_raw(rec, pos + cur.s0, wh);
+        tp_load_raw(rec, pos + (cur.eE > cur.eL ? cur.eE : cur.eL), wt);
 #pragma unroll 1
-        for (int c = c_first + tid; c <= c_last; c += TRK_THREADS) {
-            asm volatile("" ::: "memory");   // the slot phasors are re-read from LDS for every chip (80 registers otherwise)
-            // ---- the chip's sample range and the early / late switch samples (exact) ----
-            // boundaries from one multiply each, u = (thr - start) / step in real arithmetic: the reference's ramp
-            // fl(fl(i step) + start) lies within 1e-11 samples of the real one, so floor(u) + 1 is the first sample above
-            // thr unless u is within 1e-7 of an integer - then (any lane of the wave) the exact probes decide
-            bool near = false;
-            int s0 = (c == c_first) ? 0 : tp_bound(startP, inv_step, (double)(c - 1), near);
-            int s1 = (c == c_last) ? blk : tp_bound(startP, inv_step, (double)c, near);
-            if (__builtin_expect(__any(near), 0)) {
-                s0 = (c == c_first) ? 0 : first_above(startP, stepP, inv_step, (double)(c - 1));
-                s1 = (c == c_last) ? blk : first_above(startP, stepP, inv_step, (double)c);
-            }
-            s0 = s0 < 0 ? 0 : s0;
-            s1 = s1 > blk ? blk : s1;
-            const int kE = (int)ceil(ramp_at(s0, stepE, startE));
-            const int kL = (int)ceil(ramp_at(s0, stepL, startL));
-            near = false;
-            int eE = tp_bound(startE, inv_step, (double)kE, near);
-            int eL = tp_bound(startL, inv_step, (double)kL, near);
-            if (__builtin_expect(__any(near), 0)) {
-                eE = first_above(startE, stepE, inv_step, (double)kE);
-                eL = first_above(startL, stepL, inv_step, (double)kL);
-            }
-            eE = eE > s1 ? s1 : eE;
-            eL = eL > s1 ? s1 : eL;
+        while (have) {
+            const int cn = c + TP_THREADS;
+            const bool have_n = cn <= c_last;
+            const TpChip nxt = bounds_of(have_n ? cn : c);   // (no next chip: the current one again - an interior chip, no branch)
+            unsigned nh[5], nt[5];
+            tp_load_raw(rec, pos + nxt.s0, nh);
+            tp_load_raw(rec, pos + (nxt.eE > nxt.eL ? nxt.eE : nxt.eL), nt);
+            asm volatile("" ::: "memory");   // the weight dwords are re-read from LDS for every chip (40 registers otherwise)
+            const int s0 = cur.s0, s1 = cur.s1, eE = cur.eE, eL = cur.eL;
             const int e1 = eE < eL ? eE : eL, e2 = eE < eL ? eL : eE;
             const int len_h = e1 - s0, len_t = s1 - e2;
+            const int kE = (int)ceil(ramp_at(s0, stepE, startE));
+            const int kL = (int)ceil(ramp_at(s0, stepL, startL));
             const double cP = __hiloint2double((int)s_code_hi[c], 0);
             const double cEh = __hiloint2double((int)s_code_hi[kE], 0), cEn = __hiloint2double((int)s_code_hi[kE + 1], 0);
             const double cLh = __hiloint2double((int)s_code_hi[kL], 0), cLn = __hiloint2double((int)s_code_hi[kL + 1], 0);
             // run-start phasor of the head from the four tables
             const double2 gh = cmul2(cmul2(s_car.W3[s0 >> 12], s_car.W2[(s0 >> 8) & 15]),
                                      cmul2(s_car.W1[(s0 >> 4) & 15], s_car.B[s0 & 15]));
-            const bool odd = (s1 > s0) && (e2 != e1 || len_h > TP_RUN || len_t > TP_RUN || e2 - s0 > 31);
-            if (__builtin_expect(__any(odd), 0)) {
-                // exact per-sample loop over the chip (rare)
-                if (s1 > s0) {
-                    double2 ph = gh;
-                    const double2 b1 = s_car.B[1];
-                    for (int i = s0; i < s1; ++i) {
-                        long long a = pos + i;
-                        const double xd = (double)(int)rec[a > K.rec_alloc - 1 ? K.rec_alloc - 1 : a];
-                        const double xs = ph.y * xd, xc = ph.x * xd;
-                        const double cE = i >= eE ? cEn : cEh;
-                        const double cL = i >= eL ? cLn : cLh;
-                        aIE = __builtin_fma(cE, xs, aIE);
-                        aQE = __builtin_fma(cE, xc, aQE);
-                        aIP = __builtin_fma(cP, xs, aIP);
-                        aQP = __builtin_fma(cP, xc, aQP);
-                        aIL = __builtin_fma(cL, xs, aIL);
-                        aQL = __builtin_fma(cL, xc, aQL);
-                        ph = cmul2(ph, b1);
+            const double q30 = 9.3132257461547852e-10;   // 2^-30: the scale of the weight digits
+            const double2 ghq = make_double2(gh.x * q30, gh.y * q30);
+            // the usual chip: early and late switch at the same sample, both runs 17..20 samples long: only the fifth
+            // dword of a run has bytes to mask
+            const bool usual = (e1 == e2) && ((unsigned)(len_h - 17) <= 3u) && ((unsigned)(len_t - 17) <= 3u);
+            bool by_runs = true;
+            if (__builtin_expect(__all(usual), 1)) {
+                wh[4] &= 0xFFFFFFFFu >> (8 * (20 - len_h));
+                wt[4] &= 0xFFFFFFFFu >> (8 * (20 - len_t));
+            } else {
+                const bool odd = (s1 > s0) && (e2 != e1 || len_h > TP_RUN || len_t > TP_RUN || e2 - s0 > 31);
+                if (__any(odd)) {
+                    // exact per-sample loop over the chip (rare)
+                    by_runs = false;
+                    if (s1 > s0) {
+                        double2 ph = gh;
+                        const double2 b1 = s_car.B[1];
+                        for (int i = s0; i < s1; ++i) {
+                            long long a = pos + i;
+                            const double xd = (double)(int)rec[a > K.rec_alloc - 1 ? K.rec_alloc - 1 : a];
+                            const double xs = ph.y * xd, xc = ph.x * xd;
+                            const double cE = i >= eE ? cEn : cEh;
+                            const double cL = i >= eL ? cLn : cLh;
+                            aIE = __builtin_fma(cE, xs, aIE);
+                            aQE = __builtin_fma(cE, xc, aQE);
+                            aIP = __builtin_fma(cP, xs, aIP);
+                            aQP = __builtin_fma(cP, xc, aQP);
+                            aIL = __builtin_fma(cL, xs, aIL);
+                            aQL = __builtin_fma(cL, xc, aQL);
+                            ph = cmul2(ph, b1);
+                        }
                     }
+                } else {
+                    // short or empty runs (the block's first and last chip): every dword masked (a lane without samples
+                    // masks everything)
+                    tp_mask_run(s1 > s0 ? len_h : 0, wh);
+                    tp_mask_run(s1 > s0 ? len_t : 0, wt);
                 }
-            } else if (s1 > s0) {
-                unsigned wh[5], wt[5];
-                load_run_u(rec, pos + s0, limit, len_h, wh);
-                load_run_u(rec, pos + e2, limit, len_t, wt);
-                const double2 gt = cmul2(gh, s_car.B[e2 - s0]);
-                double Hc = 0.0, Hs = 0.0, Tc = 0.0, Ts = 0.0;
-#pragma unroll
-                for (int k = 0; k < TP_RUN; ++k) {
-                    const unsigned a = wh[k >> 2], b = wt[k >> 2];
-                    const int xh = ((k & 3) == 3) ? ((int)a >> 24) : (int)(signed char)((a >> (8 * (k & 3))) & 0xFF);
-                    const int xt = ((k & 3) == 3) ? ((int)b >> 24) : (int)(signed char)((b >> (8 * (k & 3))) & 0xFF);
-                    const double dh = (double)xh, dt = (double)xt;
-                    const double2 Bk = s_car.B[k];
-                    Hc = __builtin_fma(dh, Bk.x, Hc);
-                    Hs = __builtin_fma(dh, Bk.y, Hs);
-                    Tc = __builtin_fma(dt, Bk.x, Tc);
-                    Ts = __builtin_fma(dt, Bk.y, Ts);
-                }
-                // rotate the runs by their start phasors: cos part -> Q, sin part -> I (tracking.py:205-207)
-                const double hQ = __builtin_fma(gh.x, Hc, -(gh.y * Hs)), hI = __builtin_fma(gh.y, Hc, gh.x * Hs);
-                const double tQ = __builtin_fma(gt.x, Tc, -(gt.y * Ts)), tI = __builtin_fma(gt.y, Tc, gt.x * Ts);
-                // code of the tail: switched iff the ramp's switch sample is the run boundary
-                const double cEt = (eE <= e2) ? cEn : cEh;
-                const double cLt = (eL <= e2) ? cLn : cLh;
-                aIE = __builtin_fma(cEt, tI, __builtin_fma(cEh, hI, aIE));
-                aQE = __builtin_fma(cEt, tQ, __builtin_fma(cEh, hQ, aQE));
-                aIP = __builtin_fma(cP, tI + hI, aIP);
-                aQP = __builtin_fma(cP, tQ + hQ, aQP);
-                aIL = __builtin_fma(cLt, tI, __builtin_fma(cLh, hI, aIL));
-                aQL = __builtin_fma(cLt, tQ, __builtin_fma(cLh, hQ, aQL));
             }
+            if (by_runs)
+                tp_runs(s_wq, s_car, ghq, (e2 - s0) & 31, wh, wt, eE <= e2, eL <= e2, cP, cEh, cEn, cLh, cLn, aIE, aQE, aIP, aQP, aIL, aQL);
+            cur = nxt;
+#pragma unroll
+            for (int d = 0; d < 5; ++d) {
+                wh[d] = nh[d];
+                wt[d] = nt[d];
+            }
+            c = cn;
+            have = have_n;
         }
         s_red[0][tid] = aIE;
         s_red[1][tid] = aQE;
@@ -204,12 +368,13 @@ __global__ __launch_bounds__(TRK_THREADS, 3) void trk_kernel_tp(const int8_t* __
         s_red[4][tid] = aIL;
         s_red[5][tid] = aQL;
         __syncthreads();
-        if (wave < 3) {
-            const int v = 2 * wave + (lane >> 5), l = lane & 31;
+        if (tid < 96) {
+            // sum v = tid / 16 is folded by a row of 16 lanes: fixed order (deterministic), then a DPP row sum
+            const int v = tid >> 4, l = tid & 15;
             double acc = s_red[v][l];
 #pragma unroll
-            for (int k = 1; k < TRK_THREADS / 32; ++k) acc += s_red[v][l + 32 * k];
-            acc = half_wave_sum(acc, lane);
+            for (int k = 1; k < TP_THREADS / 16; ++k) acc += s_red[v][l + 16 * k];
+            acc = row_sum(acc);
             if (l == 0) s_tot[v] = acc;
         }
         __syncthreads();
@@ -223,13 +388,15 @@ __global__ __launch_bounds__(TRK_THREADS, 3) void trk_kernel_tp(const int8_t* __
             double rc = __builtin_fma(-kq, two_pi, arg_end);
             if (rc < 0.0) rc += two_pi;
             if (rc >= two_pi) rc -= two_pi;
-            const double carrError = div_rn(atan(Q_P / I_P) / 2.0, M_PI, K.inv_pi);
+            const double carrError = sgx_atan_ratio(Q_P, I_P) * K.inv_2pi;   // atan(Q/I) / 2 / pi to 1.5 ulp (sgx_trk_math.h)
             const double carrNco = oldNco + K.k_carr_a * (carrError - oldErr) + carrError * K.k_carr_b;
             const double carrFreq = basis + carrNco;
             const double w_new = (carrFreq * 2.0) * M_PI;
             if (more) {
                 tp_tables(K, w_new, rc, s_car, lane, 0);
                 tp_tables(K, w_new, rc, s_car, lane, 1);
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                tp_weight_digits(s_car, s_wq, lane);
             }
             if (lane == 0) {
                 s_st.w = w_new;
@@ -253,9 +420,9 @@ __global__ __launch_bounds__(TRK_THREADS, 3) void trk_kernel_tp(const int8_t* __
             const double oldNco = s_st.oldCodeNco, oldErr = s_st.oldCodeErr;
             const long long pos_after = s_st.pos;
             const double rem_next = s_st.remCode;
-            const double eE = sqrt(I_E * I_E + Q_E * Q_E);
-            const double eL = sqrt(I_L * I_L + Q_L * Q_L);
-            const double codeError = (eE - eL) / (eE + eL);
+            const double eE = sgx_sqrt1(I_E * I_E + Q_E * Q_E);      // (<= 1 ulp each: sgx_trk_math.h)
+            const double eL = sgx_sqrt1(I_L * I_L + Q_L * Q_L);
+            const double codeError = sgx_div1(eE - eL, eE + eL);
             const double codeNco = oldNco + K.k_code_a * (codeError - oldErr) + codeError * K.k_code_b;
             const double codeFreq = K.code_basis - codeNco;
             if (lane == 0) {
@@ -281,6 +448,6 @@ void sgx_trk_tp_launch(int n_blocks, hipStream_t st, const int8_t* rec, const in
     (void)prof;
     (void)xch;
     (void)err;
-    trk_kernel_tp<<<K.n_ch, TRK_THREADS, 0, st>>>(rec, codes, (const TrkChan*)chans, out, done, K);
+    trk_kernel_tp<<<K.n_ch, TP_THREADS, 0, st>>>(rec, codes, (const TrkChan*)chans, out, done, K);
     (void)n_blocks;
 }
