@@ -1,46 +1,21 @@
-// TrackingResult.track on gfx950 (reference tracking.py:13-295).
+// TrackingResult.track on gfx950 (reference tracking.py:13-295): the host side.
 //
-// A channel is a chain of `ms` dependent 1-ms steps: every block's length, code ramps and NCO rates
-// depend on the previous block's six correlator sums.  Channels are independent.  The kernel is
-// persistent: one launch walks all code periods of all channels.
+// A channel is a chain of `ms` dependent 1-ms steps: every block's length, code ramps and NCO rates depend on the
+// previous block's six correlator sums.  Channels are independent.  Every kernel is persistent: one launch walks all
+// code periods of all channels.  A block (~38 192 samples) is cut into UNITS of 256 groups x 16 samples (4 KiB of IF).
 //
-// Work decomposition
-//   * a block (~38 192 samples) is cut into UNITS of 256 groups x 16 samples (4 KiB of IF);
-//   * `split` workgroups of 256 threads (4 waves, one per SIMD of a CU) cooperate on one channel,
-//     member c takes units c, c+split, ...; split = 1 keeps a channel on one CU (throughput mode,
-//     many channels), split = 10 spreads a channel over ten CUs of one XCD (few channels, latency mode);
-//   * members exchange their six partial sums once per block through HBM/L2 as tagged 8-byte granules
-//     (write-through stores, relaxed agent-scope polls, epoch tags, double-buffered by epoch parity,
-//     bounded spins) and then every member runs the loop filter redundantly, so the next block's
-//     parameters need no broadcast.  Nothing depends on which CU or XCD a member lands on.
-//
-// Per block (one loop iteration)
-//   map     every lane takes 16 consecutive int8 samples of a unit as ONE aligned 16-byte load (a wave
-//           reads 1 KiB contiguous); the load of the lane's next unit (or the next block's first unit)
-//           is issued before the current one is processed, so HBM latency hides behind arithmetic.
-//           * code replicas: the three linspace ramps t = fl(fl(i*step)+start) are monotonic and move
-//             0.43 chip over 16 samples, so a group holds at most ONE chip switch (prompt at integer t,
-//             early/late together at half-integer t).  Chip index at the group's first sample and the
-//             switch sample come from the exact reference arithmetic (an estimate plus two exact
-//             probes), which keeps the indices bit-identical to code[int64(ceil(linspace(...)))].
-//           * carrier: sample b of a group has phasor G*B_b, G = the lane's group-start phasor (fp64
-//             "turns" reduction + one sincospi per block, then a rotation per further unit) and
-//             B_b = exp(j b delta), a 16-entry per-block table held in registers.  The lane accumulates
-//             sum x_b B_b over the group and over the samples after the switch (5 fp64 ops per sample),
-//             then applies G and the code signs once per group.
-//           * a group in which early and late switch at different samples (fp64 rounding at a chip
-//             boundary) falls back to an exact per-sample loop.
-//   reduce  six fp64 partials per lane -> LDS transpose -> 3 waves fold them (DPP) -> exchange.
-//   filter  wave 0 runs the PLL and prepares the carrier parameters while wave 1 runs the DLL and
-//           prepares block size and code ramps, both with the reference's fp64 operation order
-//           (-ffp-contract=off; fused multiply-adds only where written as __builtin_fma).
-// fp64 everywhere: 1e-7 errors in the sums move the code NCO enough to flip a chip-boundary sample
-// somewhere in a 37 s run, which is a 1e-3 relative blip.
+// Three kernels, chosen here:
+//   trk2_kernel     (sgx_trk2.hip) - the latency-mode kernel, every cooperative case and its own fallback: P members per
+//                   channel, member m owns units m, m + P, ...  P = units (one workgroup per unit - or, when three times
+//                   as many CUs are free, one per unit and correlator arm) while the CUs last, fewer members with
+//                   several units each for more channels, P = 1 (no co-residency needed) when a cooperative launch
+//                   timed out or the CUs are taken.  int8 and int16 records, resident or still streaming in.
+//   trk_kernel_tp   (sgx_trk_tp.hip) - throughput mode: more than 128 int8 channels, one workgroup per channel.
+//   trk_kernel_multi (sgx_trk_multi.hip) - sampling rates below ~15.4 samples per chip, where a 16-sample group can hold
+//                   several chip switches of one ramp (per-sample replica lookup; the round-1 cooperative body).
+// fp64 everywhere: 1e-7 errors in the sums move the code NCO enough to flip a chip-boundary sample somewhere in a 37 s
+// run, which is a 1e-3 relative blip.
 #include "sgx_trk_common.h"
-
-#define TRK_KERNEL_NAME trk_kernel
-#define TRK_MINW 1
-#include "sgx_trk_kernel.inc"
 
 // sgx_trk_tp.hip: throughput-mode kernel (one lane per prompt chip, two workgroups per CU) for split == 1, > 128 channels
 void sgx_trk_tp_launch(int n_blocks, hipStream_t st, const int8_t* rec, const int8_t* codes, const void* chans,
@@ -115,23 +90,24 @@ static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
     K.file_off = rec_file_offset;
     K.ms = ms;
     K.n_ch = n_ch;
+    int cus_total = 0;
+    SGX_HIP(hipDeviceGetAttribute(&cus_total, hipDeviceAttributeMultiprocessorCount, c->device));
+    const int ch8 = ((n_ch + 7) / 8) * 8;
     {
-        // cooperating workgroups per channel: one 256-thread workgroup per CU, all of a launch must be
-        // resident at once (they wait for each other), so split * n_ch <= CU count
-        int cus = 0;
-        SGX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
         // units needed by the longest possible block, worst alignment.  A block is samplesPerCode +- 1 samples long
         // while the code NCO stays near its basis; the allowance of 64 samples corresponds to a code-rate error of
         // 0.17 % (1.7 kHz at 1.023 MHz), three orders of magnitude beyond what the DLL's filter can command.
         K.n_units = (int)((c->n_code + 64 + 15 + 15) / 16 + TRK_THREADS - 1) / TRK_THREADS;
-        int split = cus / (n_ch > 0 ? ((n_ch + 7) / 8) * 8 : 8);
-        if (split > TRK_MAX_SPLIT) split = TRK_MAX_SPLIT;
         if (K.n_units > 16) {
             sgx_set_error("samplesPerCode %lld needs %d units, the tracking kernel holds 16", (long long)c->n_code,
                           K.n_units);
             return SGX_E_ARG;
         }
+        // members (cooperating workgroups) per channel: one workgroup per CU, all of a cooperative launch must be
+        // resident at once (they wait for each other), so members * channels <= CU count
+        int split = cus_total / ch8;
         if (split > K.n_units) split = K.n_units;
+        if (K.multi && split > TRK_MAX_SPLIT) split = TRK_MAX_SPLIT;
         if (split < 1) split = 1;
         const char* se = getenv("SGX_TRK_SPLIT");
         if (se && atoi(se) >= 1 && atoi(se) <= split) split = atoi(se);
@@ -215,21 +191,21 @@ static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
     const char* pe = getenv("SGX_TRK_PROFILE");
     const bool want_prof = pe && pe[0] == '1';
     long long* d_prof = want_prof ? (long long*)(aux + sz_ch + sz_done + sz_xch + 256) : nullptr;
-    // The latency-mode kernel (sgx_trk2.hip) gives every member exactly one unit: it runs when the CUs allow one
-    // workgroup per (channel, unit) - and with one workgroup per (channel, unit, correlator arm) when they allow three
-    // times as many (SGX_TRK_ARMS=3 keeps one workgroup per unit).  SGX_TRK_V1=1 (or an explicit SGX_TRK_SPLIT) keeps
-    // the round-1 cooperative kernel.
-    const char* v1 = getenv("SGX_TRK_V1");
-    int cus_total = 0;
-    SGX_HIP(hipDeviceGetAttribute(&cus_total, hipDeviceAttributeMultiprocessorCount, c->device));
-    const int ch8 = ((n_ch + 7) / 8) * 8;
-    bool use_v2 = !(v1 && v1[0] == '1') && !getenv("SGX_TRK_SPLIT") && !K.multi && K.n_units >= 2 && K.n_units <= T2_MAXP &&
-                  ch8 * K.n_units <= cus_total;
+    // Which kernel: the low-rate variant when a group can hold several switches of a ramp; throughput mode for more
+    // than 128 int8 channels (one workgroup per channel anyway); the latency-mode kernel otherwise - with one workgroup
+    // per (unit, correlator arm) when three times the CUs of one-per-unit are free (SGX_TRK_ARMS=3 keeps one per unit).
+    if (K.multi && sample_bytes != 1) {
+        sgx_set_error("two-byte samples need samplingFreq >= 16 x the chip rate (the low-rate kernel reads int8 records)");
+        return SGX_E_ARG;
+    }
+    const bool use_tp = !K.multi && sample_bytes == 1 && K.split == 1 && n_ch > 128;
+    const bool use_v2 = !K.multi && !use_tp;
     const char* ae = getenv("SGX_TRK_ARMS");
-    const bool arm_split = use_v2 && 3 * ch8 * K.n_units <= cus_total && !(ae && ae[0] == '3');
+    const bool arm_split = use_v2 && K.split == K.n_units && K.n_units >= 2 && 3 * ch8 * K.n_units <= cus_total &&
+                           !getenv("SGX_TRK_SPLIT") && !(ae && ae[0] == '3');
     const char* le = getenv("SGX_TRK_LDSPAD");   // dynamic LDS per workgroup (bytes); default: one workgroup per CU
-    const int lds_pad = le ? atoi(le) : 90112;
-    const int split_v1 = K.split;
+    const int lds_pad_coop = le ? atoi(le) : 90112;
+    const int split0 = K.split;
     // CUs claimed by a cooperative launch; given back on EVERY way out of this function
     struct CuGuard {
         int device, n;
@@ -251,45 +227,27 @@ static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
         SGX_HIP(hipMemsetAsync(aux + sz_ch, 0, sz_done + sz_xch + 256, st));   // done, every polled word, err
         if (!direct) trk_fill_kernel<<<(unsigned)((elems + 255) / 256), 256, 0, st>>>(d_out, ms, (long long)elems);
         // a record that is still streaming in is followed by the latency-mode kernel (its record wave watches the
-        // device watermark); the other kernels, and a repeated launch, first wait for the whole record
+        // device watermark); the other kernels, and a launch repeated on the resident record, first wait for all of it
         const char* se2 = getenv("SGX_TRK_STREAM");
-        const bool v2 = use_v2 && (attempt == 0 || retry_resident);
+        const bool v2 = use_v2;
         const bool want_stream = r->loader && !r->load_done.load() && attempt == 0 && !(se2 && se2[0] == '0') && v2;
-        const int arms = (v2 && arm_split) ? 1 : 3;
-        if (attempt == 0) K.split = v2 ? K.n_units : split_v1;
-        const int members = K.split * (arms == 1 ? 3 : 1);      // workgroups per channel
-        if (sample_bytes != 1 && !(v2 && K.split > 1)) {
-            if (attempt == 1)
-                sgx_set_error("tracking: channel %d timed out waiting for a cooperating workgroup; two-byte samples have "
-                              "no one-workgroup-per-channel kernel to fall back to", (h_err & 0xFFFF) - 1);
-            else
-                sgx_set_error("two-byte samples are tracked by the one-unit-per-workgroup kernel only: it needs %d free CUs "
-                              "(%d channels x %d units) and samplingFreq >= 16 x the chip rate", ch8 * K.n_units, ch8, K.n_units);
-            return attempt == 1 ? SGX_E_HIP : SGX_E_ARG;
-        }
+        if (attempt == 0 || retry_resident) K.split = split0;
+        else K.split = 1;                                        // a member timed out: no co-residency needed with one
+        int arms_now = (v2 && arm_split && K.split > 1) ? 1 : 3;
         // Cooperating workgroups wait for each other, so all of a launch must be resident at once: one workgroup per CU
         // out of a per-device budget shared by every context of this process (a launch that does not fit the CUs left
         // by the others runs with one workgroup per channel, which needs no co-residency).
-        int arms_now = arms;
         if (K.split > 1) {
-            reserved.n = sgx_cu_reserve(c->device, cus_total, ch8 * members);
-            if (reserved.n == 0 && arms == 1) {
+            reserved.n = sgx_cu_reserve(c->device, cus_total, ch8 * K.split * (arms_now == 1 ? 3 : 1));
+            if (reserved.n == 0 && arms_now == 1) {
                 arms_now = 3;                                    // the CUs left may still hold one workgroup per unit
                 reserved.n = sgx_cu_reserve(c->device, cus_total, ch8 * K.split);
             }
-            if (reserved.n == 0) {
-                if (sample_bytes != 1) {
-                    sgx_set_error("two-byte samples are tracked by the one-unit-per-workgroup kernel only: it needs %d free "
-                                  "CUs (%d channels x %d units), other launches of this process hold them", ch8 * K.n_units,
-                                  ch8, K.n_units);
-                    return SGX_E_ARG;
-                }
-                K.split = 1;
-            }
+            if (reserved.n == 0) K.split = 1;
         }
         const int members_now = K.split * ((v2 && K.split > 1 && arms_now == 1) ? 3 : 1);
         const int n_blocks = ch8 * members_now;
-        const bool streaming = want_stream && K.split > 1;
+        const bool streaming = want_stream;
         if (!streaming) {
             const int rq = sgx_if_require(r, r->n);
             if (rq != SGX_OK) return rq;
@@ -297,26 +255,24 @@ static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
         K.mark = streaming ? r->d_mark : nullptr;
         if (want_prof) SGX_HIP(hipMemsetAsync(d_prof, 0, sz_prof, st));
         hipEventRecord(c->ev[3], st);
-        if (v2 && K.split > 1) {
+        if (v2) {
             const char* wh = getenv("SGX_TRK_TEST_WITHHOLD");   // test hook: launch without each channel's last member
-            const int nb2 = (wh && wh[0] == '1') ? n_blocks - 8 : n_blocks;
+            const int nb2 = (wh && wh[0] == '1' && K.split > 1) ? n_blocks - 8 : n_blocks;
+            // (one workgroup per CU only matters while members wait for each other)
             sgx_trk2_launch(nb2, st, r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err, sample_bytes, arms_now,
-                            lds_pad);
+                            K.split > 1 ? lds_pad_coop : 0);
             used_v2 = true;
             used_members = members_now;
             c->timing.track_kernel = 2.f;
         }
-        else if (K.split == 1 && n_ch > 128) {   // (general in the sampling rate: one lane per prompt chip)
+        else if (use_tp) {   // (one lane per prompt chip)
             sgx_trk_tp_launch(n_blocks, st, r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err);
             c->timing.track_kernel = 3.f;
-        } else if (K.multi) {
-            sgx_trk_multi_launch(n_blocks, st, r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err);
-            c->timing.track_kernel = 4.f;
         } else {
-            c->timing.track_kernel = 1.f;
-            const char* wh = getenv("SGX_TRK_TEST_WITHHOLD");   // (the same test hook for the round-1 cooperative kernel)
+            const char* wh = getenv("SGX_TRK_TEST_WITHHOLD");   // (the same test hook for the low-rate cooperative kernel)
             const int nb1 = (wh && wh[0] == '1' && K.split > 1) ? n_blocks - 8 : n_blocks;
-            trk_kernel<<<nb1, TRK_THREADS, 0, st>>>(r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err);
+            sgx_trk_multi_launch(nb1, st, r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err);
+            c->timing.track_kernel = 4.f;
         }
         hipEventRecord(c->ev[4], st);
         c->timing.track_members = (float)members_now;

@@ -64,6 +64,14 @@
 // fixed-point scale and the reported file position (bytes, tracking.py:107 / fid.tell(), tracking.py:255) depend on it.
 template <int SB>
 __device__ __forceinline__ constexpr double t2_fix() { return SB == 1 ? T2_FIX : T2_FIX16; }
+// ... when a member owns ceil(n_units / P) units its sum can be that many times larger: the scale drops by the next
+// power of two (exact), so the 48-bit payload still holds it
+template <int SB>
+__device__ __forceinline__ double t2_fix_of(int P, int n_units) {
+    const int u = (n_units + P - 1) / P;
+    const int sh = (u <= 1) ? 0 : (32 - __builtin_clz((unsigned)(u - 1)));
+    return __hiloint2double(__double2hiint(t2_fix<SB>()) - (sh << 20), 0);
+}
 #define T2_MAGIC 6755399441055744.0   // 1.5 * 2^52: fl(x + MAGIC) holds round(x) in its low mantissa bits
 #define T2_POLL_BUDGET (1 << 20)
 
@@ -114,10 +122,11 @@ struct __attribute__((aligned(128))) T2Code {   // code side of a block's parame
 };
 
 struct T2Carr {   // carrier side (PLL wave -> map waves), double-buffered: (cos, sin)(2 pi r m), r = turns per sample
-    double2 T[52];    // [0..15]  B:  m = b         sample b of a group
+    double2 T[64];    // [0..15]  B:  m = b         sample b of a group
                       // [16..31] W1: m = 16 a      group a = tid & 15
                       // [32..47] W2: m = 256 b     group row b = tid >> 4
-                      // [48]     W3: first sample of this member's unit (4096 u - head), plus the block's start phase
+                      // [48 + j] W3: first sample of this member's j-th unit (4096 (u + j P) - head), plus the block's
+                      //              start phase
 };
 #define T2_B 0
 #define T2_W1 16
@@ -204,9 +213,9 @@ __device__ __forceinline__ void ramp_locate(double start, double step, double in
 
 // ---- carrier tables (T5): entry `lane` of B | W1 | W2 | W3 (lanes 48..63 all hold this member's W3) ----
 // table index multiplier: the entry is the phasor of sample m of the block
-__device__ __forceinline__ int t2_carr_mult(int lane, int unit, int head) {
+__device__ __forceinline__ int t2_carr_mult(int lane, int unit, int P, int head) {
     const int sel = lane >> 4, idx = lane & 15;
-    return (sel == 3) ? (TRK_UNIT * unit - head) : (idx << (4 * sel));
+    return (sel == 3) ? (TRK_UNIT * (unit + idx * P) - head) : (idx << (4 * sel));
 }
 
 // (cos, sin)(w m / fs [+ rc for W3]) evaluated in full: fp64 "turns" reduction with w / (2 pi fs) as a double-double
@@ -304,19 +313,22 @@ __device__ __forceinline__ void t2_convert_hi(const T2Raw<SB>& raw, int i0, int 
     }
 }
 
-// ================================ MAP (waves 0-3), one workgroup per unit: all three arms ================================
+// ================================ MAP (waves 0-3), all three arms in one workgroup ================================
+// Member m of a channel owns units m, m + P, m + 2 P, ... (one unit when the CUs allow a workgroup per unit; several
+// when there are more channels than that - up to all of them with one workgroup per channel).  The first unit's bytes
+// are loaded and converted one block ahead; further units are loaded and converted when their turn comes.
 template <int SB>
 __device__ __forceinline__ int t2_map3_role(T2Shared& S, const int8_t* __restrict__ rec, long long rec_alloc, int ms,
-                                            long long pos0, int member, int tid, unsigned long long* __restrict__ xbase,
-                                            bool fast, bool prof_on, bool prof_any) {
+                                            long long pos0, int member, int P, int n_units, int tid,
+                                            unsigned long long* __restrict__ xbase, bool fast, bool prof_on, bool prof_any) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const long long limit = rec_alloc - 16;                  // bytes: the last 16-byte word that may be loaded
-    const int g = (tid & 255) + member * T2_MAP;             // the lane's group inside the block's aligned window
+    const int g = (tid & 255) + member * T2_MAP;             // the lane's group (first unit) inside the block's aligned window
     const long long lane_off = (long long)g * 16;
     T2_FP_DECL
     (void)prof_on;
-    // state prepared one block ahead: the lane's 16 samples as fp64 and where they sit in the block
+    // state prepared one block ahead: the lane's 16 samples (first unit) as fp64 and where they sit in the block
     double xd[16];
     int i0, ilo;
     double ilod;
@@ -324,12 +336,12 @@ __device__ __forceinline__ int t2_map3_role(T2Shared& S, const int8_t* __restric
     int blk_pred;                    // block length the prepared samples are cut for
 
     // samples from block sample index END on belong to the next block: zeroed by an integer mask on the high dword
-#define T2_CUT(END)                                                                                            \
+#define T2_CUT(XD, I0, END)                                                                                    \
     do {                                                                                                       \
-        if (i0 < (END) && i0 + 16 > (END)) {                                                                   \
-            const int e_ = (END) - i0;                                                                         \
+        if ((I0) < (END) && (I0) + 16 > (END)) {                                                               \
+            const int e_ = (END) - (I0);                                                                       \
             _Pragma("unroll") for (int b_ = 0; b_ < 16; ++b_)                                                  \
-                xd[b_] = __hiloint2double(__double2hiint(xd[b_]) & ((b_ - e_) >> 31), 0);                      \
+                (XD)[b_] = __hiloint2double(__double2hiint((XD)[b_]) & ((b_ - e_) >> 31), 0);                  \
         }                                                                                                      \
     } while (0)
     // The block's last, partial group is cut in the shadow too, for the length the block will most likely have (the
@@ -343,7 +355,7 @@ __device__ __forceinline__ int t2_map3_role(T2Shared& S, const int8_t* __restric
         ilod = (double)ilo;                                                                                    \
         t2_convert<SB>(raw, i0, xd);                                                                           \
         blk_pred = (BLK_PRED);                                                                                 \
-        T2_CUT(blk_pred);                                                                                      \
+        T2_CUT(xd, i0, blk_pred);                                                                              \
     } while (0)
 
     raw = t2_load<SB>(rec, (pos0 & ~15ll) + lane_off, limit);
@@ -359,113 +371,128 @@ __device__ __forceinline__ int t2_map3_role(T2Shared& S, const int8_t* __restric
         const double startE = C.start[0], startP = C.start[1], startL = C.start[2];
         const long long pos = C.pos;
         const T2Carr& CR = S.carr[par];
-        const double2 w1 = CR.T[T2_W1 + (tid & 15)], w2 = CR.T[T2_W2 + ((tid >> 4) & 15)], w3 = CR.T[T2_W3];
+        const double2 w1 = CR.T[T2_W1 + (tid & 15)], w2 = CR.T[T2_W2 + ((tid >> 4) & 15)];
         if (hd.y) break;
         T2_FP_TOP
         __builtin_amdgcn_s_setprio(2);
         const int blk = hd.x;
         const long long pos_next = pos + blk;
-        const T2Raw<SB> nraw = t2_load<SB>(rec, (pos_next & ~15ll) + lane_off, limit);   // next block's bytes
+        const T2Raw<SB> nraw = t2_load<SB>(rec, (pos_next & ~15ll) + lane_off, limit);   // next block's bytes (first unit)
         T2PROBE(prof_on, 0);   // parameters read, next block's load issued
-        int kE, kP, kL, swE, swP, swL;
-        bool bad = false;
-        ramp_locate(startE, step, inv_step, ilod, ilo, kE, swE, bad);
-        ramp_locate(startP, step, inv_step, ilod, ilo, kP, swP, bad);
-        ramp_locate(startL, step, inv_step, ilod, ilo, kL, swL, bad);
-        if (__builtin_expect(__any(bad && i0 < blk), 0)) {
-            // a chip boundary within 1e-7 samples of a sample somewhere in this wave: exact search with the exact
-            // linspace steps (posted by the DLL wave right after the barrier)
-            int budget = 1 << 20;
-            while (C.xflag != it + 1 && --budget) __builtin_amdgcn_s_sleep(1);
-            const double stpE = C.stp[0], stpP = C.stp[1], stpL = C.stp[2];
-            ramp_setup(startE, stpE, inv_step, ilo, kE, swE);
-            ramp_setup(startP, stpP, inv_step, ilo, kP, swP);
-            ramp_setup(startL, stpL, inv_step, ilo, kL, swL);
-        }
-        // chips k1 and k1 + 1 of every ramp (two sign bits each); they are needed only after the accumulation
-        const unsigned bE = chip_bits2(S.cbits, kE), bP = chip_bits2(S.cbits, kP), bL = chip_bits2(S.cbits, kL);
-        // group-start phasor G = W1[tid & 15] * W2[(tid >> 4) & 15] * W3; a group that lies entirely beyond the block
-        // (its samples belong to the next one) gets a zero phasor, i.e. adds nothing
-        double gc, gs;
-        {
-            const double lc = __builtin_fma(w1.x, w2.x, -(w1.y * w2.y));
-            const double ls = __builtin_fma(w1.x, w2.y, w1.y * w2.x);
-            gc = __builtin_fma(lc, w3.x, -(ls * w3.y));
-            gs = __builtin_fma(lc, w3.y, ls * w3.x);
-            const bool beyond = i0 >= blk;
-            gc = beyond ? 0.0 : gc;
-            gs = beyond ? 0.0 : gs;
-        }
+        // W1[tid & 15] * W2[(tid >> 4) & 15]: the lane's phasor inside a unit
+        const double lc = __builtin_fma(w1.x, w2.x, -(w1.y * w2.y));
+        const double ls = __builtin_fma(w1.x, w2.y, w1.y * w2.x);
         if (__builtin_expect(blk != blk_pred, 0)) {
             // the block is a sample longer or shorter than predicted (about one block in ten): the lanes around its
             // end convert their bytes again and cut them at the real length
             const int lo_ = blk < blk_pred ? blk : blk_pred, hi_ = blk < blk_pred ? blk_pred : blk;
             if (__any(i0 < hi_ && i0 + 16 > lo_)) {
                 t2_convert<SB>(raw, i0, xd);
-                T2_CUT(blk);
+                T2_CUT(xd, i0, blk);
             }
         }
-        T2PROBE(prof_on, 1);   // switch samples resolved
-        const double cE1 = __hiloint2double((int)(0x3FF00000u | (bE << 31)), 0), cE2 = __hiloint2double((int)(0x3FF00000u | ((bE >> 1) << 31)), 0);
-        const double cP1 = __hiloint2double((int)(0x3FF00000u | (bP << 31)), 0), cP2 = __hiloint2double((int)(0x3FF00000u | ((bP >> 1) << 31)), 0);
-        const double cL1 = __hiloint2double((int)(0x3FF00000u | (bL << 31)), 0), cL2 = __hiloint2double((int)(0x3FF00000u | ((bL >> 1) << 31)), 0);
-        double aIE, aQE, aIP, aQP, aIL, aQL;
-        const int iend = i0 + 16;
-        int swmin = swE < swP ? swE : swP;
-        swmin = swL < swmin ? swL : swmin;
-        const bool eS = (swE == swmin), pS = (swP == swmin), lS = (swL == swmin);
-        const bool odd = (swE < iend && !eS) || (swP < iend && !pS) || (swL < iend && !lS);
-        if (__builtin_expect(__any(odd), 0)) {
-            // exact per-sample path (a ramp switches at a second position inside the group)
-            aIE = aQE = aIP = aQP = aIL = aQL = 0.0;
-#pragma unroll
-            for (int b = 0; b < 16; ++b) {
-                const int i = i0 + b;
-                const double2 Bb = CR.T[T2_B + b];
-                const double c = __builtin_fma(gc, Bb.x, -(gs * Bb.y));
-                const double s = __builtin_fma(gs, Bb.x, gc * Bb.y);
-                const double xs = s * xd[b], xc = c * xd[b];
-                const double cE = i >= swE ? cE2 : cE1;
-                const double cP = i >= swP ? cP2 : cP1;
-                const double cL = i >= swL ? cL2 : cL1;
-                aIE = __builtin_fma(cE, xs, aIE);
-                aQE = __builtin_fma(cE, xc, aQE);
-                aIP = __builtin_fma(cP, xs, aIP);
-                aQP = __builtin_fma(cP, xc, aQP);
-                aIL = __builtin_fma(cL, xs, aIL);
-                aQL = __builtin_fma(cL, xc, aQL);
+        double aIE = 0.0, aQE = 0.0, aIP = 0.0, aQP = 0.0, aIL = 0.0, aQL = 0.0;
+        // ---- one 16-sample group of one unit: adds its six sums ----
+        auto group = [&](const double (&x)[16], int gi0, int gilo, double gilod, double2 w3) {
+            int kE, kP, kL, swE, swP, swL;
+            bool bad = false;
+            ramp_locate(startE, step, inv_step, gilod, gilo, kE, swE, bad);
+            ramp_locate(startP, step, inv_step, gilod, gilo, kP, swP, bad);
+            ramp_locate(startL, step, inv_step, gilod, gilo, kL, swL, bad);
+            if (__builtin_expect(__any(bad && gi0 < blk), 0)) {
+                // a chip boundary within 1e-7 samples of a sample somewhere in this wave: exact search with the exact
+                // linspace steps (posted by the DLL wave right after the barrier)
+                int budget = 1 << 20;
+                while (C.xflag != it + 1 && --budget) __builtin_amdgcn_s_sleep(1);
+                const double stpE = C.stp[0], stpP = C.stp[1], stpL = C.stp[2];
+                ramp_setup(startE, stpE, inv_step, gilo, kE, swE);
+                ramp_setup(startP, stpP, inv_step, gilo, kP, swP);
+                ramp_setup(startL, stpL, inv_step, gilo, kL, swL);
             }
-        } else {
-            // samples b >= bsw come after the switch.  The samples are small integers, so their fp64 low dword is zero
-            // and masking the HIGH dword alone zeroes one
-            int bsw = swmin - i0;
-            bsw = bsw > 16 ? 16 : bsw;
-            double Ac = 0.0, As = 0.0, Tc = 0.0, Ts = 0.0;
-#pragma unroll
-            for (int b = 0; b < 16; ++b) {
-                const double2 Bb = CR.T[T2_B + b];
-                Ac = __builtin_fma(xd[b], Bb.x, Ac);
-                As = __builtin_fma(xd[b], Bb.y, As);
-                const int keep = ~((b - bsw) >> 31);                  // all ones iff b >= bsw
-                const double xt = __hiloint2double(__double2hiint(xd[b]) & keep, 0);
-                Tc = __builtin_fma(xt, Bb.x, Tc);
-                Ts = __builtin_fma(xt, Bb.y, Ts);
+            // chips k1 and k1 + 1 of every ramp (two sign bits each); they are needed only after the accumulation
+            const unsigned bE = chip_bits2(S.cbits, kE), bP = chip_bits2(S.cbits, kP), bL = chip_bits2(S.cbits, kL);
+            // group-start phasor G = W1 * W2 * W3; a group that lies entirely beyond the block (its samples belong to
+            // the next one) gets a zero phasor, i.e. adds nothing
+            double gc = __builtin_fma(lc, w3.x, -(ls * w3.y));
+            double gs = __builtin_fma(lc, w3.y, ls * w3.x);
+            {
+                const bool beyond = gi0 >= blk;
+                gc = beyond ? 0.0 : gc;
+                gs = beyond ? 0.0 : gs;
             }
-            T2PROBE(prof_on, 2);   // 16-sample accumulation
-            // rotate by the group phasor: cos part -> Q, sin part -> I (tracking.py:205-207)
-            const double allQ = __builtin_fma(gc, Ac, -(gs * As));
-            const double allI = __builtin_fma(gs, Ac, gc * As);
-            const double tlQ = __builtin_fma(gc, Tc, -(gs * Ts));
-            const double tlI = __builtin_fma(gs, Tc, gc * Ts);
-            const double dE = eS ? (cE2 - cE1) : 0.0;
-            const double dP = pS ? (cP2 - cP1) : 0.0;
-            const double dL = lS ? (cL2 - cL1) : 0.0;
-            aIE = __builtin_fma(dE, tlI, cE1 * allI);
-            aQE = __builtin_fma(dE, tlQ, cE1 * allQ);
-            aIP = __builtin_fma(dP, tlI, cP1 * allI);
-            aQP = __builtin_fma(dP, tlQ, cP1 * allQ);
-            aIL = __builtin_fma(dL, tlI, cL1 * allI);
-            aQL = __builtin_fma(dL, tlQ, cL1 * allQ);
+            T2PROBE(prof_on, 1);   // switch samples resolved
+            const double cE1 = __hiloint2double((int)(0x3FF00000u | (bE << 31)), 0), cE2 = __hiloint2double((int)(0x3FF00000u | ((bE >> 1) << 31)), 0);
+            const double cP1 = __hiloint2double((int)(0x3FF00000u | (bP << 31)), 0), cP2 = __hiloint2double((int)(0x3FF00000u | ((bP >> 1) << 31)), 0);
+            const double cL1 = __hiloint2double((int)(0x3FF00000u | (bL << 31)), 0), cL2 = __hiloint2double((int)(0x3FF00000u | ((bL >> 1) << 31)), 0);
+            const int iend = gi0 + 16;
+            int swmin = swE < swP ? swE : swP;
+            swmin = swL < swmin ? swL : swmin;
+            const bool eS = (swE == swmin), pS = (swP == swmin), lS = (swL == swmin);
+            const bool odd = (swE < iend && !eS) || (swP < iend && !pS) || (swL < iend && !lS);
+            if (__builtin_expect(__any(odd), 0)) {
+                // exact per-sample path (a ramp switches at a second position inside the group)
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    const int i = gi0 + b;
+                    const double2 Bb = CR.T[T2_B + b];
+                    const double c = __builtin_fma(gc, Bb.x, -(gs * Bb.y));
+                    const double s_ = __builtin_fma(gs, Bb.x, gc * Bb.y);
+                    const double xs = s_ * x[b], xc = c * x[b];
+                    const double cE = i >= swE ? cE2 : cE1;
+                    const double cP = i >= swP ? cP2 : cP1;
+                    const double cL = i >= swL ? cL2 : cL1;
+                    aIE = __builtin_fma(cE, xs, aIE);
+                    aQE = __builtin_fma(cE, xc, aQE);
+                    aIP = __builtin_fma(cP, xs, aIP);
+                    aQP = __builtin_fma(cP, xc, aQP);
+                    aIL = __builtin_fma(cL, xs, aIL);
+                    aQL = __builtin_fma(cL, xc, aQL);
+                }
+            } else {
+                // samples b >= bsw come after the switch.  The samples are small integers, so their fp64 low dword is
+                // zero and masking the HIGH dword alone zeroes one
+                int bsw = swmin - gi0;
+                bsw = bsw > 16 ? 16 : bsw;
+                double Ac = 0.0, As = 0.0, Tc = 0.0, Ts = 0.0;
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    const double2 Bb = CR.T[T2_B + b];
+                    Ac = __builtin_fma(x[b], Bb.x, Ac);
+                    As = __builtin_fma(x[b], Bb.y, As);
+                    const int keep = ~((b - bsw) >> 31);                  // all ones iff b >= bsw
+                    const double xt = __hiloint2double(__double2hiint(x[b]) & keep, 0);
+                    Tc = __builtin_fma(xt, Bb.x, Tc);
+                    Ts = __builtin_fma(xt, Bb.y, Ts);
+                }
+                T2PROBE(prof_on, 2);   // 16-sample accumulation
+                // rotate by the group phasor: cos part -> Q, sin part -> I (tracking.py:205-207)
+                const double allQ = __builtin_fma(gc, Ac, -(gs * As));
+                const double allI = __builtin_fma(gs, Ac, gc * As);
+                const double tlQ = __builtin_fma(gc, Tc, -(gs * Ts));
+                const double tlI = __builtin_fma(gs, Tc, gc * Ts);
+                const double dE = eS ? (cE2 - cE1) : 0.0;
+                const double dP = pS ? (cP2 - cP1) : 0.0;
+                const double dL = lS ? (cL2 - cL1) : 0.0;
+                aIE += __builtin_fma(dE, tlI, cE1 * allI);
+                aQE += __builtin_fma(dE, tlQ, cE1 * allQ);
+                aIP += __builtin_fma(dP, tlI, cP1 * allI);
+                aQP += __builtin_fma(dP, tlQ, cP1 * allQ);
+                aIL += __builtin_fma(dL, tlI, cL1 * allI);
+                aQL += __builtin_fma(dL, tlQ, cL1 * allQ);
+            }
+        };
+        group(xd, i0, ilo, ilod, CR.T[T2_W3]);
+        // further units of this member (more channels than CUs for one workgroup per unit): loaded and converted now
+#pragma unroll 1
+        for (int j = 1; member + j * P < n_units; ++j) {
+            const int gj = g + j * P * T2_MAP;
+            const int j0 = gj * 16 - (int)(pos & 15);
+            if (j0 >= blk) break;                              // (uniform: the whole unit lies beyond the block)
+            const T2Raw<SB> rj = t2_load<SB>(rec, (pos & ~15ll) + (long long)gj * 16, limit);
+            double xj[16];
+            t2_convert<SB>(rj, j0, xj);
+            T2_CUT(xj, j0, blk);
+            group(xj, j0, j0, (double)j0, CR.T[T2_W3 + j]);   // (j0 > 0: only the block's very first group starts before it)
         }
         T2PROBE(prof_on, 3);   // group finalisation
         // ---- transposing reduction inside each row of 16 lanes; exchange order I_P Q_P I_E Q_E I_L Q_L ----
@@ -505,8 +532,10 @@ __device__ __forceinline__ int t2_map3_role(T2Shared& S, const int8_t* __restric
             v = v + dpp_mov<0x4E>(v);
             v = v + dpp_mov<0x141>(v);   // row_half_mirror: the other quad of the eight
             if (pp == 0 && word < 6) {
-                // {16-bit epoch tag | 48-bit two's-complement fixed point}, ONE aligned 8-byte store
-                const double t = __builtin_fma(v, t2_fix<SB>(), T2_MAGIC);
+                // {16-bit epoch tag | 48-bit two's-complement fixed point}, ONE aligned 8-byte store.  A member that
+                // owns several units can hold more than 2^19 (2^28): the scale drops by the number of units, rounded up
+                // to a power of two, and the reader's scale with it (t2_fix_of).
+                const double t = __builtin_fma(v, t2_fix_of<SB>(P, n_units), T2_MAGIC);
                 const unsigned long long q = (unsigned long long)(__double_as_longlong(t) - __double_as_longlong(T2_MAGIC));
                 const unsigned long long gran = ((unsigned long long)((unsigned)(it + 1) & 0xFFFFu) << 48) | (q & 0xFFFFFFFFFFFFull);
                 granule_store(xbase + T2_XG + par * 96 + word * 16 + member, gran, fast);
@@ -711,8 +740,8 @@ __device__ __forceinline__ int t2_pll_role(T2Shared& S, const TrkConst& K, const
            inv_fs = K.inv_fs, fs = K.fs;
     T2_PIN(k_a); T2_PIN(k_b); T2_PIN(inv_2pi); T2_PIN(c_hi); T2_PIN(c_lo); T2_PIN(inv_fs); T2_PIN(carrBasis);
     T2_PIN(fs);
-    // the largest rate step the rotation takes: the farthest table entry is sample P * UNIT of the block
-    double dw_max = SGX_ROT_MAX / ((double)(P * TRK_UNIT) * K.inv_fs);
+    // the largest rate step the rotation takes: the farthest table entry is sample n_units * UNIT of the block
+    double dw_max = SGX_ROT_MAX / ((double)(K.n_units * TRK_UNIT) * K.inv_fs);
     T2_PIN(dw_max);
     const int ms = K.ms;
     // polynomial coefficients in registers (a constant the compiler materialises in front of every use is an
@@ -724,7 +753,7 @@ __device__ __forceinline__ int t2_pll_role(T2Shared& S, const TrkConst& K, const
     T2_PIN(rk.c0); T2_PIN(rk.c1); T2_PIN(rk.c2); T2_PIN(rk.c3); T2_PIN(rk.c4); T2_PIN(rk.c5);
     // lane 0 of a row adds the bits of 1.5 2^52 to its payload: the row's integer sum then IS the double 1.5 2^52 + sum
     const int bias_hi = ((lane & 15) == 0) ? 0x43380000 : 0;
-    double unfix = 1.0 / t2_fix<SB>();
+    double unfix = 1.0 / t2_fix_of<SB>(P, K.n_units);
     T2_PIN(unfix);
     const bool w3 = lane >= 48;
     // lane = 16 word + unit polls that unit's granule of I_P (word 0, row 0) / Q_P (word 1, row 1)
@@ -769,7 +798,7 @@ __device__ __forceinline__ int t2_pll_role(T2Shared& S, const TrkConst& K, const
             if (rc >= two_pi) rc -= two_pi;
         }
         // the next block's table entry of this lane at the CURRENT rate, in full; the sums then only turn it
-        const int mi = t2_carr_mult(lane, unit, head_next);
+        const int mi = t2_carr_mult(lane, unit, P, head_next);
         double mf = (double)mi * inv_fs;             // m / fs: the rate step dw turns the entry by dw * mf radians
         double cs_p, sn_p;
         t2_carr_entry(c_hi, c_lo, inv_2pi, w_cur, rc, mi, w3, cs_p, sn_p);
@@ -828,8 +857,8 @@ __device__ __forceinline__ int t2_pll_role(T2Shared& S, const TrkConst& K, const
             } else {
                 t2_carr_entry(c_hi, c_lo, inv_2pi, w_new, rc, mi, w3, cs, sn);
             }
-            // B, W1, W2 are consecutive 16-entry tables, W3 follows: lanes 48..63 all store the same W3
-            S.carr[par ^ 1].T[lane < 48 ? lane : 48] = make_double2(cs, sn);
+            // B, W1, W2 are consecutive 16-entry tables, the W3 of this member's units follow
+            S.carr[par ^ 1].T[lane] = make_double2(cs, sn);
         }
         w_cur = w_new;
         remCarr = rc;
@@ -897,9 +926,9 @@ __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const
     int blk = blk0, stop = stop0;
     const int l4 = lane & 3;
     const double off = (l4 == 0) ? -D.spacing : ((l4 == 2) ? D.spacing : 0.0);   // rem - spc == rem + (-spc) exactly
-    const int lim3 = P * TRK_UNIT - 15;                    // the longest block the units of the launch hold
+    const int lim3 = K.n_units * TRK_UNIT - 15;            // the longest block the units of the launch hold
     const int bias_hi = ((lane & 15) == 0) ? 0x43380000 : 0;   // (see the PLL wave)
-    double unfix = 1.0 / t2_fix<SB>();
+    double unfix = 1.0 / t2_fix_of<SB>(P, K.n_units);
     T2_PIN(unfix);
     // lane = 16 row + unit polls that unit's granule of word 2 + row: rows I_E, Q_E, I_L, Q_L
     const bool mine = (lane & 15) < P;
@@ -1064,11 +1093,11 @@ __device__ __forceinline__ void t2_rec_store(T2Shared& S, int k, long long m, in
 // size), so no line is ever fetched half written; the watermark is cached in a register, so the uncached load is
 // issued once per ~900 blocks.
 template <int SB>
-__device__ __forceinline__ int t2_rec_role(T2Shared& S, const TrkConst& K, int pad, int P, int ch, bool owner, int lane,
+__device__ __forceinline__ int t2_rec_role(T2Shared& S, const TrkConst& K, int pad, int ch, bool owner, int lane,
                                            double* __restrict__ o, int* __restrict__ err, unsigned long long mark_seen) {
     const long long m = K.ms;
     const int ms = K.ms;
-    const long long span = (2ll * P * TRK_UNIT + 64) * SB;    // bytes: a block and the window of the prefetch behind it
+    const long long span = (2ll * K.n_units * TRK_UNIT + 64) * SB;   // bytes: a block and the window of the prefetch behind it
     int it = 0;
     for (; it < ms; ++it) {
         const int par = it & 1;
@@ -1181,7 +1210,7 @@ __global__ __launch_bounds__(T2_THREADS) void trk2_kernel(const int8_t* __restri
         D.rec_len = (K.rec_len - cc.pad) / SB;      // samples on the channel's grid (cc.pad: its byte shift, SB = 2 only)
         double step_a, inv_step;
         blk0 = sgx_block_length(K.code_len - 0.0, K.code_basis, D.fs, D.inv_fs, step_a, inv_step);
-        const int lim3 = P * TRK_UNIT - 15;
+        const int lim3 = K.n_units * TRK_UNIT - 15;
         stop0 = dead ? 2 : ((blk0 <= 0 || cc.pos0 + blk0 > D.rec_len) ? 1 : ((blk0 > lim3) ? 3 : 0));
         const double off = ((lane & 3) == 0) ? -K.spacing : (((lane & 3) == 2) ? K.spacing : 0.0);
         if (lane < 3) S.code[0].start[lane] = 0.0 + off;
@@ -1199,13 +1228,13 @@ __global__ __launch_bounds__(T2_THREADS) void trk2_kernel(const int8_t* __restri
     if (wave == 4) {
         double cs, sn;
         t2_carr_entry(K.inv_2pifs_hi, K.inv_2pifs_lo, K.inv_2pi, (cc.acquiredFreq * 2.0) * M_PI, 0.0,
-                      t2_carr_mult(lane, unit, (int)(cc.pos0 & 15)), lane >= 48, cs, sn);
-        S.carr[0].T[lane < 48 ? lane : 48] = make_double2(cs, sn);
+                      t2_carr_mult(lane, unit, P, (int)(cc.pos0 & 15)), lane >= 48, cs, sn);
+        S.carr[0].T[lane] = make_double2(cs, sn);
     }
     // a streaming record: block 0 and the prefetch of block 1 must be resident before the first loads
     unsigned long long mark_seen = K.mark ? 0ull : ~0ull;
     if (wave == 6 && K.mark) {
-        const long long need = cc.pos0 * SB + cc.pad + 3 * (2ll * P * TRK_UNIT + 64) * SB;
+        const long long need = cc.pos0 * SB + cc.pad + 3 * (2ll * K.n_units * TRK_UNIT + 64) * SB;
         wait_mark(K.mark, need < K.rec_len ? need : K.rec_len, mark_seen, err, ch);
     }
     __syncthreads();
@@ -1217,13 +1246,13 @@ __global__ __launch_bounds__(T2_THREADS) void trk2_kernel(const int8_t* __restri
             done = t2_map1_role<SB>(S, rec + cc.pad, K.rec_alloc, K.ms, cc.pos0, unit, arm, tid, xbase, fast,
                                     K.code_basis / K.fs, K.spacing, prof_on, prof != nullptr);
         else
-            done = t2_map3_role<SB>(S, rec + cc.pad, K.rec_alloc, K.ms, cc.pos0, unit, tid, xbase, fast, prof_on, prof != nullptr);
+            done = t2_map3_role<SB>(S, rec + cc.pad, K.rec_alloc, K.ms, cc.pos0, unit, P, K.n_units, tid, xbase, fast, prof_on, prof != nullptr);
     } else if (wave == 4)
         done = t2_pll_role<SB>(S, K, cc, unit, member, owner, lane, P, ch, xbase, err, prof_on, prof);
     else if (wave == 5)
         done = t2_dll_role<SB, ARMS>(S, K, D, cc.pos0, blk0, stop0, arm, owner, lane, P, ch, xbase, err, prof_on, K.file_off + cc.pad);
     else
-        done = t2_rec_role<SB>(S, K, cc.pad, P, ch, owner, lane, o, err, mark_seen);
+        done = t2_rec_role<SB>(S, K, cc.pad, ch, owner, lane, o, err, mark_seen);
 
     // a channel that was given up reports the blocks completed before the abort
     const bool aborted = S.code[done & 1].stop == 2;

@@ -297,15 +297,20 @@ def test_full_length_tracking_locks_onto_the_scene(full_run):
 
 
 def test_split_variants_agree_on_the_full_run(full_run):
-    """1 CU per channel vs 10 cooperating CUs, and the placement-independent exchange path: identical
-    block boundaries, sums equal to rounding (different summation order only)."""
+    """The decompositions of the latency-mode kernel against the default (30 members per channel: one per unit and
+    correlator arm): one workgroup per channel owning all ten units, ten members of one unit with all three arms and the
+    placement-independent exchange path, three members owning four / three / three units, and the arm split switched
+    off.  Identical block boundaries, sums equal to rounding (different summation order only)."""
     m, s, ctx, sc, rec, a, chans, series, done = full_run
-    old = {k: os.environ.get(k) for k in ("SGX_TRK_SPLIT", "SGX_TRK_FASTX")}
+    old = {k: os.environ.get(k) for k in ("SGX_TRK_SPLIT", "SGX_TRK_FASTX", "SGX_TRK_ARMS")}
     try:
-        for env in ({"SGX_TRK_SPLIT": "1"}, {"SGX_TRK_SPLIT": "10", "SGX_TRK_FASTX": "0"}, {"SGX_TRK_SPLIT": "3"}):
+        for env, members in (({"SGX_TRK_SPLIT": "1"}, 1), ({"SGX_TRK_SPLIT": "10", "SGX_TRK_FASTX": "0"}, 10),
+                             ({"SGX_TRK_SPLIT": "3"}, 3), ({"SGX_TRK_ARMS": "3"}, 10)):
             os.environ.update(env)
             ms = 6000
             s2, d2 = ctx.track(rec, chans, ms)
+            tm = ctx.timing()
+            assert tm["track_kernel"] == 2 and tm["track_members"] == members, (env, tm)
             assert np.all(d2 == ms)
             assert np.array_equal(s2[:, 0], series[:, 0, :ms])
             assert _trk_err(s2, series[:, :, :ms]) < 1e-9
@@ -345,60 +350,61 @@ def test_many_channels_throughput_mode(full_run):
     assert _trk_err(s2[:8], series[:, :, :ms]) < 1e-9
 
 
-def test_round1_and_round2_kernels_agree_on_a_long_run(full_run):
-    """SGX_TRK_V1=1 (the round-1 cooperative kernel: fp64 granule exchange, libm loop filter) against the default
-    round-2 kernel (prepared switch candidates, integer-atomic exchange, short-chain loop filter): identical block
-    boundaries and sums equal to rounding over a long run including the pull-in transient."""
+def test_one_workgroup_per_channel_agrees_on_a_long_run(full_run):
+    """One workgroup per channel (every member-to-member exchange degenerate, all units in one map) against the default
+    30-member launch over a long run including the pull-in transient: identical block boundaries, sums equal to
+    rounding, NCO frequencies within 1e-6 Hz."""
     m, s, ctx, sc, rec, a, chans, series, done = full_run
-    old = os.environ.get("SGX_TRK_V1")
+    old = os.environ.get("SGX_TRK_SPLIT")
     try:
-        os.environ["SGX_TRK_V1"] = "1"
+        os.environ["SGX_TRK_SPLIT"] = "1"
         ms = 12000
         s2, d2 = ctx.track(rec, chans, ms)
     finally:
         if old is None:
-            os.environ.pop("SGX_TRK_V1", None)
+            os.environ.pop("SGX_TRK_SPLIT", None)
         else:
-            os.environ["SGX_TRK_V1"] = old
+            os.environ["SGX_TRK_SPLIT"] = old
     assert np.all(d2 == ms)
     assert np.array_equal(s2[:, 0], series[:, 0, :ms])
     assert _trk_err(s2, series[:, :, :ms]) < 1e-9
     assert np.max(np.abs(s2[:, 1:3] - series[:, 1:3, :ms])) < 1e-6
 
 
-@pytest.mark.parametrize("kernel", ["round2", "round1"])
-def test_a_withheld_member_aborts_the_channel_quickly(full_run, capfd, kernel):
+@pytest.mark.parametrize("layout", ["arms", "units"])
+def test_a_withheld_member_aborts_the_channel_quickly(full_run, capfd, layout):
     """The launch really lacks one member per channel (SGX_TRK_TEST_WITHHOLD=1): the others must give the channel up
     within one poll budget - not spin block after block - and the host's repeat with one workgroup per channel must
-    deliver the usual results.  Both cooperative kernels (SGX_TRK_V1=1: the round-1 one, which streaming records and
-    low sampling rates still use)."""
+    deliver the usual results.  Both member layouts of the latency-mode kernel (30 per channel: unit x arm; 10: units)."""
     import time
     m, s, ctx, sc, rec, a, chans, series, done = full_run
     os.environ["SGX_TRK_TEST_WITHHOLD"] = "1"
-    if kernel == "round1":
-        os.environ["SGX_TRK_V1"] = "1"
+    if layout == "units":
+        os.environ["SGX_TRK_ARMS"] = "3"
     try:
         t0 = time.perf_counter()
         s2, d2 = ctx.track(rec, chans, 500)
         dt = time.perf_counter() - t0
     finally:
         os.environ.pop("SGX_TRK_TEST_WITHHOLD", None)
-        os.environ.pop("SGX_TRK_V1", None)
+        os.environ.pop("SGX_TRK_ARMS", None)
     assert "repeating the launch with one workgroup per channel" in capfd.readouterr().err
     assert dt < 20.0, dt
     assert np.all(d2 == 500) and np.array_equal(s2[:, 0], series[:, 0, :500])
     assert _trk_err(s2, series[:, :, :500]) < 1e-9
 
 
-@pytest.mark.parametrize("kernel", ["round2", "round1"])
-def test_a_block_beyond_the_units_of_the_launch_is_an_error_not_a_silent_truncation(kernel):
+@pytest.mark.parametrize("layout", ["arms", "units", "one"])
+def test_a_block_beyond_the_units_of_the_launch_is_an_error_not_a_silent_truncation(layout):
     """A DLL bandwidth of 6 kHz on a channel without a signal drives the code NCO tens of kHz off: blocks become longer than
-    the ten 4096-sample units of the launch.  Both cooperative kernels must say so (SGX_E_RANGE) instead of dropping
-    the tail samples; at 2 kHz the same run still fits and completes."""
+    the ten 4096-sample units of the launch.  Every member layout must say so (SGX_E_RANGE) instead of dropping the tail
+    samples; at 2 kHz the same run still fits and completes."""
     m = pkg()
     chans = [(7, 9.548e6, 1234.0), (1, 9.5478e6, 12345.0)]
-    if kernel == "round1":
-        os.environ["SGX_TRK_V1"] = "1"
+    if layout == "units":
+        os.environ["SGX_TRK_ARMS"] = "3"
+    if layout == "one":
+        os.environ["SGX_TRK_SPLIT"] = "1"
     try:
         for bw, fits in ((2000.0, True), (6000.0, False)):
             s = m.Settings()
@@ -414,7 +420,8 @@ def test_a_block_beyond_the_units_of_the_launch_is_an_error_not_a_silent_truncat
                 with pytest.raises(m._native.SgxError, match="plausible range"):
                     ctx.track(rec, chans, 60)
     finally:
-        os.environ.pop("SGX_TRK_V1", None)
+        os.environ.pop("SGX_TRK_ARMS", None)
+        os.environ.pop("SGX_TRK_SPLIT", None)
 
 
 def test_second_front_end_golden():
@@ -438,7 +445,7 @@ def test_second_front_end_golden():
     assert np.allclose(a.peakMetric, g["peakMetric"], rtol=1e-9, atol=0)
     a.preRun()
     assert np.array_equal(a.channels.PRN, g["ch_PRN"])
-    for env in ({}, {"SGX_TRK_SPLIT": "1"}, {"SGX_TRK_V1": "1"}):
+    for env in ({}, {"SGX_TRK_SPLIT": "1"}, {"SGX_TRK_ARMS": "3"}):
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:
@@ -946,9 +953,9 @@ def test_streaming_record_overlaps_tracking_with_identical_results(full_run, tmp
                 assert tm["track_streamed"] == (0 if env else 1)
                 assert np.array_equal(s2, series[:, :, :6000])
             else:
-                # one workgroup per channel (round-1 body, after the whole record arrived): other arithmetic and
-                # reduction order, equal to rounding
-                assert tm["track_kernel"] == 1 and tm["track_streamed"] == 0
+                # one workgroup per channel owning all ten units, following the watermark too: another reduction
+                # order, equal to rounding
+                assert tm["track_kernel"] == 2 and tm["track_members"] == 1 and tm["track_streamed"] == 1
                 assert _trk_err(s2, series[:, :, :6000]) < 1e-9
             assert np.array_equal(r.download(n_bytes - 5000, 5000), rec.download(n_bytes - 5000, 5000))
             r.free()
@@ -1015,6 +1022,8 @@ def test_config5_full_64_replicated_channels(full_run):
     m, s, ctx, sc, rec, a, chans, series, done = full_run
     many = [chans[i % 8] for i in range(64)]
     s64, d64 = ctx.track(rec, many, 37000)
+    tm = ctx.timing()
+    assert tm["track_kernel"] == 2 and tm["track_members"] == 4      # four members per channel, three / three / two / two units
     assert np.all(d64 == 37000)
     for i in range(8, 64):
         assert np.array_equal(s64[i], s64[i % 8])
@@ -1208,9 +1217,11 @@ def test_track_int16_record_matches_reference():
         assert np.array_equal(t2.series[:, 0], t.series[:, 0]) and _trk_err(t2.series, t.series) < 1e-9
 
 
-def test_track_int16_needs_the_one_unit_kernel_and_a_known_type():
-    """int16 records are tracked by the one-unit-per-workgroup kernel only: asking for the round-1 kernel, or for a
-    sample type the C-ABI does not know, is an argument error with a message, not a wrong result."""
+def test_track_int16_every_member_layout_and_a_known_type():
+    """int16 records run every member layout of the latency-mode kernel (one workgroup per channel, three members with
+    several units, one per unit, one per unit and arm) with equal results, and more channels than the throughput-mode
+    kernel's threshold (it reads int8 only: the latency-mode kernel takes them, one workgroup per channel); a sample type
+    the C-ABI does not know is an argument error with a message, not a wrong result."""
     g = load_golden("trk_int16.npz")
     m = pkg()
     rec16 = (m.synth.generate(scene_from_json(g["scene"]), int(g["n_samples"])).astype(np.int16)
@@ -1219,16 +1230,24 @@ def test_track_int16_needs_the_one_unit_kernel_and_a_known_type():
     ctx = m.engine.get_context(s, 0)
     rec = ctx.upload_bytes(rec16)
     chans = [(int(g["locked_PRN"][0]), float(g["locked_acquiredFreq"][0]), float(g["locked_codePhase"][0]))]
-    os.environ["SGX_TRK_V1"] = "1"
-    try:
-        with pytest.raises(m._native.SgxError, match="two-byte samples"):
-            ctx.track(rec, chans, 5, data_type=m._native.DT_INT16)
-    finally:
-        os.environ.pop("SGX_TRK_V1", None)
     with pytest.raises(m._native.SgxError, match="data_type"):
         ctx.track(rec, chans, 5, data_type=7)
     ser, done = ctx.track(rec, chans, 5, rec_file_offset=0, data_type=m._native.DT_INT16)
-    assert ser.shape == (1, 13, 5)
+    assert ser.shape == (1, 13, 5) and ctx.timing()["track_members"] == 30
+    for env, members in (({"SGX_TRK_SPLIT": "1"}, 1), ({"SGX_TRK_SPLIT": "3"}, 3), ({"SGX_TRK_ARMS": "3"}, 10)):
+        os.environ.update(env)
+        try:
+            s2, d2 = ctx.track(rec, chans, 5, data_type=m._native.DT_INT16)
+        finally:
+            for k in env:
+                os.environ.pop(k)
+        assert ctx.timing()["track_members"] == members and np.all(d2 == 5)
+        assert np.array_equal(s2[:, 0], ser[:, 0]) and _trk_err(s2, ser) < 1e-9
+    many, dm = ctx.track(rec, chans * 130, 5, data_type=m._native.DT_INT16)
+    tm = ctx.timing()
+    assert tm["track_kernel"] == 2 and tm["track_members"] == 1 and np.all(dm == 5)
+    assert all(np.array_equal(many[i], many[0]) for i in range(1, 130))
+    assert np.array_equal(many[0, 0], ser[0, 0]) and _trk_err(many[:1], ser) < 1e-9
 
 
 def test_track_int16_odd_start_byte_and_short_record():

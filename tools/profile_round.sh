@@ -2,11 +2,13 @@
 # The rocprofv3 passes behind profiles/<tag>_*: kernel trace + stats of the bench command, FETCH_SIZE / WRITE_SIZE passes
 # (separate, kernel trace only, as MI355X_MICROARCH.md prescribes) of the bench command and of three plain acquisitions,
 # and the VALU passes of the many-channel tracking leg.  Usage (GPU box): bash tools/profile_round.sh r02
-tag=${1:-r02}
+tag=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/prof_$tag
 rm -rf $out && mkdir -p $out
-BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+# the headline command alone: no concurrent-records or many-channel leg, so that trk2_kernel's average in the trace is the
+# duration of the launches the bench line's roofline is computed from
+BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --concurrent 0 --many-channels 0"
 BENCH1="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --concurrent 0 --no-config4"
 rocprofv3 --kernel-trace --stats -d $out/trace -- $BENCH > $out/trace.json 2> $out/trace.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/fetch -- $BENCH1 > /dev/null 2> $out/fetch.err

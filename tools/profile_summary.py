@@ -41,8 +41,8 @@ def main():
     # ---- kernel trace ----
     rows = top_kernels(db_of(os.path.join(out, "trace")))
     with open(os.path.join(dst, "%s_kernel_trace_stats.csv" % tag), "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "
-                "(the bench command; the CPU leg forks and is left out under the profiler)\n")
+        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --concurrent 0 "
+                "--many-channels 0 (the headline command alone; the CPU leg forks and is left out under the profiler)\n")
         f.write("kernel,calls,total_us,average_us,percent\n")
         for n, calls, tot, avg, pct in rows:
             f.write('"%s",%d,%.3f,%.3f,%.3f\n' % (n, calls, tot, avg, pct))
@@ -80,7 +80,7 @@ def main():
             if insts and act and gui:
                 rec["valu_insts_per_sample"] = insts * 64.0 / (8 * 37000 * 38192.0)
                 rec["valu_busy_frac_chip"] = act * 4.0 / 1024.0 / (gui / 8.0)
-                rec["valu_busy_frac_on_the_80_occupied_cus"] = rec["valu_busy_frac_chip"] * 256.0 / 80.0
+                rec["valu_busy_frac_on_the_240_occupied_cus"] = rec["valu_busy_frac_chip"] * 256.0 / 240.0
                 rec["valu_formula"] = ("SQ_INSTS_VALU * 64 lanes / (8 channels * 37000 ms * 38192 samples); SQ_ACTIVE_INST_VALU * 4 / "
                                        "1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs)")
         with open(os.path.join(dst, "%s_pmc_trk_kernel.json" % tag), "w") as f:
