@@ -199,7 +199,7 @@ int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset,
  * np.fromfile(fid, dataType, blksize) at tracking.py:154).  data_type SGX_DT_INT8 is sgx_track; with SGX_DT_INT16 the
  * record handle holds the file's BYTES as they are (upload 2 n bytes for n samples, little endian) and
  * rec_file_offset, skipNumberOfBytes + codePhase and absoluteSample stay BYTE positions, exactly as the reference's
- * fid.seek / fid.tell treat them (tracking.py:107, 167) - so a channel whose start byte is odd reads samples that
+ * fid.seek / fid.tell treat them (tracking.py:107, 255) - so a channel whose start byte is odd reads samples that
  * straddle the file's, as it does there.  Needs the one-unit-per-workgroup kernel: 8 ceil(n_ch / 8) x units CUs free
  * and samplingFreq >= 16 x codeFreqBasis, otherwise SGX_E_ARG. */
 #define SGX_DT_INT8  0

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void trk_fill_kernel(double* __restrict__ out,
 
 // sample_bytes: 1 (int8 record) or 2 (little-endian int16 record; the record handle holds the file's BYTES).  The
 // reference seeks skipNumberOfBytes + codePhase BYTES whatever the sample type and reports fid.tell(), also bytes
-// (tracking.py:107, 167); so a two-byte channel may start on an odd byte - its samples then straddle the file's - and
+// (tracking.py:107, 255); so a two-byte channel may start on an odd byte - its samples then straddle the file's - and
 // the kernel follows it there (per-channel byte shift of the record pointer, unaligned 16-byte loads).
 static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const sgx_chan_init* ch, int32_t n_ch,
                       int32_t ms, double* out, int32_t* ms_done, int sample_bytes) {

@@ -32,7 +32,7 @@ class TrackingResult(Result):
 
     def _data_type(self):
         """Settings.dataType -> (sgx_track_ex data_type, bytes per sample).  The reference reads np.fromfile(fid,
-        dataType, blksize) (tracking.py:154) but seeks and tells in BYTES (tracking.py:107, 167): both are kept."""
+        dataType, blksize) (tracking.py:154) but seeks and tells in BYTES (tracking.py:107, 255): both are kept."""
         dt = np.dtype(self._settings.dataType)
         if dt == np.dtype(np.int8):
             return _native.DT_INT8, 1
