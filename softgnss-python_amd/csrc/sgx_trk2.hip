@@ -268,6 +268,30 @@ template <int SB> struct T2Raw;
 template <> struct T2Raw<1> { uint4 a; };
 template <> struct T2Raw<2> { uint4 a, b; };
 
+// the (clamped) addresses of a lane's 16 samples, and the load from them: the arm-split map prepares the addresses in the
+// shadow of the previous block, so that the chain only holds the load itself
+// (byte offsets, not pointers: a pointer kept in a struct loses its address space and the load becomes a flat one)
+template <int SB> struct T2Ptr;
+template <> struct T2Ptr<1> { long long a; };
+template <> struct T2Ptr<2> { long long a, b; };
+
+template <int SB>
+__device__ __forceinline__ T2Ptr<SB> t2_ptr(long long first_sample, long long limit) {
+    T2Ptr<SB> p;
+    const long long a = first_sample * SB;
+    p.a = a > limit ? limit : a;
+    if constexpr (SB == 2) p.b = a + 16 > limit ? limit : a + 16;
+    return p;
+}
+
+template <int SB>
+__device__ __forceinline__ T2Raw<SB> t2_load_at(const int8_t* __restrict__ rec, const T2Ptr<SB>& p) {
+    T2Raw<SB> r;
+    r.a = *reinterpret_cast<const uint4*>(rec + p.a);
+    if constexpr (SB == 2) r.b = *reinterpret_cast<const uint4*>(rec + p.b);
+    return r;
+}
+
 template <int SB>
 __device__ __forceinline__ T2Raw<SB> t2_load(const int8_t* __restrict__ rec, long long first_sample, long long limit) {
     T2Raw<SB> r;
@@ -588,6 +612,8 @@ __device__ __forceinline__ int t2_map1_role(T2Shared& S, const int8_t* __restric
         const unsigned lo = S.cbits[bi >> 5], hi = S.cbits[(bi >> 5) + 1];
         win = (unsigned)((((unsigned long long)hi << 32) | lo) >> (bi & 31)) & 0xFFu;
     }
+    double magic = T2_MAGIC;
+    T2_PIN(magic);
     // state prepared one block ahead
     unsigned xh[16];                 // high dwords of the samples as fp64, zero outside the block
     int i0, ilo;
@@ -595,7 +621,7 @@ __device__ __forceinline__ int t2_map1_role(T2Shared& S, const int8_t* __restric
     T2Raw<SB> raw;
     int blk_pred;                    // block length the prepared samples are cut for
     long long pos = pos0;            // first sample of the current block
-    long long win_pred;              // first sample of this lane's window in the NEXT block if that block is blk_pred long
+    T2Ptr<SB> ptr_pred;              // where this lane's 16 samples of the NEXT block lie if that block is blk_pred long
 
 #define T2_PREPARE1(BLK_PRED)                                                                                  \
     do {                                                                                                       \
@@ -605,7 +631,9 @@ __device__ __forceinline__ int t2_map1_role(T2Shared& S, const int8_t* __restric
         ilod = (double)ilo;                                                                                    \
         blk_pred = (BLK_PRED);                                                                                 \
         t2_convert_hi<SB>(raw, i0, blk_pred, xh);                                                              \
-        win_pred = ((pos + blk_pred) & ~15ll) + lane_off;                                                      \
+        ptr_pred = t2_ptr<SB>(((pos + blk_pred) & ~15ll) + lane_off, limit);                                  \
+        T2_PIN(ilod);                                                                                          \
+        asm volatile("" : "+v"(ptr_pred.a));                                                                   \
     } while (0)
 
     raw = t2_load<SB>(rec, (pos0 & ~15ll) + lane_off, limit);
@@ -626,16 +654,16 @@ __device__ __forceinline__ int t2_map1_role(T2Shared& S, const int8_t* __restric
         const int blk = hd.x;
         const double inv_step = __hiloint2double(hd.w, hd.z);
         // next block's bytes: the address was prepared for the predicted length
-        long long nwin = win_pred;
-        if (__builtin_expect(blk != blk_pred, 0)) nwin = ((pos + blk) & ~15ll) + lane_off;
-        const T2Raw<SB> nraw = t2_load<SB>(rec, nwin, limit);
+        T2Ptr<SB> nptr = ptr_pred;
+        if (__builtin_expect(blk != blk_pred, 0)) nptr = t2_ptr<SB>(((pos + blk) & ~15ll) + lane_off, limit);
+        const T2Raw<SB> nraw = t2_load_at<SB>(rec, nptr);
         T2PROBE(prof_on, 0);   // parameters read, next block's load issued
         int k1, isw;
         bool bad = false;
         ramp_locate(sp.y, sp.x, inv_step, ilod, ilo, k1, isw, bad);
         int sh = k1 - ws;
         unsigned bits;
-        if (__builtin_expect(__any(i0 < blk && (bad || (unsigned)sh > 6u)), 0)) {
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(i0 < blk && (bad || (unsigned)sh > 6u)) != 0, 0)) {
             // a chip boundary within 1e-7 samples of a sample somewhere in this wave (or a chip outside the window):
             // exact search with the exact linspace step (posted by the DLL wave right after the barrier), chips from LDS
             int budget = 1 << 20;
@@ -685,8 +713,12 @@ __device__ __forceinline__ int t2_map1_role(T2Shared& S, const int8_t* __restric
         // Two-byte samples: 2^24 in the lanes (a member's total needs 52 bits), rounded to the granule's 2^19 once.
         constexpr double lane_fix = (SB == 1) ? T2_FIX : T2_FIX16 * 32.0;
         constexpr unsigned long long res_mask = (SB == 1) ? 0xFFFFFFFFFFFFull : 0xFFFFFFFFFFFFFull;
-        const unsigned long long qI = (unsigned long long)__double_as_longlong(__builtin_fma(aI, lane_fix, T2_MAGIC));
-        const unsigned long long qQ = (unsigned long long)__double_as_longlong(__builtin_fma(aQ, lane_fix, T2_MAGIC));
+        // (three-address FMAs with the bias in a register pair: the accumulating form wants it copied in front of each)
+        double tI, tQ;
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(tI) : "v"(aI), "s"(lane_fix), "v"(magic));
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(tQ) : "v"(aQ), "s"(lane_fix), "v"(magic));
+        const unsigned long long qI = (unsigned long long)__double_as_longlong(tI);
+        const unsigned long long qQ = (unsigned long long)__double_as_longlong(tQ);
         T2PROBE(prof_on, 3);   // group finalisation
         // transposing reduction inside each row of 16 lanes: even lanes end with the row's I, odd lanes with its Q
         const bool b0 = (lane & 1) != 0;
@@ -986,10 +1018,12 @@ __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const
         if (ARMS == 1 && lane == arm) N.start_arm = rem_next + off;
         if (lane == 0) N.pos = pos_next;
         double a_next = D.code_len - rem_next;                                      // (1023 - rem) of T1
-        // the longest next block the record still holds (stop 1 beyond it)
+        // the longest next block the record (stop 1 beyond it) and the units of the launch (stop 3) hold: ONE compare on
+        // the chain, which of the two it was is sorted out in the (rare) branch
         const long long room = D.rec_len - pos_next;
-        int lim1 = room > (long long)0x3FFFFFFF ? 0x3FFFFFFF : (int)room;
-        T2_PIN(a_next); T2_PIN(lim1);
+        const int lim1 = room > (long long)0x3FFFFFFF ? 0x3FFFFFFF : (room < 0 ? 0 : (int)room);
+        unsigned lim = (unsigned)(lim1 < lim3 ? lim1 : lim3);
+        T2_PIN(a_next); T2_PIN(lim);
         __builtin_amdgcn_s_setprio(3);
         const unsigned long long* gp = xbase + T2_XG + par * 96 + 32 + lane;
         const unsigned long long tag = (unsigned long long)((unsigned)(it + 1) & 0xFFFFu);
@@ -1019,7 +1053,7 @@ __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const
         const double v = (__longlong_as_double((long long)q) - T2_MAGIC) * unfix;   // I_E | Q_E | I_L | Q_L by row
         const double sq = v * v;
         const double e2 = sq + dpp_bcast<0x142, 0xA>(sq);    // rows 1, 3: I_E^2 + Q_E^2, I_L^2 + Q_L^2
-        const double mag = sgx_sqrt1(e2);                    // rows 1, 3: E, L
+        const double mag = sgx_sqrt1_pos(e2);                // rows 1, 3: E, L (two zero envelopes: NaN, as in the reference)
         const double oth = dpp_bcast<0x143, 0xC>(mag);       // rows 2, 3: E
         const double ce_lane = sgx_div1(oth - mag, oth + mag);       // row 3: (E - L) / (E + L)
         const double codeError = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ce_lane), 48),
@@ -1032,14 +1066,17 @@ __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const
         // chain part of the next block: its length, the ramps' slope and the slope's reciprocal
         double step_a, inv_step;
         const int blk_n = sgx_block_length(a_next, cf_new, D.fs, D.inv_fs, step_a, inv_step);
-        const int stop_n = gave_up ? 2 : ((blk_n <= 0 || blk_n > lim1) ? 1 : ((blk_n > lim3) ? 3 : 0));
-        if (lane == 0) {
-            *reinterpret_cast<int4*>(&N.blk) = make_int4(blk_n, stop_n, __double2loint(inv_step), __double2hiint(inv_step));
-            N.step = step_a;
-            if (blk_n > lim3 && !gave_up) {
+        int stop_n = 0;
+        if (__builtin_expect((unsigned)(blk_n - 1) >= lim || gave_up, 0)) {      // (blk <= 0 wraps to a huge number)
+            stop_n = gave_up ? 2 : ((blk_n <= 0 || blk_n > lim1) ? 1 : 3);
+            if (lane == 0 && stop_n == 3) {
                 atomicOr(err, TRK_ERR_RANGE);
                 atomicCAS(err + 1, 0, 1 + ch);
             }
+        }
+        if (lane == 0) {
+            *reinterpret_cast<int4*>(&N.blk) = make_int4(blk_n, stop_n, __double2loint(inv_step), __double2hiint(inv_step));
+            N.step = step_a;
         }
         rem = rem_next;
         pos = pos_next;

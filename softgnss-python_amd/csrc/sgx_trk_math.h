@@ -82,6 +82,19 @@ SGX_HD double sgx_sqrt1(double x) {
     return x > 0.0 ? g : 0.0;
 }
 
+// the same without the x > 0 select: x = 0 gives NaN (0 * inf), which is what the DLL discriminator makes of two zero
+// envelopes anyway ((0 - 0) / (0 + 0), tracking.py:238-244)
+SGX_HD double sgx_sqrt1_pos(double x) {
+    const double y = SGX_RSQ_SEED(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    const double d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+}
+
 #define SGX_ATAN_SHORT_MAX 0.25
 // atan(z) for |z| <= 0.25: z + z u Q(u), u = z^2, Q of degree 8 (tools/fit_atan.py: < 1 ulp), evaluated
 // Estrin-style (depth 6 after z instead of 11)
