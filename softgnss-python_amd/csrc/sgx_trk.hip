@@ -27,7 +27,10 @@ void sgx_trk2_launch(int n_blocks, hipStream_t st, const int8_t* rec, const int8
                      double* out, int* done, const TrkConst& K, long long* prof, unsigned long long* xch, int* err,
                      int sample_bytes, int arms, int lds_pad);
 #define T2_MAXP 16
-#define T2_XCH_STRIDE 256
+#ifndef T2_XLINE
+#define T2_XLINE 16
+#endif
+#define T2_XCH_STRIDE (((12 * T2_XLINE + 8 + 48) + 255) / 256 * 256)   // (as in sgx_trk2.hip)
 #define T2_PROF_STRIDE 192
 
 // sgx_trk_multi.hip: the cooperative kernel with a per-sample replica lookup, for low sampling rates

@@ -53,10 +53,15 @@
 #define T2_THREADS 448             // 4 map waves + PLL wave (4) + DLL wave (5) + record wave (6)
 #define T2_MAXP 16                 // units per channel
 #define T2_MAXM 48                 // members per channel (3 arms x 16 units)
-#define T2_XCH_STRIDE 256          // 64-bit words per channel in the exchange area:
-#define T2_XG 0                    //   [2 parities][6 words][16 units] granules
-#define T2_XABORT 192              //   abort word
-#define T2_XPLACE 200              //   [48] placement granules
+// The exchange area of a channel, in 64-bit words: 12 granule lines [2 parities][6 sums] of 16 units each, T2_XLINE words
+// apart, then the abort word and 48 placement granules.  (sgx_trk.hip sizes the allocation with the same T2_XCH_STRIDE.)
+#ifndef T2_XLINE
+#define T2_XLINE 16                // 128 bytes: the lines are adjacent
+#endif
+#define T2_XG 0
+#define T2_XABORT (12 * T2_XLINE)
+#define T2_XPLACE (12 * T2_XLINE + 8)
+#define T2_XCH_STRIDE (((12 * T2_XLINE + 8 + 48) + 255) / 256 * 256)
 #define T2_PROF_STRIDE 192         // profile words per channel: [3 phases][64 members]
 #define T2_FIX 268435456.0         // 2^28: fixed-point scale of a granule's 48-bit payload (member sums are < 2^19)
 #define T2_FIX16 524288.0          // 2^19: the same for two-byte samples (member sums are < 2^28)
@@ -117,7 +122,7 @@ struct __attribute__((aligned(128))) T2Code {   // code side of a block's parame
     long long pos;          // record index of the block's first sample
     // exact part: posted right after the barrier that starts the block (the exact search needs it, ~1e-5 of the waves)
     double stp[3];          // linspace steps E, P, L (tracking.py:166-188)
-    volatile int xflag;     // block number + 1 once stp[] is valid
+    int xflag;              // block number + 1 once stp[] is valid (lds_peek / lds_poke)
     int pad;
 };
 
@@ -230,6 +235,23 @@ __device__ __forceinline__ void t2_carr_entry(double inv_2pifs_hi, double inv_2p
     const double u3 = u + rc * inv_2pi;        // < 2
     u = w3 ? (u3 - ((u3 >= 1.0) ? 1.0 : 0.0)) : u;
     sgx_sincos_turns_short(u, sn, cs);
+}
+
+// Flags in LDS that another wave of the workgroup writes: read and written by LDS instructions, never through a generic
+// pointer (a volatile access to a __shared__ object goes through the flat aperture - slower, and one shape of it makes
+// this compiler emit an illegal compare against src_shared_base).  The low dword of a generic LDS address is the LDS offset.
+__device__ __forceinline__ int lds_peek(const int* p) {
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(unsigned long long)p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_poke(int* p, int v) {
+    asm volatile("ds_write_b32 %0, %1" : : "v"((unsigned)(unsigned long long)p), "v"(v) : "memory");
+}
+__device__ __forceinline__ long long lds_peek64(const long long* p) {
+    long long v;
+    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(unsigned long long)p) : "memory");
+    return v;
 }
 
 #define T2_PIN(x) asm volatile("" : "+v"(x))
@@ -427,7 +449,7 @@ __device__ __forceinline__ int t2_map3_role(T2Shared& S, const int8_t* __restric
                 // a chip boundary within 1e-7 samples of a sample somewhere in this wave: exact search with the exact
                 // linspace steps (posted by the DLL wave right after the barrier)
                 int budget = 1 << 20;
-                while (C.xflag != it + 1 && --budget) __builtin_amdgcn_s_sleep(1);
+                while (lds_peek(&C.xflag) != it + 1 && --budget) __builtin_amdgcn_s_sleep(1);
                 const double stpE = C.stp[0], stpP = C.stp[1], stpL = C.stp[2];
                 ramp_setup(startE, stpE, inv_step, gilo, kE, swE);
                 ramp_setup(startP, stpP, inv_step, gilo, kP, swP);
@@ -562,7 +584,7 @@ __device__ __forceinline__ int t2_map3_role(T2Shared& S, const int8_t* __restric
                 const double t = __builtin_fma(v, t2_fix_of<SB>(P, n_units), T2_MAGIC);
                 const unsigned long long q = (unsigned long long)(__double_as_longlong(t) - __double_as_longlong(T2_MAGIC));
                 const unsigned long long gran = ((unsigned long long)((unsigned)(it + 1) & 0xFFFFu) << 48) | (q & 0xFFFFFFFFFFFFull);
-                granule_store(xbase + T2_XG + par * 96 + word * 16 + member, gran, fast);
+                granule_store(xbase + T2_XG + (par * 6 + word) * T2_XLINE + member, gran, fast);
             }
             if (prof_any && lane == 0) S.tpub[par] = (long long)__builtin_amdgcn_s_memtime();
         }
@@ -667,7 +689,7 @@ __device__ __forceinline__ int t2_map1_role(T2Shared& S, const int8_t* __restric
             // a chip boundary within 1e-7 samples of a sample somewhere in this wave (or a chip outside the window):
             // exact search with the exact linspace step (posted by the DLL wave right after the barrier), chips from LDS
             int budget = 1 << 20;
-            while (C.xflag != it + 1 && --budget) __builtin_amdgcn_s_sleep(1);
+            while (lds_peek(&C.xflag) != it + 1 && --budget) __builtin_amdgcn_s_sleep(1);
             ramp_setup(sp.y, C.stp[arm], inv_step, ilo, k1, isw);
             bits = chip_bits2(S.cbits, k1);
         } else {
@@ -736,7 +758,7 @@ __device__ __forceinline__ int t2_map1_role(T2Shared& S, const int8_t* __restric
                 if constexpr (SB == 2) tot = (unsigned long long)((((long long)(tot << 12) >> 12) + 16) >> 5);
                 S.acc[par][lane & 1] = 0ull;
                 const unsigned long long gran = ((unsigned long long)((unsigned)(it + 1) & 0xFFFFu) << 48) | (tot & 0xFFFFFFFFFFFFull);
-                granule_store(xbase + T2_XG + par * 96 + (wbase + (lane & 1)) * 16 + unit, gran, fast);
+                granule_store(xbase + T2_XG + (par * 6 + wbase + (lane & 1)) * T2_XLINE + unit, gran, fast);
                 if (prof_any && (lane & 1) == 0) S.tpub[par] = (long long)__builtin_amdgcn_s_memtime();
             }
         }
@@ -812,7 +834,7 @@ __device__ __forceinline__ int t2_pll_role(T2Shared& S, const TrkConst& K, const
                 R[12] = r_nco;
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
-            if (lane == 0) *(volatile int*)&S.rflag[0] = it;
+            if (lane == 0) lds_poke(&S.rflag[0], it);
         }
         if (hd.y) break;
         T2_FP_TOP
@@ -836,25 +858,44 @@ __device__ __forceinline__ int t2_pll_role(T2Shared& S, const TrkConst& K, const
         t2_carr_entry(c_hi, c_lo, inv_2pi, w_cur, rc, mi, w3, cs_p, sn_p);
         T2_PIN(cs_p); T2_PIN(sn_p); T2_PIN(mf); T2_PIN(rc);   // (keeps all of this ahead of the wait)
         __builtin_amdgcn_s_setprio(3);
-        const unsigned long long* gp = xbase + T2_XG + par * 96 + (lane & 31);
+        const unsigned long long* gp = xbase + T2_XG + (par * 6 + ((lane >> 4) & 1)) * T2_XLINE + (lane & 15);
         const unsigned long long tag = (unsigned long long)((unsigned)(it + 1) & 0xFFFFu);
         unsigned long long x = 0;
         int budget = T2_POLL_BUDGET;
         bool gave_up = false;
+#ifdef T2_POLL2
+        {   // two polls in flight, half a round trip apart
+            unsigned long long xa_ = 0, xb_ = 0;
+            if (mine) xa_ = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (;;) {
+                if (mine) xb_ = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all(!mine || (xa_ >> 48) == tag)) { x = xa_; break; }
+                if (mine) xa_ = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all(!mine || (xb_ >> 48) == tag)) { x = xb_; break; }
+                if ((--budget & 31) == 0) {
+                    if (budget == 0 || lds_peek(&S.flag[1]) != 0) {
+                        gave_up = true;
+                        break;
+                    }
+                }
+            }
+        }
+#else
         for (;;) {
             if (mine) x = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (__all(!mine || (x >> 48) == tag)) break;
             if ((--budget & 31) == 0) {
-                if (budget == 0 || *(volatile int*)&S.flag[1] != 0) {
+                if (budget == 0 || lds_peek(&S.flag[1]) != 0) {
                     gave_up = true;
                     break;
                 }
             }
         }
+#endif
         T2STAMP(prof_on, 8);   // waiting for the sums
         if (prof) {
             t_arr = (long long)__builtin_amdgcn_s_memtime();
-            const long long tp = *(volatile long long*)&S.tpub[par];
+            const long long tp = lds_peek64(&S.tpub[par]);
             acc_map += tp - t_top;       // barrier release -> this member's publish
             acc_xch += t_arr - tp;       // this member's publish -> every member's sums visible
         }
@@ -921,7 +962,7 @@ __device__ __forceinline__ int t2_pll_role(T2Shared& S, const TrkConst& K, const
             R[12] = r_nco;
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
-        if (lane == 0) *(volatile int*)&S.rflag[0] = it;
+        if (lane == 0) lds_poke(&S.rflag[0], it);
     }
     if (prof && lane == 0) {
         prof[ch * T2_PROF_STRIDE + mslot] = acc_map;
@@ -986,7 +1027,7 @@ __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const
                 R[10] = r_nco;
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
-            if (lane == 0) *(volatile int*)&S.rflag[1] = it;
+            if (lane == 0) lds_poke(&S.rflag[1], it);
         }
         if (stop) break;
         T2_FP_TOP
@@ -1007,7 +1048,7 @@ __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const
         else stp = d / nb;
         if (lane < 3) C.stp[lane] = stp;
         __builtin_amdgcn_s_waitcnt(0xc07f);
-        if (lane == 0) C.xflag = it + 1;
+        if (lane == 0) lds_poke(&C.xflag, it + 1);
         // code phase and first sample of the next block (T4) and that block's ramp starts
         const double t_last = ramp_at(blk - 1, stp, start);
         const double rn_lane = (t_last + step) - 1023.0;                            // meaningful in the prompt lane
@@ -1025,11 +1066,30 @@ __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const
         unsigned lim = (unsigned)(lim1 < lim3 ? lim1 : lim3);
         T2_PIN(a_next); T2_PIN(lim);
         __builtin_amdgcn_s_setprio(3);
-        const unsigned long long* gp = xbase + T2_XG + par * 96 + 32 + lane;
+        const unsigned long long* gp = xbase + T2_XG + (par * 6 + 2 + (lane >> 4)) * T2_XLINE + (lane & 15);
         const unsigned long long tag = (unsigned long long)((unsigned)(it + 1) & 0xFFFFu);
         unsigned long long x = 0, xa = 0;
         int budget = T2_POLL_BUDGET;
         bool gave_up = false;
+#ifdef T2_POLL2
+        {
+            unsigned long long xa_ = 0, xb_ = 0;
+            if (mine) xa_ = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (;;) {
+                if (mine) xb_ = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all(!mine || (xa_ >> 48) == tag)) { x = xa_; break; }
+                if (mine) xa_ = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all(!mine || (xb_ >> 48) == tag)) { x = xb_; break; }
+                if ((--budget & 15) == 0) {
+                    xa = __hip_atomic_load(xabort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (xa != 0 || budget == 0) {
+                        gave_up = true;
+                        break;
+                    }
+                }
+            }
+        }
+#else
         for (;;) {
             if (mine) x = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (__all(!mine || (x >> 48) == tag)) break;
@@ -1041,6 +1101,7 @@ __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const
                 }
             }
         }
+#endif
         T2STAMP(prof_on, 12);  // waiting for the sums
         // T8 DLL (tracking.py:238-251).  Row r of the wave holds the units' payloads of I_E | Q_E | I_L | Q_L: integer
         // row sums (exact, order-free; lanes that poll nothing hold 0), every lane of a row then has its row's total.
@@ -1109,7 +1170,7 @@ __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const
             R[10] = r_nco;
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
-        if (lane == 0) *(volatile int*)&S.rflag[1] = it;
+        if (lane == 0) lds_poke(&S.rflag[1], it);
     }
     T2_FP_PRINT(prof_on && lane == 0, 12, 16)
     return it;
@@ -1119,7 +1180,7 @@ __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const
 // Stores block k's 13 series values once both filter waves have posted them (rflag >= k + 1): one block behind.
 __device__ __forceinline__ void t2_rec_store(T2Shared& S, int k, long long m, int lane, double* __restrict__ o) {
     int budget = 1 << 16;
-    while ((*(volatile int*)&S.rflag[0] < k + 1 || *(volatile int*)&S.rflag[1] < k + 1) && --budget) __builtin_amdgcn_s_sleep(2);
+    while ((lds_peek(&S.rflag[0]) < k + 1 || lds_peek(&S.rflag[1]) < k + 1) && --budget) __builtin_amdgcn_s_sleep(2);
     if (lane < SGX_NUM_SERIES) o[lane * m + k] = S.rec[k & 1][lane];
 }
 
