@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--ms", type=int, default=37000, help="code periods tracked (default: full config)")
     ap.add_argument("--channels", type=int, default=8, help="tracking channels per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--many-channels", type=int, default=2048,
+    ap.add_argument("--many-channels", type=int, default=3072,
                     help="extra leg at N=1: channels of the many-channel (bandwidth-regime) tracking run, 0 = skip")
     ap.add_argument("--many-ms", type=int, default=500)
     ap.add_argument("--concurrent", type=int, default=3,

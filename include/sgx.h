@@ -204,6 +204,7 @@ int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset,
  * and samplingFreq >= 16 x codeFreqBasis, otherwise SGX_E_ARG. */
 #define SGX_DT_INT8  0
 #define SGX_DT_INT16 1
+#define SGX_DT_UINT8 2   /* offset-binary bytes as the reference reads them with dataType 'uint8': no offset is removed */
 int sgx_track_ex(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset,
                  const sgx_chan_init* ch, int32_t n_ch, int32_t ms,
                  double* out, int32_t* ms_done, int32_t data_type);

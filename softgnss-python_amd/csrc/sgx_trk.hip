@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void trk_fill_kernel(double* __restrict__ out,
 // (tracking.py:107, 255); so a two-byte channel may start on an odd byte - its samples then straddle the file's - and
 // the kernel follows it there (per-channel byte shift of the record pointer, unaligned 16-byte loads).
 static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const sgx_chan_init* ch, int32_t n_ch,
-                      int32_t ms, double* out, int32_t* ms_done, int sample_bytes) {
+                      int32_t ms, double* out, int32_t* ms_done, int sample_bytes, bool sample_uns) {
     SGX_CHECK_ARG(c && r && ch && out && ms_done);
     SGX_CHECK_ARG(n_ch >= 1 && n_ch <= 65535 && ms >= 1);
     if (!(c->s.dllCorrelatorSpacing > 0.0 && c->s.dllCorrelatorSpacing < 1.0)) {
@@ -89,7 +89,7 @@ static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
     // 16 consecutive samples span 15 code-phase steps: below one chip (with margin for the code NCO's excursions)
     // a group holds at most one switch per ramp, which the fast map relies on
     K.multi = (15.0 * 1.001 * S.codeFreqBasis / S.samplingFreq >= 1.0) ? 1 : 0;
-    K.pad_ = 0;
+    K.uns = sample_uns ? 1 : 0;
     K.file_off = rec_file_offset;
     K.ms = ms;
     K.n_ch = n_ch;
@@ -197,11 +197,11 @@ static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
     // Which kernel: the low-rate variant when a group can hold several switches of a ramp; throughput mode for more
     // than 128 int8 channels (one workgroup per channel anyway); the latency-mode kernel otherwise - with one workgroup
     // per (unit, correlator arm) when three times the CUs of one-per-unit are free (SGX_TRK_ARMS=3 keeps one per unit).
-    if (K.multi && sample_bytes != 1) {
-        sgx_set_error("two-byte samples need samplingFreq >= 16 x the chip rate (the low-rate kernel reads int8 records)");
+    if (K.multi && (sample_bytes != 1 || sample_uns)) {
+        sgx_set_error("int16 and uint8 samples need samplingFreq >= 16 x the chip rate (the low-rate kernel reads int8 records)");
         return SGX_E_ARG;
     }
-    const bool use_tp = !K.multi && sample_bytes == 1 && K.split == 1 && n_ch > 128;
+    const bool use_tp = !K.multi && sample_bytes == 1 && !sample_uns && K.split == 1 && n_ch > 128;
     const bool use_v2 = !K.multi && !use_tp;
     const char* ae = getenv("SGX_TRK_ARMS");
     const bool arm_split = use_v2 && K.split == K.n_units && K.n_units >= 2 && 3 * ch8 * K.n_units <= cus_total &&
@@ -358,14 +358,15 @@ static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
 
 extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const sgx_chan_init* ch,
                          int32_t n_ch, int32_t ms, double* out, int32_t* ms_done) {
-    return track_impl(c, r, rec_file_offset, ch, n_ch, ms, out, ms_done, 1);
+    return track_impl(c, r, rec_file_offset, ch, n_ch, ms, out, ms_done, 1, false);
 }
 
 extern "C" int sgx_track_ex(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const sgx_chan_init* ch,
                             int32_t n_ch, int32_t ms, double* out, int32_t* ms_done, int32_t data_type) {
-    if (data_type != SGX_DT_INT8 && data_type != SGX_DT_INT16) {
-        sgx_set_error("sgx_track_ex: data_type %d (SGX_DT_INT8 = 0 and SGX_DT_INT16 = 1 are tracked)", (int)data_type);
+    if (data_type != SGX_DT_INT8 && data_type != SGX_DT_INT16 && data_type != SGX_DT_UINT8) {
+        sgx_set_error("sgx_track_ex: data_type %d (SGX_DT_INT8 = 0, SGX_DT_INT16 = 1 and SGX_DT_UINT8 = 2 are tracked)", (int)data_type);
         return SGX_E_ARG;
     }
-    return track_impl(c, r, rec_file_offset, ch, n_ch, ms, out, ms_done, data_type == SGX_DT_INT16 ? 2 : 1);
+    return track_impl(c, r, rec_file_offset, ch, n_ch, ms, out, ms_done, data_type == SGX_DT_INT16 ? 2 : 1,
+                      data_type == SGX_DT_UINT8);
 }

@@ -72,9 +72,9 @@ __device__ __forceinline__ constexpr double t2_fix() { return SB == 1 ? T2_FIX :
 // ... when a member owns ceil(n_units / P) units its sum can be that many times larger: the scale drops by the next
 // power of two (exact), so the 48-bit payload still holds it
 template <int SB>
-__device__ __forceinline__ double t2_fix_of(int P, int n_units) {
+__device__ __forceinline__ double t2_fix_of(int P, int n_units, bool uns) {
     const int u = (n_units + P - 1) / P;
-    const int sh = (u <= 1) ? 0 : (32 - __builtin_clz((unsigned)(u - 1)));
+    const int sh = ((u <= 1) ? 0 : (32 - __builtin_clz((unsigned)(u - 1)))) + (uns ? 1 : 0);   // (bytes up to 255: one bit)
     return __hiloint2double(__double2hiint(t2_fix<SB>()) - (sh << 20), 0);
 }
 #define T2_MAGIC 6755399441055744.0   // 1.5 * 2^52: fl(x + MAGIC) holds round(x) in its low mantissa bits
@@ -326,13 +326,14 @@ __device__ __forceinline__ T2Raw<SB> t2_load(const int8_t* __restrict__ rec, lon
     return r;
 }
 
-// sample b of a lane's 16 as an integer
+// sample b of a lane's 16 as an integer; uns: one-byte samples are unsigned (dataType 'uint8')
 template <int SB>
-__device__ __forceinline__ int t2_sample(const T2Raw<SB>& raw, int b) {
+__device__ __forceinline__ int t2_sample(const T2Raw<SB>& raw, int b, bool uns) {
     if constexpr (SB == 1) {
         const unsigned w = (b < 4) ? raw.a.x : (b < 8) ? raw.a.y : (b < 12) ? raw.a.z : raw.a.w;
         const int sh = 8 * (b & 3);
-        return (sh == 24) ? ((int)w >> 24) : (int)(signed char)((w >> sh) & 0xFF);
+        const int sx = (sh == 24) ? ((int)w >> 24) : (int)(signed char)((w >> sh) & 0xFF);
+        return uns ? (sx & 0xFF) : sx;
     } else {
         const uint4& q = (b < 8) ? raw.a : raw.b;
         const int bb = b & 7;
@@ -343,18 +344,18 @@ __device__ __forceinline__ int t2_sample(const T2Raw<SB>& raw, int b) {
 
 // 16 samples -> fp64, samples before the block's first one (i0 + b < 0) zeroed
 template <int SB>
-__device__ __forceinline__ void t2_convert(const T2Raw<SB>& raw, int i0, double (&xd)[16]) {
+__device__ __forceinline__ void t2_convert(const T2Raw<SB>& raw, int i0, bool uns, double (&xd)[16]) {
 #pragma unroll
-    for (int b = 0; b < 16; ++b) xd[b] = (i0 + b >= 0) ? (double)t2_sample<SB>(raw, b) : 0.0;
+    for (int b = 0; b < 16; ++b) xd[b] = (i0 + b >= 0) ? (double)t2_sample<SB>(raw, b, uns) : 0.0;
 }
 
 // 16 samples -> the HIGH dwords of their fp64 values (small integers: the low dword is zero); samples outside the
 // block [0, cut) are zeroed
 template <int SB>
-__device__ __forceinline__ void t2_convert_hi(const T2Raw<SB>& raw, int i0, int cut, unsigned (&xh)[16]) {
+__device__ __forceinline__ void t2_convert_hi(const T2Raw<SB>& raw, int i0, int cut, bool uns, unsigned (&xh)[16]) {
 #pragma unroll
     for (int b = 0; b < 16; ++b) {
-        const unsigned hi = (unsigned)__double2hiint((double)t2_sample<SB>(raw, b));
+        const unsigned hi = (unsigned)__double2hiint((double)t2_sample<SB>(raw, b, uns));
         xh[b] = ((unsigned)(i0 + b) < (unsigned)cut) ? hi : 0u;
     }
 }
@@ -365,7 +366,7 @@ __device__ __forceinline__ void t2_convert_hi(const T2Raw<SB>& raw, int i0, int 
 // are loaded and converted one block ahead; further units are loaded and converted when their turn comes.
 template <int SB>
 __device__ __forceinline__ int t2_map3_role(T2Shared& S, const int8_t* __restrict__ rec, long long rec_alloc, int ms,
-                                            long long pos0, int member, int P, int n_units, int tid,
+                                            long long pos0, int member, int P, int n_units, bool uns, int tid,
                                             unsigned long long* __restrict__ xbase, bool fast, bool prof_on, bool prof_any) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -399,7 +400,7 @@ __device__ __forceinline__ int t2_map3_role(T2Shared& S, const int8_t* __restric
         i0 = g * 16 - head_;                                                                                   \
         ilo = i0 < 0 ? 0 : i0;                                                                                 \
         ilod = (double)ilo;                                                                                    \
-        t2_convert<SB>(raw, i0, xd);                                                                           \
+        t2_convert<SB>(raw, i0, uns, xd);                                                                           \
         blk_pred = (BLK_PRED);                                                                                 \
         T2_CUT(xd, i0, blk_pred);                                                                              \
     } while (0)
@@ -433,7 +434,7 @@ __device__ __forceinline__ int t2_map3_role(T2Shared& S, const int8_t* __restric
             // end convert their bytes again and cut them at the real length
             const int lo_ = blk < blk_pred ? blk : blk_pred, hi_ = blk < blk_pred ? blk_pred : blk;
             if (__any(i0 < hi_ && i0 + 16 > lo_)) {
-                t2_convert<SB>(raw, i0, xd);
+                t2_convert<SB>(raw, i0, uns, xd);
                 T2_CUT(xd, i0, blk);
             }
         }
@@ -536,7 +537,7 @@ __device__ __forceinline__ int t2_map3_role(T2Shared& S, const int8_t* __restric
             if (j0 >= blk) break;                              // (uniform: the whole unit lies beyond the block)
             const T2Raw<SB> rj = t2_load<SB>(rec, (pos & ~15ll) + (long long)gj * 16, limit);
             double xj[16];
-            t2_convert<SB>(rj, j0, xj);
+            t2_convert<SB>(rj, j0, uns, xj);
             T2_CUT(xj, j0, blk);
             group(xj, j0, j0, (double)j0, CR.T[T2_W3 + j]);   // (j0 > 0: only the block's very first group starts before it)
         }
@@ -581,7 +582,7 @@ __device__ __forceinline__ int t2_map3_role(T2Shared& S, const int8_t* __restric
                 // {16-bit epoch tag | 48-bit two's-complement fixed point}, ONE aligned 8-byte store.  A member that
                 // owns several units can hold more than 2^19 (2^28): the scale drops by the number of units, rounded up
                 // to a power of two, and the reader's scale with it (t2_fix_of).
-                const double t = __builtin_fma(v, t2_fix_of<SB>(P, n_units), T2_MAGIC);
+                const double t = __builtin_fma(v, t2_fix_of<SB>(P, n_units, uns), T2_MAGIC);
                 const unsigned long long q = (unsigned long long)(__double_as_longlong(t) - __double_as_longlong(T2_MAGIC));
                 const unsigned long long gran = ((unsigned long long)((unsigned)(it + 1) & 0xFFFFu) << 48) | (q & 0xFFFFFFFFFFFFull);
                 granule_store(xbase + T2_XG + (par * 6 + word) * T2_XLINE + member, gran, fast);
@@ -613,7 +614,7 @@ template <int SB>
 __device__ __forceinline__ int t2_map1_role(T2Shared& S, const int8_t* __restrict__ rec, long long rec_alloc, int ms,
                                             long long pos0, int unit, int arm, int tid,
                                             unsigned long long* __restrict__ xbase, bool fast, double step_nom, double spacing,
-                                            bool prof_on, bool prof_any) {
+                                            bool uns, bool prof_on, bool prof_any) {
     const int lane = tid & 63;
     const long long limit = rec_alloc - 16;                  // bytes: the last 16-byte word that may be loaded
     const int g = (tid & 255) + unit * T2_MAP;               // the lane's group inside the block's aligned window
@@ -652,7 +653,7 @@ __device__ __forceinline__ int t2_map1_role(T2Shared& S, const int8_t* __restric
         ilo = i0 < 0 ? 0 : i0;                                                                                 \
         ilod = (double)ilo;                                                                                    \
         blk_pred = (BLK_PRED);                                                                                 \
-        t2_convert_hi<SB>(raw, i0, blk_pred, xh);                                                              \
+        t2_convert_hi<SB>(raw, i0, blk_pred, uns, xh);                                                              \
         ptr_pred = t2_ptr<SB>(((pos + blk_pred) & ~15ll) + lane_off, limit);                                  \
         T2_PIN(ilod);                                                                                          \
         asm volatile("" : "+v"(ptr_pred.a));                                                                   \
@@ -704,7 +705,7 @@ __device__ __forceinline__ int t2_map1_role(T2Shared& S, const int8_t* __restric
             // the block is a sample longer or shorter than predicted (about one block in ten): the lanes around its
             // end convert their bytes again and cut them at the real length
             const int lo_ = blk < blk_pred ? blk : blk_pred, hi_ = blk < blk_pred ? blk_pred : blk;
-            if (__any(i0 < hi_ && i0 + 16 > lo_)) t2_convert_hi<SB>(raw, i0, blk, xh);
+            if (__any(i0 < hi_ && i0 + 16 > lo_)) t2_convert_hi<SB>(raw, i0, blk, uns, xh);
         }
         // group-start phasor G = W1[tid & 15] * W2[(tid >> 4) & 15] * W3, times the first chip
         double gc, gs;
@@ -733,7 +734,7 @@ __device__ __forceinline__ int t2_map1_role(T2Shared& S, const int8_t* __restric
         // fixed point: the raw bits of fma(a, 2^28, 1.5 2^52) are bias + round(a 2^28); sums of them carry the sum of
         // the integers in their low 48 bits whatever the bias adds up to (sixteen biases leave the low 52 bits alone).
         // Two-byte samples: 2^24 in the lanes (a member's total needs 52 bits), rounded to the granule's 2^19 once.
-        constexpr double lane_fix = (SB == 1) ? T2_FIX : T2_FIX16 * 32.0;
+        const double lane_fix = (SB == 1) ? (uns ? T2_FIX * 0.5 : T2_FIX) : T2_FIX16 * 32.0;
         constexpr unsigned long long res_mask = (SB == 1) ? 0xFFFFFFFFFFFFull : 0xFFFFFFFFFFFFFull;
         // (three-address FMAs with the bias in a register pair: the accumulating form wants it copied in front of each)
         double tI, tQ;
@@ -807,7 +808,7 @@ __device__ __forceinline__ int t2_pll_role(T2Shared& S, const TrkConst& K, const
     T2_PIN(rk.c0); T2_PIN(rk.c1); T2_PIN(rk.c2); T2_PIN(rk.c3); T2_PIN(rk.c4); T2_PIN(rk.c5);
     // lane 0 of a row adds the bits of 1.5 2^52 to its payload: the row's integer sum then IS the double 1.5 2^52 + sum
     const int bias_hi = ((lane & 15) == 0) ? 0x43380000 : 0;
-    double unfix = 1.0 / t2_fix_of<SB>(P, K.n_units);
+    double unfix = 1.0 / t2_fix_of<SB>(P, K.n_units, K.uns != 0);
     T2_PIN(unfix);
     const bool w3 = lane >= 48;
     // lane = 16 word + unit polls that unit's granule of I_P (word 0, row 0) / Q_P (word 1, row 1)
@@ -1001,7 +1002,7 @@ __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const
     const double off = (l4 == 0) ? -D.spacing : ((l4 == 2) ? D.spacing : 0.0);   // rem - spc == rem + (-spc) exactly
     const int lim3 = K.n_units * TRK_UNIT - 15;            // the longest block the units of the launch hold
     const int bias_hi = ((lane & 15) == 0) ? 0x43380000 : 0;   // (see the PLL wave)
-    double unfix = 1.0 / t2_fix_of<SB>(P, K.n_units);
+    double unfix = 1.0 / t2_fix_of<SB>(P, K.n_units, K.uns != 0);
     T2_PIN(unfix);
     // lane = 16 row + unit polls that unit's granule of word 2 + row: rows I_E, Q_E, I_L, Q_L
     const bool mine = (lane & 15) < P;
@@ -1342,9 +1343,9 @@ __global__ __launch_bounds__(T2_THREADS) void trk2_kernel(const int8_t* __restri
     if (wave < 4) {
         if constexpr (ARMS == 1)
             done = t2_map1_role<SB>(S, rec + cc.pad, K.rec_alloc, K.ms, cc.pos0, unit, arm, tid, xbase, fast,
-                                    K.code_basis / K.fs, K.spacing, prof_on, prof != nullptr);
+                                    K.code_basis / K.fs, K.spacing, K.uns != 0, prof_on, prof != nullptr);
         else
-            done = t2_map3_role<SB>(S, rec + cc.pad, K.rec_alloc, K.ms, cc.pos0, unit, P, K.n_units, tid, xbase, fast, prof_on, prof != nullptr);
+            done = t2_map3_role<SB>(S, rec + cc.pad, K.rec_alloc, K.ms, cc.pos0, unit, P, K.n_units, K.uns != 0, tid, xbase, fast, prof_on, prof != nullptr);
     } else if (wave == 4)
         done = t2_pll_role<SB>(S, K, cc, unit, member, owner, lane, P, ch, xbase, err, prof_on, prof);
     else if (wave == 5)

@@ -53,7 +53,7 @@ struct TrkConst {
     double inv_pi;        // RN(1 / pi)
     const unsigned long long* mark;   // streaming record: bytes resident so far (device watermark), or null
     int multi;            // fewer than ~15 samples per chip: a 16-sample group can hold several chip switches
-    int pad_;
+    int uns;              // one-byte samples are unsigned (Settings.dataType 'uint8')
 };
 
 struct TrkChan {

@@ -38,7 +38,9 @@ class TrackingResult(Result):
             return _native.DT_INT8, 1
         if dt == np.dtype('<i2'):
             return _native.DT_INT16, 2
-        raise TypeError("the GPU path tracks int8 and int16 IF samples (Settings.dataType %r)"
+        if dt == np.dtype(np.uint8):
+            return _native.DT_UINT8, 1
+        raise TypeError("the GPU path tracks int8, uint8 and int16 IF samples (Settings.dataType %r)"
                         % (self._settings.dataType,))
 
     def _window(self, fid, first, need):

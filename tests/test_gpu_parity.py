@@ -1282,6 +1282,55 @@ def test_track_int16_odd_start_byte_and_short_record():
         assert (o is not None) == ok
 
 
+def test_track_uint8_record_against_the_oracle(tmp_path):
+    """Settings.dataType = 'uint8' (tracking.py:154 reads whatever numpy dtype the settings name): offset-binary bytes
+    tracked as they are - the reference removes no offset - against the oracle on the same bytes: every member layout of
+    the latency-mode kernel, through a real file (streamed) and from HBM; more channels than the throughput-mode kernel's
+    threshold stay on the latency-mode kernel (one workgroup per channel)."""
+    m = pkg()
+    ms = 60
+    s = m.Settings()
+    s.dataType = 'uint8'
+    s.numberOfChannels = 3
+    s.msToProcess = float(ms)
+    n = s.samplesPerCode
+    sc = m.synth.Scene.default()
+    rec8 = m.synth.generate(sc, m.synth.record_length(n, ms))
+    recu = (rec8.astype(np.int16) + 128).astype(np.uint8)
+    a8 = orc.acquire(orc.OracleSettings(), rec8[:11 * n])
+    ch = orc.pre_run(orc.OracleSettings(numberOfChannels=3), a8)
+    so = orc.OracleSettings(numberOfChannels=3, msToProcess=float(ms), dataType='uint8')
+    want = orc.stack_series(orc.track(so, ch, recu))
+    a = m.AcquisitionResult(s, device=0)
+    a._channels = np.rec.fromarrays([ch["PRN"], ch["acquiredFreq"], ch["codePhase"], ['T'] * 3],
+                                    names='PRN,acquiredFreq,codePhase,status')
+    path = str(tmp_path / "u8.bin")
+    recu.tofile(path)
+    t = m.TrackingResult(a, device=0)
+    with open(path, "rb") as fid:
+        t.track(fid)
+    assert np.array_equal(t.series[:, 0], want[:, 0]) and _trk_err(t.series, want) < TRK_TOL
+    ctx = m.engine.get_context(s, 0)
+    rec = ctx.upload_bytes(recu)
+    chans = [(int(ch["PRN"][i]), float(ch["acquiredFreq"][i]), float(ch["codePhase"][i])) for i in range(3)]
+    for env, members in (({}, 30), ({"SGX_TRK_SPLIT": "1"}, 1), ({"SGX_TRK_SPLIT": "3"}, 3), ({"SGX_TRK_ARMS": "3"}, 10)):
+        os.environ.update(env)
+        try:
+            s2, d2 = ctx.track(rec, chans, ms, data_type=m._native.DT_UINT8)
+        finally:
+            for k in env:
+                os.environ.pop(k)
+        assert ctx.timing()["track_members"] == members and np.all(d2 == ms)
+        assert np.array_equal(s2[:, 0], want[:, 0]) and _trk_err(s2, want) < TRK_TOL
+    many, dm = ctx.track(rec, chans * 50, 20, data_type=m._native.DT_UINT8)
+    tm = ctx.timing()
+    assert tm["track_kernel"] == 2 and tm["track_members"] == 1 and np.all(dm == 20)
+    assert np.array_equal(many[:3, 0], want[:, 0, :20]) and _trk_err(many[:3], want[:, :, :20]) < TRK_TOL
+    s.dataType = 'float32'
+    with pytest.raises(TypeError, match="int8, uint8 and int16"):
+        m.TrackingResult(a, device=0).track(open(path, "rb"))
+
+
 @pytest.mark.parametrize("seed", list(range(31, 43)))
 def test_random_front_ends_and_scenes_against_oracle(seed):
     """Random sampling rate (other FFT factorisations: 26 000 = 2^4 5^3 13, 20 460 = 2^2 3 5 11 31, 12 276 =

@@ -98,15 +98,16 @@ def main():
         insts = biggest(valu_db, "SQ_INSTS_VALU", "trk_kernel_tp")
         gui = biggest(grbm_db, "GRBM_GUI_ACTIVE", "trk_kernel_tp")
         hbm = 2.0 * f_tp + w_tp
-        samples = 2048 * 500 * 38192.0
+        n_many = int(os.environ.get("SGX_MANY_CHANNELS", "3072"))      # bench.py's --many-channels default
+        samples = n_many * 500 * 38192.0
         # SQ_ACTIVE_INST_VALU counts quad-cycles summed over SIMDs; GRBM_GUI_ACTIVE cycles summed over the 8 XCDs
         valu_busy = act * 4.0 / 1024.0 / (gui / 8.0)
-        json.dump({"kernel": "trk_kernel_tp", "workload": {"channels": 2048, "ms": 500},
+        json.dump({"kernel": "trk_kernel_tp", "workload": {"channels": n_many, "ms": 500},
                    "fetch_size_raw_bytes_per_launch": f_tp, "write_size_raw_bytes_per_launch": w_tp, "correction": corr,
                    "hbm_bytes_per_launch": hbm, "valu_busy_frac": valu_busy,
                    "valu_insts_per_sample": insts * 64.0 / samples,
                    "valu_formula": "SQ_ACTIVE_INST_VALU * 4 / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs); "
-                                   "SQ_INSTS_VALU * 64 lanes / (2048 channels * 500 ms * 38192 samples)",
+                                   "SQ_INSTS_VALU * 64 lanes / (channels * 500 ms * 38192 samples)",
                    "bound": "valu"},
                   open(os.path.join(dst, "%s_pmc_trk_tp.json" % tag), "w"), indent=1)
     # ---- acquisition: all kernels of one call ----
