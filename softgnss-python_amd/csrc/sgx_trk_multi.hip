@@ -1,8 +1,7 @@
 // The cooperative tracking kernel for low sampling rates (fewer than ~15 samples per chip, e.g. 5.456 or 4.092
-// Msps): a 16-sample group can then hold several chip switches of a code ramp, which the fast map of
-// sgx_trk_kernel.inc excludes by construction, so this variant indexes the replicas sample by sample like the
-// reference (tracking.py:166-188).  A translation unit of its own so that the default kernel's code generation
-// is untouched (a run-time branch in the shared body cost the default kernel 11 %).
+// Msps): a 16-sample group can then hold several chip switches of a code ramp, which the maps of sgx_trk2.hip
+// exclude by construction, so this kernel indexes the replicas sample by sample like the reference
+// (tracking.py:166-188).  int8 records; members own units c, c + split, ... (split <= 10).
 #include "sgx_trk_common.h"
 
 #define TRK_MULTI 1

@@ -189,6 +189,10 @@ class Settings(object):
         name = self.fileName if not fileNameStr else fileNameStr
         if not isinstance(name, str):
             raise TypeError('File name must be a string')
+        if self.skipAcquisition:
+            # (the reference then reads acqResults before anything assigned it: NameError, initialize.py:476,490)
+            raise ValueError('skipAcquisition is set, but there are no acquisition results to reuse: '
+                             'postProcessing() always acquires (initialize.py:476-490)')
         with open(name, 'rb') as fid:
             fid.seek(self.skipNumberOfBytes, 0)
             data = np.fromfile(fid, self.dataType, 11 * self.samplesPerCode)

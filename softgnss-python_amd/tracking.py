@@ -22,7 +22,10 @@ RESULT_DTYPE = [('status', 'S1'), ('absoluteSample', 'object'), ('codeFreq', 'ob
 
 
 class TrackingResult(Result):
-    def __init__(self, acqResult, device=None):
+    def __init__(self, acqResult, device=None, verbose=False):
+        """verbose: print the reference's progress lines (tracking.py:137-143: one per channel and 50 ms) - after the
+        kernel has finished; the GPU is never synchronised every 50 ms to print."""
+        self._verbose = verbose
         self._results = None
         self._channels = acqResult.channels
         self._settings = acqResult.settings
@@ -104,6 +107,11 @@ class TrackingResult(Result):
             print('Not able to read the specified number of samples for tracking, exiting!')
             fid.close()
             return None
+        if self._verbose:
+            for j, i in enumerate(active):
+                for k in range(0, ms, 50):
+                    print('Tracking: Ch %d' % (i + 1) + ' of %d' % nch + '; PRN#%02d' % int(channel[i].PRN) +
+                          '; Completed %d' % k + ' of %d' % ms + ' msec')
         fid.seek(int(series[-1, 0, ms - 1]), 0)    # where the reference's last read left the file
         self.series = series
         res = np.recarray((len(active),), dtype=RESULT_DTYPE)

@@ -92,6 +92,11 @@ def test_settings_surface_matches_reference(built):
         r.results
     with pytest.raises(AssertionError):
         r.results = [1, 2, 3]
+    # skipAcquisition=True makes the reference read acquisition results nothing assigned (NameError,
+    # initialize.py:476-490); here: a clean error before any file is opened
+    s.skipAcquisition = True
+    with pytest.raises(ValueError, match="skipAcquisition"):
+        s.postProcessing("/nonexistent/record.bin")
 
 
 def test_no_gpu_means_loud_failure(built):

@@ -189,6 +189,27 @@ def test_track_golden_via_real_file(default_record):
     assert np.array_equal(r[2].I_P, got[2, 3])
 
 
+def test_track_progress_lines_behind_verbose(default_record, capsys):
+    """The reference prints a progress line per channel and 50 ms (tracking.py:137-143); offered behind verbose=True,
+    printed after the kernel has finished."""
+    g = load_golden("trk_default.npz")
+    m = pkg()
+    s, t0 = _golden_tracker(m, g)
+    s.msToProcess = 120.0
+    ctx = m.engine.get_context(s, 0)
+    rec = ctx.upload(default_record)
+    t = m.TrackingResult(t0, device=0, verbose=True)
+    capsys.readouterr()
+    t.track(m.DeviceFile(rec))
+    out = capsys.readouterr().out
+    n_act = int(np.sum(t0.channels.PRN != 0))
+    assert out.count("Tracking: Ch ") == 3 * n_act
+    assert "Tracking: Ch 1 of %d; PRN#%02d; Completed 100 of 120 msec" % (s.numberOfChannels, int(t0.channels.PRN[0])) in out
+    t2 = m.TrackingResult(t0, device=0)
+    t2.track(m.DeviceFile(rec))
+    assert "Tracking: Ch" not in capsys.readouterr().out
+
+
 def test_track_device_file_equals_host_file(default_record):
     g = load_golden("trk_default.npz")
     m, s0, ctx = _ctx()
