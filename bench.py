@@ -553,8 +553,11 @@ def many_channels_leg(pkg, ctx, rec, acq, args, read_gbs, n_code):
         shift_ms = (i // len(chans)) * max(1, span_ms // max(1, args.many_channels // len(chans))) if span_ms > 0 else 0
         many.append((prn, f, cp + shift_ms * n_code))
     ctx.track(rec, many, 20)
-    ser, dn = ctx.track(rec, many, args.many_ms)
-    t_ms = ctx.timing()["track_ms"]
+    t_ms = None
+    for _ in range(3):                                   # (kernel time by HIP events; the best of three launches)
+        ser, dn = ctx.track(rec, many, args.many_ms)
+        t = ctx.timing()["track_ms"]
+        t_ms = t if t_ms is None else min(t_ms, t)
     first = np.array([c[2] for c in many])
     b_many = float(np.sum(ser[:, 0, -1] - first)) + len(many) * args.many_ms * 13 * 8.0
     lo, hi = float(np.min(first)), float(np.max(ser[:, 0, -1]))
