@@ -23,7 +23,8 @@
 #include "sgx_trk_math.h"
 
 // Threads per workgroup (one channel) and workgroups per CU the register budget is cut for.  Measured on 2048 channels
-// x 500 ms: 256 x 2 13.8 ms; 256 x 3 (168 registers, spills) 15.3 ms; 128 x 4 (both waves busy in every phase) 15.4 ms.
+// x 500 ms: 256 x 2 13.8 ms (13.4 with the weight dwords kept in registers, which only this budget allows); 256 x 3 (168
+// registers, spills) 15.3 ms; 128 x 4 (both waves busy in every phase) 15.4 ms.
 #ifndef TP_THREADS
 #define TP_THREADS 256
 #endif
@@ -155,18 +156,18 @@ __device__ __forceinline__ int tp_dot4_first(int x, int w) {
 
 // Head and tail run of a chip (bytes beyond the runs already zero): sum_k x_k B_k of each by int8 dot products against
 // the digit dwords, the runs rotated by their start phasors, the three codes applied.
-__device__ __forceinline__ void tp_runs(const signed char (&wq)[2][4][32], const TpCarr& car, double2 gh, int tail_off,
+__device__ __forceinline__ void tp_runs(const int (&wr)[2][4][5], const TpCarr& car, double2 gh, int tail_off,
                                         const unsigned (&wh)[5], const unsigned (&wt)[5], bool e_switched, bool l_switched,
                                         double cP, double cEh, double cEn, double cLh, double cLn, double& aIE, double& aQE,
                                         double& aIP, double& aQP, double& aIL, double& aQL) {
     const double2 gt = cmul2(gh, car.B[tail_off]);
-    // weight dwords [cos, sin][digit][d]: dword d holds the digits of k = 4 d .. 4 d + 3 (broadcast LDS reads)
+    // weight dwords [cos, sin][digit][d]: dword d holds the digits of k = 4 d .. 4 d + 3; in registers for the whole block
     int hc[4], hs[4], tc[4], ts[4];
-    const int* w32 = reinterpret_cast<const int*>(&wq[0][0][0]);
 #pragma unroll
     for (int l = 0; l < 4; ++l) {
-        const int4 wc = *reinterpret_cast<const int4*>(w32 + l * 8), ws = *reinterpret_cast<const int4*>(w32 + (4 + l) * 8);
-        const int wc4 = w32[l * 8 + 4], ws4 = w32[(4 + l) * 8 + 4];
+        const int4 wc = make_int4(wr[0][l][0], wr[0][l][1], wr[0][l][2], wr[0][l][3]);
+        const int4 ws = make_int4(wr[1][l][0], wr[1][l][1], wr[1][l][2], wr[1][l][3]);
+        const int wc4 = wr[0][l][4], ws4 = wr[1][l][4];
         // (the three-address form with a literal zero: the accumulating v_dot4c would want sixteen zeroed registers)
         int a = tp_dot4_first((int)wh[0], wc.x);
         int b = tp_dot4_first((int)wh[0], ws.x);
@@ -291,21 +292,31 @@ __global__ __launch_bounds__(TP_THREADS, TP_OCC) void trk_kernel_tp(const int8_t
         unsigned wh[5], wt[5];
         tp_load_raw(rec, pos + cur.s0, wh);
         tp_load_raw(rec, pos + (cur.eE > cur.eL ? cur.eE : cur.eL), wt);
-#pragma unroll 1
-        while (have) {
-            const int cn = c + TP_THREADS;
-            const bool have_n = cn <= c_last;
-            const TpChip nxt = bounds_of(have_n ? cn : c);   // (no next chip: the current one again - an interior chip, no branch)
-            unsigned nh[5], nt[5];
-            tp_load_raw(rec, pos + nxt.s0, nh);
-            tp_load_raw(rec, pos + (nxt.eE > nxt.eL ? nxt.eE : nxt.eL), nt);
-            asm volatile("" ::: "memory");   // the weight dwords are re-read from LDS for every chip (40 registers otherwise)
-            const int s0 = cur.s0, s1 = cur.s1, eE = cur.eE, eL = cur.eL;
+        // the block's 40 weight dwords (two workgroups per CU leave 256 registers per lane: no LDS read per chip - with
+        // them re-read for every chip the kernel measured 4 % slower)
+        int wr[2][4][5];
+        {
+            const int* w32 = reinterpret_cast<const int*>(&s_wq[0][0][0]);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int l = 0; l < 4; ++l)
+#pragma unroll
+                    for (int d = 0; d < 5; ++d) wr[q][l][d] = w32[(q * 4 + l) * 8 + d];
+        }
+        // one chip: `ck` with its bytes in wh / wt (the runs, unmasked), while the next chip's bounds go to `nk` and its
+        // bytes are requested into yh / yt.  Called alternately with the two register sets swapped, so nothing is copied.
+        auto chip = [&](const TpChip& ck, int cc_, unsigned (&wh)[5], unsigned (&wt)[5], TpChip& nk, int cn_, unsigned (&yh)[5],
+                        unsigned (&yt)[5]) {
+            nk = bounds_of(cn_);
+            tp_load_raw(rec, pos + nk.s0, yh);
+            tp_load_raw(rec, pos + (nk.eE > nk.eL ? nk.eE : nk.eL), yt);
+            const int s0 = ck.s0, s1 = ck.s1, eE = ck.eE, eL = ck.eL;
             const int e1 = eE < eL ? eE : eL, e2 = eE < eL ? eL : eE;
             const int len_h = e1 - s0, len_t = s1 - e2;
             const int kE = (int)ceil(ramp_at(s0, stepE, startE));
             const int kL = (int)ceil(ramp_at(s0, stepL, startL));
-            const double cP = __hiloint2double((int)s_code_hi[c], 0);
+            const double cP = __hiloint2double((int)s_code_hi[cc_], 0);
             const double cEh = __hiloint2double((int)s_code_hi[kE], 0), cEn = __hiloint2double((int)s_code_hi[kE + 1], 0);
             const double cLh = __hiloint2double((int)s_code_hi[kL], 0), cLn = __hiloint2double((int)s_code_hi[kL + 1], 0);
             // run-start phasor of the head from the four tables
@@ -351,13 +362,21 @@ __global__ __launch_bounds__(TP_THREADS, TP_OCC) void trk_kernel_tp(const int8_t
                 }
             }
             if (by_runs)
-                tp_runs(s_wq, s_car, ghq, (e2 - s0) & 31, wh, wt, eE <= e2, eL <= e2, cP, cEh, cEn, cLh, cLn, aIE, aQE, aIP, aQP, aIL, aQL);
-            cur = nxt;
-#pragma unroll
-            for (int d = 0; d < 5; ++d) {
-                wh[d] = nh[d];
-                wt[d] = nt[d];
-            }
+                tp_runs(wr, s_car, ghq, (e2 - s0) & 31, wh, wt, eE <= e2, eL <= e2, cP, cEh, cEn, cLh, cLn, aIE, aQE, aIP, aQP, aIL, aQL);
+        };
+        TpChip nxt;
+        unsigned nh[5], nt[5];
+#pragma unroll 1
+        while (have) {
+            int cn = c + TP_THREADS;
+            bool have_n = cn <= c_last;
+            chip(cur, c, wh, wt, nxt, have_n ? cn : c, nh, nt);   // (no next chip: the current one again - an interior chip, no branch)
+            c = cn;
+            have = have_n;
+            if (!have) break;
+            cn = c + TP_THREADS;
+            have_n = cn <= c_last;
+            chip(nxt, c, nh, nt, cur, have_n ? cn : c, wh, wt);
             c = cn;
             have = have_n;
         }
