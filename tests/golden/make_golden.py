@@ -14,7 +14,7 @@ reference's outputs as small .npz fixtures next to this file (SURVEY.md section 
         geo    geo_cases.npz       satpos, leastSquarePos, cart2geo, findUtmZone, cart2utm and helpers
         nav    nav_preambles.npz   track 2 x 10 s + findPreambles + calculatePseudoranges
         fix    fix_scene.npz       acquire + track 6 x 37 s + postNavigate on the consistent scene (~12 min)
-    (codes, acq_*, trk_*, rate2 come from the default run.)
+    (codes, acq_*, trk_*, rate2 come from the default run, which also rewrites every part above.)
 """
 import importlib
 import io
