@@ -474,6 +474,9 @@ int sgx_fft_forward_fused(const FftPlan* p, cplx* a, cplx* b, int64_t rows, hipS
 // The first kernel can form the correlation product conj(X_b[(i + shift) mod n]) * F_prn[i] on load; the circular
 // shift is how one forward spectrum serves every Doppler bin that differs from it by whole output bins.
 
+#define F4W_N1 217
+#define F4W_N2 176
+
 struct F4Args {
     const cplx* in;
     cplx* out;
@@ -753,6 +756,185 @@ __global__ __launch_bounds__(TPB) void fft4_cols_kernel(F4Args a) {
     }
 }
 
+// The columns kernel of the 217 x 176 transform with TWO WAVES per tile of 8 columns (round 3).  The four-wave kernel
+// above is bound by instruction issue (about 1 200 instructions per wave and tile, 4 800 per tile): the 56 radix-31
+// butterflies of a tile fill one wave, so splitting each over four waves repeats their input side (31 LDS reads, 30
+// twiddle products, 60 sums) four times, and the staging of the tile through LDS in front of the first pass and behind
+// the last one costs an LDS access and a wait per element.  Here
+//   217 = 31 a + b on the way in, c + 7 d on the way out:  X[c + 7 d] = sum_b W_31^(b d) W_217^(b c) sum_a x[31 a + b] W_7^(a c)
+//   stage 1   lane (column, b) loads its seven inputs x[31 a + b] straight from memory (forming the correlation product
+//             on the way), runs the 7-point transform in registers and writes Y[c][b] W_217^(b c) to LDS: four rounds
+//             of 8 b's, two per wave;
+//   stage 2   lane (column, c) (56 of 64) reads its 31 values, runs the 31-point transform in registers - the roots in
+//             scalar registers, outputs in pairs (d, 31 - d), the odd d in one wave and the even d in the other - and
+//             stores each output times W_n^(n2 (c + 7 d)) where it belongs, the factors by two recurrences (up from
+//             d = 0, down from d = 31).
+// About 2 700 instructions per tile; 27 KB of LDS: five workgroups = ten waves per CU (ONE wave per tile measured 340 us
+// for the 1 856 rows of config 2 against 390-415 for the four-wave kernel: five waves per CU leave every SIMD waiting on
+// its own dependent instructions).
+template <int PART>
+__device__ __forceinline__ void f4w_stage2(const double (&wc)[15], const double (&wsn)[15], const cplx* __restrict__ y,
+                                           cplx w0, cplx ws, cplx wN, cplx* __restrict__ out, unsigned o0) {
+    constexpr int C = 8, N2 = F4W_N2, R = 31, H = 15;
+    constexpr int NP = PART == 0 ? 8 : 7;   // this wave's output pairs (d, 31 - d): d = 1 + PART, 3 + PART, ...
+    const cplx v0 = y[0];
+    cplx sa[H], sb[H];
+#pragma unroll
+    for (int q = 1; q <= H; ++q) {
+        const cplx x = y[q * C], z = y[(R - q) * C];
+        sa[q - 1] = cadd(x, z);
+        sb[q - 1] = csub(x, z);
+    }
+    if (PART == 0) {
+        cplx s0 = v0;
+#pragma unroll
+        for (int q = 0; q < H; ++q) s0 = cadd(s0, sa[q]);
+        out[o0] = cmul(s0, w0);
+    }
+    // output factors W_n^(n2 (c + 7 d)) by steps of ws^2: up from d = 1 + PART, down from d = 30 - PART
+    const cplx ws2 = cmul(ws, ws);
+    const cplx first = PART == 0 ? ws : ws2;
+    cplx up = cmul(w0, first);
+    cplx dn = cmul(cmul(w0, wN), make_double2(first.x, -first.y));
+    const cplx ws2c = make_double2(ws2.x, -ws2.y);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int k = 1 + PART + 2 * i;
+        double pr = v0.x, pi = v0.y, qr = 0.0, qi = 0.0;
+#pragma unroll
+        for (int q = 1; q <= H; ++q) {
+            const int m0 = (q * k) % R;
+            const bool lowhalf = m0 <= H;
+            const int m = lowhalf ? m0 : R - m0;
+            const double sy = lowhalf ? wsn[m - 1] : -wsn[m - 1];
+            pr = __builtin_fma(sa[q - 1].x, wc[m - 1], pr);
+            pi = __builtin_fma(sa[q - 1].y, wc[m - 1], pi);
+            qr = __builtin_fma(sb[q - 1].y, -sy, qr);
+            qi = __builtin_fma(sb[q - 1].x, sy, qi);
+        }
+        if (i > 0) {
+            up = cmul(up, ws2);
+            dn = cmul(dn, ws2c);
+        }
+        out[o0 + (unsigned)(7 * k * N2)] = cmul(make_double2(pr + qr, pi + qi), up);
+        out[o0 + (unsigned)(7 * (R - k) * N2)] = cmul(make_double2(pr - qr, pi - qi), dn);
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(128) void fft4_cols217_kernel(F4Args a) {
+    constexpr int N1 = F4W_N1, N2 = F4W_N2, C = 8;
+    __shared__ cplx buf[N1 * C];   // [c][b][column]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = lane & 7, g = lane >> 3;
+    const int c0 = blockIdx.x * C;
+    const long long row = blockIdx.y;
+    const int n2 = c0 + col;
+    // output factors: W_n^(n2 c), the step W_n^(7 n2) and W_n^(217 n2) (stage 2's lane: c = g)
+    const int lo_mask = (1 << a.lo_bits) - 1;
+    const int t0 = n2 * (g < 7 ? g : 0), t7 = 7 * n2, t217 = N1 * n2;
+    const cplx h0 = a.tw_hi[t0 >> a.lo_bits], l0 = a.tw_lo[t0 & lo_mask];
+    const cplx h7 = a.tw_hi[t7 >> a.lo_bits], l7 = a.tw_lo[t7 & lo_mask];
+    const cplx hN = a.tw_hi[t217 >> a.lo_bits], lN = a.tw_lo[t217 & lo_mask];
+    // the radix-31 roots: read HERE, in front of the barrier and the stores, where the compiler still takes them
+    // through the scalar cache into scalar registers (behind those it loads them per lane: sixty vector registers)
+    double wc31[15], ws31[15];
+    {
+        const cplx* __restrict__ wr = a.wr[1];
+#pragma unroll
+        for (int m = 1; m <= 15; ++m) {
+            wc31[m - 1] = wr[m].x;
+            ws31[m - 1] = wr[m].y;
+        }
+    }
+    const cplx* __restrict__ in = a.in + row * a.n;
+    const cplx* __restrict__ px = nullptr;
+    const cplx* __restrict__ pf = nullptr;
+    int shift = 0;
+    if (MODE == 1) {
+        int bk, prn;
+        if (a.row_map) {
+            const int2 rm = a.row_map[row];
+            bk = rm.x;
+            prn = rm.y;
+        } else {
+            bk = (int)(row % a.rows_per_prn);
+            prn = a.prn_base + (int)(row / a.rows_per_prn);
+        }
+        const bool bf = a.blocks_fast && !a.row_map;
+        const int b = bf ? bk % a.n_blocks : bk / a.n_bins, kb = bf ? bk / a.n_blocks : bk % a.n_bins;
+        const int2 bm = a.bin_map[kb];
+        px = a.mul_x + (long long)(b * a.n_phi + bm.x) * a.n;
+        pf = a.mul_f + (long long)prn * a.n;
+        shift = bm.y;
+    }
+    // ---- stage 1: this wave's rounds are wave and wave + 2 ----
+    cplx xv[2][7], fv[2][7], w1[2];
+    auto load_round = [&](int r) {
+        const int bq = g + 8 * (wave + 2 * r);
+        const int b = bq < 31 ? bq : 30;   // (lanes 56..63 of the last round repeat b = 30 and store nothing)
+        w1[r] = a.tw_sub[b];
+#pragma unroll
+        for (int m = 0; m < 7; ++m) {
+            // (32-bit element indices on uniform bases: one address add per load)
+            const unsigned idx = (unsigned)((31 * m + b) * N2 + n2);
+            if (MODE == 1) {
+                unsigned ix = idx + (unsigned)shift;
+                ix = ix >= (unsigned)(N1 * N2) ? ix - (unsigned)(N1 * N2) : ix;
+                xv[r][m] = px[ix];
+                fv[r][m] = pf[idx];
+            } else {
+                xv[r][m] = ((long long)idx < a.nonzero_len) ? in[idx] : make_double2(0.0, 0.0);
+            }
+        }
+    };
+    auto run_round = [&](int r) {
+        const int b = g + 8 * (wave + 2 * r);
+        cplx v[7];
+#pragma unroll
+        for (int m = 0; m < 7; ++m) {
+            v[m] = xv[r][m];
+            if (MODE == 1)
+                v[m] = make_double2(__builtin_fma(xv[r][m].x, fv[r][m].x, xv[r][m].y * fv[r][m].y),
+                                    __builtin_fma(xv[r][m].x, fv[r][m].y, -(xv[r][m].y * fv[r][m].x)));
+        }
+        cplx tw[7];
+        tw[1] = w1[r];
+        tw[2] = cmul(tw[1], tw[1]);
+        tw[3] = cmul(tw[2], tw[1]);
+        tw[4] = cmul(tw[2], tw[2]);
+        tw[5] = cmul(tw[4], tw[1]);
+        tw[6] = cmul(tw[3], tw[3]);
+        cplx sa[3], sb[3];
+#pragma unroll
+        for (int q = 1; q <= 3; ++q) {
+            sa[q - 1] = cadd(v[q], v[7 - q]);
+            sb[q - 1] = csub(v[q], v[7 - q]);
+        }
+        const bool act = b < 31;
+        dft_odd_part<7, 0, 1>(sa, sb, v[0], a.wr[0], [&](int c, cplx V) {
+            if (c > 0) V = cmul(V, tw[c]);
+            if (act) buf[(c * 31 + b) * C + col] = V;
+        });
+    };
+    load_round(0);
+    load_round(1);
+    run_round(0);
+    run_round(1);
+    __syncthreads();
+    // ---- stage 2 ----
+    if (g < 7) {
+        const int c = g;
+        const cplx* __restrict__ y = buf + (c * 31) * C + col;
+        cplx* __restrict__ out = a.out + row * a.n;
+        const unsigned o0 = (unsigned)(c * N2 + n2);
+        const cplx w0 = cmul(h0, l0), ws = cmul(h7, l7), wN = cmul(hN, lN);
+        if (wave == 0) f4w_stage2<0>(wc31, ws31, y, w0, ws, wN, out, o0);
+        else f4w_stage2<1>(wc31, ws31, y, w0, ws, wN, out, o0);
+    }
+}
+
 // (value, first index) maximum over a workgroup of TPB threads; result valid in thread 0.  sv / si: TPB / 64 slots each.
 template <int TPB>
 __device__ __forceinline__ void wg_argmax(double& best, int& arg, double* __restrict__ sv, int* __restrict__ si, int tid) {
@@ -917,6 +1099,13 @@ int sgx_fft4_row_blocks(void) { return F4_N1 / F4_CB; }
 
 template <int MODE>
 static void f4_launch_cols(const F4Args& a, int64_t rows, hipStream_t st) {
+    static const bool four_waves = getenv("SGX_ACQ_COLS4") && atoi(getenv("SGX_ACQ_COLS4")) != 0;
+    dim3 grid(F4_N2 / F4_C, (unsigned)rows);
+    if (!four_waves) {
+        static_assert(F4_N1 == F4W_N1 && F4_N2 == F4W_N2 && F4_C == 8, "the one-wave columns kernel is written for 217 x 176");
+        fft4_cols217_kernel<MODE><<<grid, 128, 0, st>>>(a);
+        return;
+    }
     auto kern = fft4_cols_kernel<F4_N1, F4_N2, F4_C, F4_TPB, 7, 31, 4, MODE>;
     const size_t lds = sizeof(cplx) * (F4_N1 * F4_C + F4_N1);
     // (the attribute is per device: a process that drives several GPUs sets it on each)
@@ -927,7 +1116,6 @@ static void f4_launch_cols(const F4Args& a, int64_t rows, hipStream_t st) {
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         once[dev_].store(true);
     }
-    dim3 grid(F4_N2 / F4_C, (unsigned)rows);
     kern<<<grid, F4_TPB, lds, st>>>(a);
 }
 
