@@ -459,15 +459,15 @@ int sgx_fft_forward_fused(const FftPlan* p, cplx* a, cplx* b, int64_t rows, hipS
 }
 
 // =====================================================================================================================
-// Four-step transform with LDS-resident sub-transforms (the acquisition's hot transforms).
+// Four-step transform with register-resident sub-transforms (the acquisition's hot transforms).
 //
 // n = N1 * N2, input index N2 n1 + n2, output index k1 + N1 k2:
 //   X[k1 + N1 k2] = sum_n2 W_N2^(n2 k2) [ W_n^(n2 k1) sum_n1 x[N2 n1 + n2] W_N1^(n1 k1) ]
-//   columns kernel   a workgroup takes C adjacent columns n2 (C * 16 bytes contiguous per n1), runs their N1-point
-//                    transforms in LDS (Stockham radix passes, outputs staged in registers across a barrier), multiplies
-//                    by W_n^(n2 k1) and stores element (k1, n2) where it came from;
-//   rows kernel      a workgroup takes CB adjacent rows k1 (CB * N2 contiguous elements), runs their N2-point transforms
-//                    in LDS and either stores X[k1 + N1 k2] or - last step of the correlation - squares, scales and
+//   columns kernel   a workgroup takes 8 adjacent columns n2 (128 contiguous bytes per n1), runs their N1-point
+//                    transforms - first radix straight from memory in registers, one exchange through LDS, second radix
+//                    in registers - multiplies by W_n^(n2 k1) and stores element (k1, n2) where it came from;
+//   rows kernel      a workgroup takes 7 adjacent rows k1 (contiguous elements), runs their N2-point transforms the same
+//                    way and either stores X[k1 + N1 k2] or - last step of the correlation - squares, scales and
 //                    max-reduces the outputs without storing anything (optionally summing the powers of several 1-ms
 //                    blocks first: the non-coherent extension).
 // A row therefore crosses HBM twice (write after the columns, read before the rows) instead of once per radix pass.
@@ -564,10 +564,8 @@ __device__ __forceinline__ void lds_radix_pass(cplx* __restrict__ buf, const TW 
     __syncthreads();
 }
 
-// A large odd radix with few butterflies per workgroup (radix 31: 7 per 217-point row): PARTS waves share a
-// butterfly, each producing a compile-time subset of the output pairs (k, R - k), so every wave keeps the roots in
-// scalar registers and the pass runs PARTS times wider.  The a = v[q] + v[R-q], b = v[q] - v[R-q] halves are what
-// is staged in registers across the barrier.  Wave w takes part w % PARTS and butterflies (w / PARTS) * 64 + lane.
+// An odd radix whose outputs are shared by PARTS waves: each produces a compile-time subset of the output pairs
+// (k, R - k) from the halves a = v[q] + v[R-q], b = v[q] - v[R-q] (PARTS = 1: all of them).
 template <int R, int PART, int PARTS, class Emit>
 __device__ __forceinline__ void dft_odd_part(const cplx (&a)[(R - 1) / 2], const cplx (&b)[(R - 1) / 2], cplx v0,
                                              const cplx* __restrict__ wr, Emit&& emit) {
@@ -604,163 +602,7 @@ __device__ __forceinline__ void dft_odd_part(const cplx (&a)[(R - 1) / 2], const
     }
 }
 
-template <int L, int R, int NS, int C, int SN, int SC, int TPB, bool CFAST, int PARTS, class TW>
-__device__ __forceinline__ void lds_odd_pass_split(cplx* __restrict__ buf, const TW twl,
-                                                   const cplx* __restrict__ wr, int tid) {
-    static_assert(PARTS == 4, "instantiated for four parts");
-    constexpr int M = L / R, H = (R - 1) / 2;
-    constexpr int TOTAL = M * C;
-    constexpr int TS = L / (NS * R);
-    static_assert((TPB / 64 / PARTS) * 64 >= TOTAL, "one round must cover every butterfly");
-    const int wv = tid >> 6, lane = tid & 63;
-    const int part = __builtin_amdgcn_readfirstlane(wv % PARTS);
-    const int w = (wv / PARTS) * 64 + lane;
-    const bool act = w < TOTAL;
-    const int c = CFAST ? w % C : w / M, j = CFAST ? w / C : w % M;
-    const int k = j % NS;
-    cplx a[H], b[H];
-    cplx v0 = make_double2(0.0, 0.0);
-    if (act) {
-        v0 = buf[j * SN + c * SC];
-#pragma unroll
-        for (int q = 1; q <= H; ++q) {
-            cplx x = buf[(j + q * M) * SN + c * SC];
-            cplx y = buf[(j + (R - q) * M) * SN + c * SC];
-            if (NS > 1) {
-                x = cmul(x, twl[q * k * TS]);
-                y = cmul(y, twl[(R - q) * k * TS]);
-            }
-            a[q - 1] = cadd(x, y);
-            b[q - 1] = csub(x, y);
-        }
-    }
-    __syncthreads();
-    if (act) {
-        const int j0 = (j / NS) * NS * R + k;
-        auto put = [&](int q, cplx V) { buf[(j0 + q * NS) * SN + c * SC] = V; };
-        if (part == 0) dft_odd_part<R, 0, PARTS>(a, b, v0, wr, put);
-        else if (part == 1) dft_odd_part<R, 1, PARTS>(a, b, v0, wr, put);
-        else if (part == 2) dft_odd_part<R, 2, PARTS>(a, b, v0, wr, put);
-        else dft_odd_part<R, 3, PARTS>(a, b, v0, wr, put);
-    }
-    __syncthreads();
-}
-
-// W_L^t, t < L, into LDS (from the plan's table of the sub-transform's roots)
-template <int L, int TPB>
-__device__ __forceinline__ void lds_fill_twiddles(cplx* __restrict__ twl, const cplx* __restrict__ tab, int tid) {
-    constexpr int PER = (L + TPB - 1) / TPB;
-    static_assert(PER <= 4, "four staging registers");
-    cplx v0, v1, v2, v3;   // (named: see the rows kernel)
-    if (PER > 0 && tid < L) v0 = tab[tid];
-    if (PER > 1 && tid + TPB < L) v1 = tab[tid + TPB];
-    if (PER > 2 && tid + 2 * TPB < L) v2 = tab[tid + 2 * TPB];
-    if (PER > 3 && tid + 3 * TPB < L) v3 = tab[tid + 3 * TPB];
-    if (PER > 0 && tid < L) twl[tid] = v0;
-    if (PER > 1 && tid + TPB < L) twl[tid + TPB] = v1;
-    if (PER > 2 && tid + 2 * TPB < L) twl[tid + 2 * TPB] = v2;
-    if (PER > 3 && tid + 3 * TPB < L) twl[tid + 3 * TPB] = v3;
-}
-
-// MODE 0: plain.  MODE 1: input = conj(X[(i + shift) mod n]) * F[i] (correlation product, acquisition.py:120-123).
-template <int N1, int N2, int C, int TPB, int R1, int R2, int R3, int MODE>
-__global__ __launch_bounds__(TPB) void fft4_cols_kernel(F4Args a) {
-    extern __shared__ __attribute__((aligned(16))) char f4_smem[];
-    cplx* __restrict__ buf = reinterpret_cast<cplx*>(f4_smem);   // [N1][C]
-    cplx* __restrict__ twl = buf + N1 * C;                       // [N1]: W_N1^t
-    const int tid = threadIdx.x;
-    // the sub-transform's twiddles: loaded now, stored to LDS after the tile's own loads are issued (loaded, waited for
-    // and stored first, the fill is one exposed memory round trip per workgroup)
-    static_assert(N1 <= TPB, "one staging register");
-    cplx tws = make_double2(0.0, 0.0);
-    if (tid < N1) tws = a.tw_sub[tid];
-    const int c0 = blockIdx.x * C;
-    const long long row = blockIdx.y;
-    // the output twiddles' table look-ups (four dependent-free global loads) are issued first: behind the passes they
-    // were one more exposed memory round trip per tile
-    static_assert(TPB % C == 0, "a thread keeps its column");
-    constexpr int STEP = TPB / C;
-    const int n2 = c0 + tid % C, k1b = tid / C;
-    const cplx tw_hi0 = a.tw_hi[((long long)n2 * k1b) >> a.lo_bits], tw_lo0 = a.tw_lo[((long long)n2 * k1b) & ((1ll << a.lo_bits) - 1)];
-    const cplx tw_hi1 = a.tw_hi[((long long)n2 * STEP) >> a.lo_bits], tw_lo1 = a.tw_lo[((long long)n2 * STEP) & ((1ll << a.lo_bits) - 1)];
-    const cplx* __restrict__ in = a.in + row * a.n;
-    const cplx* __restrict__ px = nullptr;
-    const cplx* __restrict__ pf = nullptr;
-    int shift = 0;
-    if (MODE == 1) {
-        int bk, prn;
-        if (a.row_map) {
-            const int2 rm = a.row_map[row];
-            bk = rm.x;
-            prn = rm.y;
-        } else {
-            bk = (int)(row % a.rows_per_prn);
-            prn = a.prn_base + (int)(row / a.rows_per_prn);
-        }
-        const bool bf = a.blocks_fast && !a.row_map;
-        const int b = bf ? bk % a.n_blocks : bk / a.n_bins, kb = bf ? bk / a.n_blocks : bk % a.n_bins;
-        const int2 bm = a.bin_map[kb];
-        px = a.mul_x + (long long)(b * a.n_phi + bm.x) * a.n;
-        pf = a.mul_f + (long long)prn * a.n;
-        shift = bm.y;
-    }
-    // every load of the tile is issued before the first one is waited for (a rolled loop runs one memory round trip
-    // per element and thread, ~1-2 us each)
-    {
-        constexpr int PER = (N1 * C + TPB - 1) / TPB;
-        cplx xv[PER], fv[PER];
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int e = tid + i * TPB;
-            if (e < N1 * C) {
-                const long long idx = (long long)(e / C) * N2 + c0 + e % C;
-                if (MODE == 1) {
-                    long long ix = idx + shift;
-                    if (ix >= a.n) ix -= a.n;
-                    xv[i] = px[ix];
-                    fv[i] = pf[idx];
-                } else {
-                    xv[i] = (idx < a.nonzero_len) ? in[idx] : make_double2(0.0, 0.0);
-                }
-            }
-        }
-        if (tid < N1) twl[tid] = tws;
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int e = tid + i * TPB;
-            if (e < N1 * C) {
-                cplx val = xv[i];
-                if (MODE == 1)
-                    val = make_double2(__builtin_fma(xv[i].x, fv[i].x, xv[i].y * fv[i].y),
-                                       __builtin_fma(xv[i].x, fv[i].y, -(xv[i].y * fv[i].x)));
-                buf[e] = val;
-            }
-        }
-    }
-    __syncthreads();
-    // R3 = 4: the second radix is a large odd one whose butterflies are split over four waves each
-    const TwDirect tw{twl};
-    lds_radix_pass<N1, R1, 1, C, C, 1, TPB, true>(buf, tw, a.wr[0], tid);
-    if constexpr (R3 == 4) lds_odd_pass_split<N1, R2, R1, C, C, 1, TPB, true, 4>(buf, tw, a.wr[1], tid);
-    else lds_radix_pass<N1, R2, R1, C, C, 1, TPB, true>(buf, tw, a.wr[1], tid);
-    // element (k1, n2) times W_n^(n2 k1).  A thread keeps its column n2 and advances k1 by STEP: one table look-up for
-    // its first element and one for the step factor W_n^(n2 STEP), the others by recurrence (<= 6 products: a few ulp)
-    cplx* __restrict__ out = a.out + row * a.n;
-    cplx w = cmul(tw_hi0, tw_lo0);
-    const cplx ws = cmul(tw_hi1, tw_lo1);
-#pragma unroll
-    for (int i = 0; i < (N1 + STEP - 1) / STEP; ++i) {
-        const int k1 = k1b + i * STEP;
-        if (k1 < N1) out[(long long)k1 * N2 + n2] = cmul(buf[k1 * C + tid % C], w);
-        w = cmul(w, ws);
-    }
-}
-
-// The columns kernel of the 217 x 176 transform with TWO WAVES per tile of 8 columns (round 3).  The four-wave kernel
-// above is bound by instruction issue (about 1 200 instructions per wave and tile, 4 800 per tile): the 56 radix-31
-// butterflies of a tile fill one wave, so splitting each over four waves repeats their input side (31 LDS reads, 30
-// twiddle products, 60 sums) four times, and the staging of the tile through LDS in front of the first pass and behind
-// the last one costs an LDS access and a wait per element.  Here
+// The columns kernel of the 217 x 176 transform: TWO WAVES per tile of 8 columns.
 //   217 = 31 a + b on the way in, c + 7 d on the way out:  X[c + 7 d] = sum_b W_31^(b d) W_217^(b c) sum_a x[31 a + b] W_7^(a c)
 //   stage 1   lane (column, b) loads its seven inputs x[31 a + b] straight from memory (forming the correlation product
 //             on the way), runs the 7-point transform in registers and writes Y[c][b] W_217^(b c) to LDS: four rounds
@@ -769,9 +611,12 @@ __global__ __launch_bounds__(TPB) void fft4_cols_kernel(F4Args a) {
 //             scalar registers, outputs in pairs (d, 31 - d), the odd d in one wave and the even d in the other - and
 //             stores each output times W_n^(n2 (c + 7 d)) where it belongs, the factors by two recurrences (up from
 //             d = 0, down from d = 31).
-// About 2 700 instructions per tile; 27 KB of LDS: five workgroups = ten waves per CU (ONE wave per tile measured 340 us
-// for the 1 856 rows of config 2 against 390-415 for the four-wave kernel: five waves per CU leave every SIMD waiting on
-// its own dependent instructions).
+// About 2 500 instructions per tile, 27 KB of LDS, 166 registers: five workgroups per CU.  History (config 2's 1 856 rows):
+// the round-2 kernel staged the tile through LDS, ran Stockham passes on it and split every radix-31 butterfly over
+// four waves (each repeating its input side): 4 800 instructions per tile, bound by instruction issue, 385-415 us.  One
+// wave per tile: 337-353 us (five waves per CU leave a SIMD waiting on its own dependent instructions).  This kernel:
+// 313-330 us, of which the stores alone account for 287 (measured with the radix-31 arithmetic removed) and the
+// arithmetic alone for 230 (measured with the stores removed).
 template <int PART>
 __device__ __forceinline__ void f4w_stage2(const double (&wc)[15], const double (&wsn)[15], const cplx* __restrict__ y,
                                            cplx w0, cplx ws, cplx wN, cplx* __restrict__ out, unsigned o0) {
@@ -965,103 +810,127 @@ __device__ __forceinline__ void wg_argmax(double& best, int& arg, double* __rest
     }
 }
 
-// MODE 0: store X.  MODE 2: |X|^2 inv_n^2 (summed over sum_blocks input rows), per-workgroup (max, first index).
-// MODE 3: the same powers stored to pout (the rows the second-peak search reads).
-#ifndef F4_ROWS_WAVES
-#define F4_ROWS_WAVES 3
+// The rows kernel of the 217 x 176 transform.
+//   176 = a + 16 b on the way in, 11 c + d on the way out:  X[11 c + d] = sum_a W_16^(a c) W_176^(a d) sum_b x[a + 16 b] W_11^(b d)
+//   stage 1   lane (row, a) (112 of 128) loads its eleven inputs x[a + 16 b] straight from memory (256 contiguous bytes
+//             per row and load), runs the 11-point transform in registers and writes Z[d][a] W_176^(a d) to LDS, 17
+//             elements per d (the next stage reads with a stride of one d: no bank conflicts);
+//   stage 2   lane (row, d) (77 of 128) reads its 16 values, runs the 16-point transform in registers and squares, adds up
+//             (blocks of the non-coherent sum) and max-reduces its outputs where they are.
+// 27 LDS accesses per thread, 21 KB of LDS.  The round-2 kernel staged the tile through LDS and ran Stockham passes on it:
+// 84 LDS accesses per thread, the radix-16 pass writing with a stride of 16 elements - the counters showed the LDS pipe
+// busy for the whole 345 us of config 2, more than a third of that in bank conflicts.  This one: 231-253 us.
+#ifndef F4R_WAVES_NB
+#define F4R_WAVES_NB 2
 #endif
-// NB1: one input row per output row (known at compile time, the power accumulators are then not live across the
-// transform: no register spills at three waves per SIMD).
-template <int N1, int N2, int CB, int TPB, int R1, int R2, int R3, int MODE, bool NB1>
-__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(F4_ROWS_WAVES))) void fft4_rows_kernel(F4Args a) {
-    extern __shared__ __attribute__((aligned(16))) char f4_smem[];
-    cplx* __restrict__ buf = reinterpret_cast<cplx*>(f4_smem);   // [CB][N2]
-    cplx* __restrict__ twl = buf + CB * N2;                      // [N2]: W_N2^t
+template <int MODE, bool NB1>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(F4R_WAVES_NB))) void fft4_rows176_kernel(F4Args a) {
+    constexpr int N1 = F4W_N1, N2 = F4W_N2, CB = 7, DP = 17, RP = 11 * DP;
+    __shared__ cplx buf[CB * RP];   // [row][d][a], 17 elements per d
     const int tid = threadIdx.x;
-    static_assert(N2 <= 2 * TPB, "two staging registers");
-    cplx tws0 = make_double2(0.0, 0.0), tws1 = make_double2(0.0, 0.0);   // (as in the columns kernel)
-    if (tid < N2) tws0 = a.tw_sub[tid];
-    if (tid + TPB < N2) tws1 = a.tw_sub[tid + TPB];
+    // roots of both radices: read here, in front of barriers and stores, where they still go through the scalar cache
+    cplx w11[11], w16[16];
+#pragma unroll
+    for (int m = 1; m <= 5; ++m) w11[m] = a.wr[1][m];
+#pragma unroll
+    for (int m = 1; m < 10; ++m) w16[m] = a.wr[0][m];
+    const bool s1 = tid < CB * 16, s2 = tid < CB * 11;
+    const int r1 = s1 ? tid >> 4 : CB - 1, a1 = tid & 15;
+    const int r2 = s2 ? tid / 11 : 0, d2 = s2 ? tid % 11 : 0;
+    // W_176^(a d), d = 1..10, for this lane's a (several blocks per output row: fetched again for every block, the
+    // forty registers are wanted by the power accumulators and the next block's loads)
+    cplx tw[11];
+    if (NB1) {
+#pragma unroll
+        for (int d = 1; d <= 10; ++d) tw[d] = a.tw_sub[a1 * d];
+    }
     const int k10 = blockIdx.x * CB;
     const long long row = blockIdx.y;
-    constexpr int E = CB * N2;
-    constexpr int PER = (E + TPB - 1) / TPB;
-    double acc[PER];
-#pragma unroll
-    for (int i = 0; i < PER; ++i) acc[i] = 0.0;
     const int nb = (NB1 || MODE == 0 || a.sum_blocks < 1) ? 1 : a.sum_blocks;
+    double acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.0;
+    cplx keep[16];   // MODE 0: the transform itself
+    cplx v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, v10;   // (named: an array inside the block loop is left in scratch memory)
+    const unsigned o1 = (unsigned)(r1 * N2 + a1);
+#define F4R_LOAD(blk)                                                                              \
+    do {                                                                                           \
+        const cplx* __restrict__ in = a.in + (row * nb + (blk)) * a.n + (long long)k10 * N2;       \
+        v0 = in[o1]; v1 = in[o1 + 16]; v2 = in[o1 + 32]; v3 = in[o1 + 48]; v4 = in[o1 + 64];        \
+        v5 = in[o1 + 80]; v6 = in[o1 + 96]; v7 = in[o1 + 112]; v8 = in[o1 + 128]; v9 = in[o1 + 144]; \
+        v10 = in[o1 + 160];                                                                        \
+    } while (0)
+    F4R_LOAD(0);
+#pragma unroll 1
     for (int b = 0; b < nb; ++b) {
-        const cplx* __restrict__ in = a.in + (row * nb + b) * a.n + (long long)k10 * N2;
+        if (!NB1) {
+            asm volatile("" ::: "memory");   // (keeps these loads inside the loop)
+#pragma unroll
+            for (int d = 1; d <= 10; ++d) tw[d] = a.tw_sub[a1 * d];
+        }
         {
-            // every load of the tile in flight together (a rolled loop runs one HBM round trip per element and thread);
-            // named registers: an array here, inside the block loop, is left in scratch memory by the compiler
-            static_assert(PER <= 10, "ten staging registers");
-            cplx p0, p1, p2, p3, p4, p5, p6, p7, p8, p9;
-#define F4_LD(i, r) if (PER > i && tid + i * TPB < E) r = in[tid + i * TPB];
-            F4_LD(0, p0) F4_LD(1, p1) F4_LD(2, p2) F4_LD(3, p3) F4_LD(4, p4)
-            F4_LD(5, p5) F4_LD(6, p6) F4_LD(7, p7) F4_LD(8, p8) F4_LD(9, p9)
-#undef F4_LD
-            if (b > 0) __syncthreads();
-            if (b == 0) {
-                if (tid < N2) twl[tid] = tws0;
-                if (tid + TPB < N2) twl[tid + TPB] = tws1;
-            }
-#define F4_ST(i, r) if (PER > i && tid + i * TPB < E) buf[tid + i * TPB] = r;
-            F4_ST(0, p0) F4_ST(1, p1) F4_ST(2, p2) F4_ST(3, p3) F4_ST(4, p4)
-            F4_ST(5, p5) F4_ST(6, p6) F4_ST(7, p7) F4_ST(8, p8) F4_ST(9, p9)
-#undef F4_ST
+            const cplx v[11] = {v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, v10};
+            cplx* __restrict__ z = buf + r1 * RP + a1;
+            dft_odd_emit<11>(v, w11, [&](int d, cplx V) {
+                if (d > 0) V = cmul(V, tw[d]);
+                if (s1) z[d * DP] = V;
+            });
         }
         __syncthreads();
-        const TwDirect tw{twl};
-        lds_radix_pass<N2, R1, 1, CB, 1, N2, TPB, false>(buf, tw, a.wr[0], tid);
-        if constexpr (R3 == 4) lds_odd_pass_split<N2, R2, R1, CB, 1, N2, TPB, false, 4>(buf, tw, a.wr[1], tid);
-        else lds_radix_pass<N2, R2, R1, CB, 1, N2, TPB, false>(buf, tw, a.wr[1], tid);
-        if (MODE == 0) {
-            cplx* __restrict__ out = a.out + row * a.n;
-            for (int e = tid; e < E; e += TPB) {
-                const int cb = e / N2, k2 = e % N2;
-                out[(long long)(k10 + cb) + (long long)N1 * k2] = buf[e];
-            }
-        } else {
+        if (!NB1 && b + 1 < nb) F4R_LOAD(b + 1);   // (in flight behind the second stage)
+        {
+            cplx y[16];
+            const cplx* __restrict__ z = buf + r2 * RP + d2 * DP;
 #pragma unroll
-            for (int i = 0; i < PER; ++i) {
-                const int e = tid + i * TPB;
-                if (e < E) {
-                    const cplx V = buf[e];
-                    const double re = V.x * a.inv_n, im = V.y * a.inv_n;
+            for (int q = 0; q < 16; ++q) y[q] = z[q];
+            dft_small<16>(y, w16);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                if (MODE == 0) {
+                    keep[c] = y[c];
+                } else {
+                    const double re = y[c].x * a.inv_n, im = y[c].y * a.inv_n;
                     const double pw = re * re + im * im;
-                    acc[i] = (b == 0) ? pw : acc[i] + pw;
+                    acc[c] = (b == 0) ? pw : acc[c] + pw;
                 }
             }
         }
+        if (!NB1 && b + 1 < nb) __syncthreads();
     }
-    if (MODE == 0) return;
+#undef F4R_LOAD
+    // output k = k1 + N1 k2, k2 = 11 c + d
+    const int idx0 = (k10 + r2) + N1 * d2;
+    if (MODE == 0) {
+        cplx* __restrict__ out = a.out + row * a.n;
+        if (s2) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) out[idx0 + N1 * 11 * c] = keep[c];
+        }
+        return;
+    }
     if (MODE == 3) {
         double* __restrict__ po = a.pout + row * a.n;
+        if (s2) {
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int e = tid + i * TPB;
-            if (e < E) po[(long long)(k10 + e / N2) + (long long)N1 * (e % N2)] = acc[i];
+            for (int c = 0; c < 16; ++c) po[idx0 + N1 * 11 * c] = acc[c];
         }
         return;
     }
     double best = -1.0;
     int arg = 0x7FFFFFFF;
+    if (s2) {
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int e = tid + i * TPB;
-        if (e < E) {
-            const int idx = (k10 + e / N2) + N1 * (e % N2);
-            if (acc[i] > best || (acc[i] == best && idx < arg)) {
-                best = acc[i];
-                arg = idx;
+        for (int c = 0; c < 16; ++c) {   // (ascending index: the first of equal maxima stays)
+            if (acc[c] > best) {
+                best = acc[c];
+                arg = idx0 + N1 * 11 * c;
             }
         }
     }
     __syncthreads();
-    double* s_v = reinterpret_cast<double*>(f4_smem);
-    int* s_i = reinterpret_cast<int*>(f4_smem + sizeof(double) * (TPB / 64));
-    wg_argmax<TPB>(best, arg, s_v, s_i, tid);
+    double* s_v = reinterpret_cast<double*>(buf);
+    int* s_i = reinterpret_cast<int*>(s_v + 2);
+    wg_argmax<128>(best, arg, s_v, s_i, tid);
     if (tid == 0) {
         a.pmax[row * gridDim.x + blockIdx.x] = best;
         a.parg[row * gridDim.x + blockIdx.x] = arg;
@@ -1069,12 +938,10 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(F4_ROWS_WAV
 }
 
 // ---- the plan the acquisition uses: n = 38192 = 176 x 217 (16*11, 7*31); other lengths keep the pass-per-radix path ----
-#define F4_N1 217          // columns: 7 x 31 (the radix-31 butterflies split over four waves each)
-#define F4_N2 176          // rows: 16 x 11
-#define F4_C 8             // 128 contiguous bytes per column-tile row; 31 KB of LDS, 148 VGPRs: three workgroups per CU
-#define F4_CB 7            // 217 = 31 x 7 rows; 22 KB of LDS: seven workgroups per CU
-#define F4_TPB 256         // columns kernel: 248 radix-7 butterflies, 56 radix-31 butterflies x 4 waves
-#define F4_TPB_ROWS 128    // rows kernel: 77 radix-16 / 112 radix-11 butterflies
+#define F4_N1 F4W_N1       // columns: 7 x 31
+#define F4_N2 F4W_N2       // rows: 16 x 11
+#define F4_C 8             // columns kernel: 128 contiguous bytes per tile row; 27 KB of LDS, 166 VGPRs: five workgroups per CU
+#define F4_CB 7            // rows kernel: 217 = 31 x 7 rows; 21 KB of LDS: seven workgroups per CU
 
 bool sgx_fft4_supported(int64_t n) { return n == (int64_t)F4_N1 * F4_N2; }
 
@@ -1099,40 +966,14 @@ int sgx_fft4_row_blocks(void) { return F4_N1 / F4_CB; }
 
 template <int MODE>
 static void f4_launch_cols(const F4Args& a, int64_t rows, hipStream_t st) {
-    static const bool four_waves = getenv("SGX_ACQ_COLS4") && atoi(getenv("SGX_ACQ_COLS4")) != 0;
     dim3 grid(F4_N2 / F4_C, (unsigned)rows);
-    if (!four_waves) {
-        static_assert(F4_N1 == F4W_N1 && F4_N2 == F4W_N2 && F4_C == 8, "the one-wave columns kernel is written for 217 x 176");
-        fft4_cols217_kernel<MODE><<<grid, 128, 0, st>>>(a);
-        return;
-    }
-    auto kern = fft4_cols_kernel<F4_N1, F4_N2, F4_C, F4_TPB, 7, 31, 4, MODE>;
-    const size_t lds = sizeof(cplx) * (F4_N1 * F4_C + F4_N1);
-    // (the attribute is per device: a process that drives several GPUs sets it on each)
-    static std::atomic<bool> once[SGX_MAX_DEVICES];
-    int dev_ = 0;
-    hipGetDevice(&dev_);
-    if (dev_ >= 0 && dev_ < SGX_MAX_DEVICES && !once[dev_].load()) {
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        once[dev_].store(true);
-    }
-    kern<<<grid, F4_TPB, lds, st>>>(a);
+    fft4_cols217_kernel<MODE><<<grid, 128, 0, st>>>(a);
 }
 
 template <int MODE, bool NB1>
 static void f4_launch_rows_nb(const F4Args& a, int64_t rows, hipStream_t st) {
-    auto kern = fft4_rows_kernel<F4_N1, F4_N2, F4_CB, F4_TPB_ROWS, 16, 11, 1, MODE, NB1>;
-    const size_t lds = sizeof(cplx) * (F4_CB * F4_N2 + F4_N2);
-    // (the attribute is per device: a process that drives several GPUs sets it on each)
-    static std::atomic<bool> once[SGX_MAX_DEVICES];
-    int dev_ = 0;
-    hipGetDevice(&dev_);
-    if (dev_ >= 0 && dev_ < SGX_MAX_DEVICES && !once[dev_].load()) {
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        once[dev_].store(true);
-    }
     dim3 grid(F4_N1 / F4_CB, (unsigned)rows);
-    kern<<<grid, F4_TPB_ROWS, lds, st>>>(a);
+    fft4_rows176_kernel<MODE, NB1><<<grid, 128, 0, st>>>(a);
 }
 
 template <int MODE>
