@@ -32,6 +32,20 @@
 #define TP_OCC 2
 #endif
 
+// workgroup barrier that waits for LDS traffic only: __syncthreads() also waits for the wave's global loads and stores
+// (the record stores of a block, the look-ahead loads behind the last chip), whose round trips nobody here depends on
+__device__ __forceinline__ void tp_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// lane 15 of rows 0 and 2 to every lane of rows 1 and 3 (the other rows get 0)
+__device__ __forceinline__ double tp_row_bcast15(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int olo = __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xA, 0xF, false);
+    const int ohi = __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xA, 0xF, false);
+    return __hiloint2double(ohi, olo);
+}
+
 // first sample above thr from real arithmetic; `near` is raised when a sample lies within 1e-7 samples of the boundary
 __device__ __forceinline__ int tp_bound(double start, double inv_step, double thr, bool& near) {
     const double u = (thr - start) * inv_step;
@@ -219,6 +233,7 @@ __global__ __launch_bounds__(TP_THREADS, TP_OCC) void trk_kernel_tp(const int8_t
     __shared__ double s_red[6][TP_THREADS];
     __shared__ double s_tot[6];
     __shared__ TrkState s_st;
+    __shared__ double s_rec[2][16];        // the record of a block, [block parity][series]
 
     const int ch = blockIdx.x;
     if (ch >= K.n_ch) return;
@@ -261,7 +276,15 @@ __global__ __launch_bounds__(TP_THREADS, TP_OCC) void trk_kernel_tp(const int8_t
     const long long m = K.ms;
     const double two_pi = 2 * M_PI;
     int done = 0;
+#ifdef TP_PROF
+    // (diagnosis build: cycles per phase of a block, printed by channels 0 and 1000; tools/build_variant.sh ... -DTP_PROF)
+    long long tp_acc[6] = {0, 0, 0, 0, 0, 0};
+#define TP_STAMP(i) const long long tp_t##i = (long long)__builtin_amdgcn_s_memtime();
+#else
+#define TP_STAMP(i)
+#endif
     for (int it = 0; it < K.ms; ++it) {
+        TP_STAMP(0)
         const long long pos = s_blk.pos;
         const int blk = s_blk.blk;
         if (s_blk.stop) break;   // short read: tracking.py:159-163
@@ -366,6 +389,7 @@ __global__ __launch_bounds__(TP_THREADS, TP_OCC) void trk_kernel_tp(const int8_t
         };
         TpChip nxt;
         unsigned nh[5], nt[5];
+        TP_STAMP(1)
 #pragma unroll 1
         while (have) {
             int cn = c + TP_THREADS;
@@ -380,23 +404,30 @@ __global__ __launch_bounds__(TP_THREADS, TP_OCC) void trk_kernel_tp(const int8_t
             c = cn;
             have = have_n;
         }
+        TP_STAMP(2)
         s_red[0][tid] = aIE;
         s_red[1][tid] = aQE;
         s_red[2][tid] = aIP;
         s_red[3][tid] = aQP;
         s_red[4][tid] = aIL;
         s_red[5][tid] = aQL;
-        __syncthreads();
-        if (tid < 96) {
-            // sum v = tid / 16 is folded by a row of 16 lanes: fixed order (deterministic), then a DPP row sum
-            const int v = tid >> 4, l = tid & 15;
-            double acc = s_red[v][l];
-#pragma unroll
-            for (int k = 1; k < TP_THREADS / 16; ++k) acc += s_red[v][l + 16 * k];
+        tp_barrier();
+        TP_STAMP(3)
+        if (tid < 192) {
+            // sum v = tid / 32 is folded by two rows of 16 lanes: eight values per lane (one batch of reads, a tree of
+            // adds), a DPP row sum, the first row's sum handed to the second.  Fixed order: deterministic.
+            // (sixteen values per lane and one row per sum: 860 cycles of every block, most of it the chain of adds)
+            static_assert(TP_THREADS == 256, "eight values per lane");
+            const int v = tid >> 5, l = tid & 31;
+            const double x0 = s_red[v][l], x1 = s_red[v][l + 32], x2 = s_red[v][l + 64], x3 = s_red[v][l + 96];
+            const double x4 = s_red[v][l + 128], x5 = s_red[v][l + 160], x6 = s_red[v][l + 192], x7 = s_red[v][l + 224];
+            double acc = ((x0 + x1) + (x2 + x3)) + ((x4 + x5) + (x6 + x7));
             acc = row_sum(acc);
-            if (l == 0) s_tot[v] = acc;
+            acc += tp_row_bcast15(acc);          // rows 1 and 3 of a wave: their own sum plus the row's before
+            if (l == 31) s_tot[v] = acc;
         }
-        __syncthreads();
+        tp_barrier();
+        TP_STAMP(4)
         const bool more = (it + 1 < K.ms);
         if (wave == 0) {
             // T7 PLL (tracking.py:223-235), T5 end-of-block carrier phase, tables of the next block
@@ -423,15 +454,16 @@ __global__ __launch_bounds__(TP_THREADS, TP_OCC) void trk_kernel_tp(const int8_t
                 s_st.oldCarrNco = carrNco;
                 s_st.oldCarrErr = carrError;
                 s_st.carrFreq = carrFreq;
-                o[2 * m + it] = carrFreq;          // T9 record (tracking.py:255-275)
-                o[3 * m + it] = I_P;
-                o[4 * m + it] = s_tot[0];
-                o[5 * m + it] = s_tot[4];
-                o[6 * m + it] = s_tot[1];
-                o[7 * m + it] = Q_P;
-                o[8 * m + it] = s_tot[5];
-                o[11 * m + it] = carrError;
-                o[12 * m + it] = carrNco;
+                double* __restrict__ r = s_rec[it & 1];   // T9 record (tracking.py:255-275): stored by wave 3, a block later
+                r[2] = carrFreq;
+                r[3] = I_P;
+                r[4] = s_tot[0];
+                r[5] = s_tot[4];
+                r[6] = s_tot[1];
+                r[7] = Q_P;
+                r[8] = s_tot[5];
+                r[11] = carrError;
+                r[12] = carrNco;
             }
         } else if (wave == 1) {
             // T8 DLL (tracking.py:238-251), then block size and ramps of the next block (T1, T3, T4)
@@ -448,16 +480,41 @@ __global__ __launch_bounds__(TP_THREADS, TP_OCC) void trk_kernel_tp(const int8_t
                 s_st.oldCodeNco = codeNco;
                 s_st.oldCodeErr = codeError;
                 s_st.codeFreq = codeFreq;
-                o[0 * m + it] = (double)(pos_after + K.file_off);
-                o[1 * m + it] = codeFreq;
-                o[9 * m + it] = codeError;
-                o[10 * m + it] = codeNco;
+                double* __restrict__ r = s_rec[it & 1];
+                r[0] = (double)(pos_after + K.file_off);
+                r[1] = codeFreq;
+                r[9] = codeError;
+                r[10] = codeNco;
             }
             if (more) prep_code(K, codeFreq, rem_next, pos_after, s_st, s_blk, lane == 0);
+        } else if (wave == TP_THREADS / 64 - 1) {
+            // the previous block's record: written to LDS by the filter waves a block ago, stored by this wave while it
+            // has nothing else to do (on the filter waves the thirteen stores and their addresses were 800 cycles of
+            // the block's critical path)
+            if (it > 0 && lane < SGX_NUM_SERIES) o[lane * m + (it - 1)] = s_rec[(it - 1) & 1][lane];
         }
         done = it + 1;
-        __syncthreads();   // next block's parameters visible
+        TP_STAMP(5)
+        tp_barrier();   // next block's parameters visible
+#ifdef TP_PROF
+        {
+            const long long tp_t6 = (long long)__builtin_amdgcn_s_memtime();
+            tp_acc[0] += tp_t1 - tp_t0;
+            tp_acc[1] += tp_t2 - tp_t1;
+            tp_acc[2] += tp_t3 - tp_t2;
+            tp_acc[3] += tp_t4 - tp_t3;
+            tp_acc[4] += tp_t5 - tp_t4;
+            tp_acc[5] += tp_t6 - tp_t5;
+        }
+#endif
     }
+#ifdef TP_PROF
+    if ((ch == 0 || ch == 1000) && lane == 0 && done > 0)
+        printf("[tp prof] ch %d wave %d cycles/block: top %lld loop %lld red-barrier %lld fold %lld filter %lld end-barrier %lld\n",
+               ch, wave, tp_acc[0] / done, tp_acc[1] / done, tp_acc[2] / done, tp_acc[3] / done, tp_acc[4] / done, tp_acc[5] / done);
+#endif
+    // the last block's record (the loop's final barrier has made it visible)
+    if (done > 0 && tid < SGX_NUM_SERIES) o[tid * m + (done - 1)] = s_rec[(done - 1) & 1][tid];
     if (tid == 0) ms_done[ch] = done;
 }
 

@@ -9,7 +9,7 @@ lib=softgnss-python_amd/lib
 mkdir -p $lib/variants
 /opt/rocm/bin/hipcc $flags --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -x hip -I include -I softgnss-python_amd/csrc \
     -Wno-unused-result -Wno-unused-value -c softgnss-python_amd/csrc/$src -o $lib/variants/$name.o
-objs=$(ls $lib/obj/*.o | grep -v "/$src.o")
+objs=$(ls $lib/obj/*.o | grep -v "/${4:-$src}.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $lib/variants/libsgx_$name.so $objs $lib/variants/$name.o -ldl
 rm -f $lib/variants/$name.o
 echo built $lib/variants/libsgx_$name.so

@@ -16,4 +16,4 @@ for nch in [int(x) for x in sys.argv[1:]] or [2048]:
         ser, dn = ctx.track(rec, many, 500); ts.append(ctx.timing()["track_ms"])
     byts = float(sum(ser[i, 0, -1] - many[i][2] for i in range(nch))) + nch * 500 * 104.0
     print(os.environ.get("SGX_LIB", "default").split("/")[-1], "%d x 500 ms: %.3f ms  %.3f TB/s  %.1f %% of 8 TB/s  locked %d"
-          % (nch, min(ts), byts / min(ts) / 1e9, byts / min(ts) / 1e9 / 80.0, int((dn == 500).sum())))
+          % (nch, min(ts), byts / min(ts) / 1e9, byts / min(ts) / 1e9 / 8.0 * 100.0, int((dn == 500).sum())))
