@@ -196,15 +196,19 @@ int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset,
               double* out, int32_t* ms_done);
 
 /* The same for a record of Settings.dataType samples (settings.dataType, initialize.py:60; read with
- * np.fromfile(fid, dataType, blksize) at tracking.py:154).  data_type SGX_DT_INT8 is sgx_track; with SGX_DT_INT16 the
- * record handle holds the file's BYTES as they are (upload 2 n bytes for n samples, little endian) and
- * rec_file_offset, skipNumberOfBytes + codePhase and absoluteSample stay BYTE positions, exactly as the reference's
- * fid.seek / fid.tell treat them (tracking.py:107, 255) - so a channel whose start byte is odd reads samples that
- * straddle the file's, as it does there.  Needs the one-unit-per-workgroup kernel: 8 ceil(n_ch / 8) x units CUs free
- * and samplingFreq >= 16 x codeFreqBasis, otherwise SGX_E_ARG. */
+ * np.fromfile(fid, dataType, blksize) at tracking.py:154).  data_type SGX_DT_INT8 is sgx_track; otherwise the record
+ * handle holds the file's BYTES as they are (little endian) and rec_file_offset, skipNumberOfBytes + codePhase and
+ * absoluteSample stay BYTE positions, exactly as the reference's fid.seek / fid.tell treat them (tracking.py:107, 255) -
+ * so an int16 channel whose start byte is odd reads samples that straddle the file's, as it does there.  int16 and uint8
+ * need samplingFreq >= 16 x codeFreqBasis (SGX_E_ARG otherwise).
+ * SGX_DT_FLOAT32: tracked EXACTLY when every sample of the window is m 2^-k for one k and 16-bit integers m (floats written
+ * from ADC samples, or normalised by a power of two): the integers go through the int8 / int16 kernels and the correlator
+ * series are scaled back, which no rounding of the reference's float64 arithmetic can tell from the real thing.
+ * SGX_E_ARG with a message for records of arbitrary floats, non-finite samples, or a channel that starts inside a sample. */
 #define SGX_DT_INT8  0
 #define SGX_DT_INT16 1
 #define SGX_DT_UINT8 2   /* offset-binary bytes as the reference reads them with dataType 'uint8': no offset is removed */
+#define SGX_DT_FLOAT32 3 /* IEEE binary32 */
 int sgx_track_ex(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset,
                  const sgx_chan_init* ch, int32_t n_ch, int32_t ms,
                  double* out, int32_t* ms_done, int32_t data_type);

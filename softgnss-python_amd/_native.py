@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("SGX_LIB") or os.path.join(HERE, "lib", "libsgx.so")  
 SGX_OK = 0
 SGX_E_ARG, SGX_E_HIP, SGX_E_NOMEM, SGX_E_INDEX, SGX_E_RCCL, SGX_E_RANGE = -1, -2, -3, -4, -5, -6
 NUM_SERIES = 13
-DT_INT8, DT_INT16, DT_UINT8 = 0, 1, 2          # sgx_track_ex data_type (include/sgx.h)
+DT_INT8, DT_INT16, DT_UINT8, DT_FLOAT32 = 0, 1, 2, 3   # sgx_track_ex data_type (include/sgx.h)
 MAX_SATS = 16
 SERIES = ("absoluteSample", "codeFreq", "carrFreq", "I_P", "I_E", "I_L", "Q_E", "Q_P", "Q_L",
           "dllDiscr", "dllDiscrFilt", "pllDiscr", "pllDiscrFilt")

@@ -363,8 +363,9 @@ extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, c
 
 extern "C" int sgx_track_ex(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const sgx_chan_init* ch,
                             int32_t n_ch, int32_t ms, double* out, int32_t* ms_done, int32_t data_type) {
+    if (data_type == SGX_DT_FLOAT32) return sgx_track_float32(c, r, rec_file_offset, ch, n_ch, ms, out, ms_done);
     if (data_type != SGX_DT_INT8 && data_type != SGX_DT_INT16 && data_type != SGX_DT_UINT8) {
-        sgx_set_error("sgx_track_ex: data_type %d (SGX_DT_INT8 = 0, SGX_DT_INT16 = 1 and SGX_DT_UINT8 = 2 are tracked)", (int)data_type);
+        sgx_set_error("sgx_track_ex: data_type %d (SGX_DT_INT8 = 0, SGX_DT_INT16 = 1, SGX_DT_UINT8 = 2 and SGX_DT_FLOAT32 = 3 are tracked)", (int)data_type);
         return SGX_E_ARG;
     }
     return track_impl(c, r, rec_file_offset, ch, n_ch, ms, out, ms_done, data_type == SGX_DT_INT16 ? 2 : 1,

@@ -43,7 +43,9 @@ class TrackingResult(Result):
             return _native.DT_INT16, 2
         if dt == np.dtype(np.uint8):
             return _native.DT_UINT8, 1
-        raise TypeError("the GPU path tracks int8, uint8 and int16 IF samples (Settings.dataType %r)"
+        if dt == np.dtype('<f4'):
+            return _native.DT_FLOAT32, 4      # exact when the samples are integers times one power of two (include/sgx.h)
+        raise TypeError("the GPU path tracks int8, uint8, int16 and float32 IF samples (Settings.dataType %r)"
                         % (self._settings.dataType,))
 
     def _window(self, fid, first, need):

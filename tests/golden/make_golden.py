@@ -429,6 +429,48 @@ def golden_int16(tmp, initialize, acquisition, tracking):
     np.savez_compressed(os.path.join(HERE, "trk_int16.npz"), **out)
 
 
+def golden_float32(tmp, initialize, acquisition, tracking):
+    """Settings.dataType = 'float32' (tracking.py:154): the default scene's int8 record as floats normalised by a power of
+    two, (200 x + 7) / 32768 - every sample is an integer times 2^-15 - in a file whose records start on whole samples:
+    the reference seeks skipNumberOfBytes + codePhase BYTES (tracking.py:107), so the channels are handed codePhase =
+    4 (sample - 1) and skipNumberOfBytes = 4000, a multiple of four."""
+    s = initialize.Settings()
+    n = s.samplesPerCode
+    sc = synth.Scene.default(n_sats=3)
+    ms = 100
+    rec8 = synth.generate(sc, synth.record_length(n, ms + 40))
+    recf = ((rec8.astype(np.int32) * 200 + 7) / 32768.0).astype("<f4")
+    skip = 4000
+    raw = np.concatenate([np.zeros(skip // 4, "<f4"), recf])
+    acq = acquisition.AcquisitionResult(s)
+    with Quiet():
+        acq.acquire(recf[:11 * n])
+    st = initialize.Settings()
+    st.dataType = 'float32'
+    st.msToProcess = float(ms)
+    st.numberOfChannels = 2
+    st.skipNumberOfBytes = skip
+    a2 = acquisition.AcquisitionResult(st)
+    a2.results = acq.results
+    with Quiet():
+        a2.preRun()
+    sample_phase = np.array(a2.channels.codePhase, dtype=np.float64)
+    a2.channels.codePhase[:] = 4.0 * (sample_phase - 1.0)
+    trk = tracking.TrackingResult(a2)
+    fid = as_file(tmp, "rec_f32.bin", raw)
+    with Quiet():
+        trk.track(fid)
+    names = ("absoluteSample", "codeFreq", "carrFreq", "I_P", "I_E", "I_L", "Q_E", "Q_P", "Q_L",
+             "dllDiscr", "dllDiscrFilt", "pllDiscr", "pllDiscrFilt")
+    r = trk.results
+    series = np.stack([np.stack([np.asarray(r[i][k], dtype=np.float64) for k in names]) for i in range(len(r))])
+    print("trk_float32", series.shape, "codePhase (bytes)", a2.channels.codePhase, "I_P rms",
+          np.sqrt(np.mean(series[:, 3, 40:] ** 2, axis=1)))
+    np.savez_compressed(os.path.join(HERE, "trk_float32.npz"), scene=scene_json(sc), n_samples=np.int64(len(recf)),
+                        ms=np.int64(ms), skip=np.int64(skip), names=np.array(names), series=series, PRN=a2.channels.PRN,
+                        acquiredFreq=a2.channels.acquiredFreq, codePhase=np.array(a2.channels.codePhase, dtype=np.float64))
+
+
 def scene_json(sc):
     return json.dumps(dict(seed=sc.seed, fs=sc.fs, sats=sc.sats))
 
@@ -449,6 +491,9 @@ def main():
             return
         if os.environ.get("SGX_GOLDEN_ONLY", "") == "int16":
             golden_int16(tmp, initialize, acquisition, tracking)
+            return
+        if os.environ.get("SGX_GOLDEN_ONLY", "") == "float32":
+            golden_float32(tmp, initialize, acquisition, tracking)
             return
         if os.environ.get("SGX_GOLDEN_ONLY", "") == "nav":
             golden_nav(tmp, initialize, acquisition, tracking)
@@ -583,6 +628,7 @@ def main():
             golden_fix(tmp, initialize, acquisition, tracking)
 
         golden_int16(tmp, initialize, acquisition, tracking)   # (part of the full run: every fixture is rewritten)
+        golden_float32(tmp, initialize, acquisition, tracking)
 
         trk2 = tracking.TrackingResult(acq_t)
         short = as_file(tmp, "short.bin", rec[:100 * n])

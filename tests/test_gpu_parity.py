@@ -1349,9 +1349,102 @@ def test_track_uint8_record_against_the_oracle(tmp_path):
     tm = ctx.timing()
     assert tm["track_kernel"] == 2 and tm["track_members"] == 1 and np.all(dm == 20)
     assert np.array_equal(many[:3, 0], want[:, 0, :20]) and _trk_err(many[:3], want[:, :, :20]) < TRK_TOL
-    s.dataType = 'float32'
-    with pytest.raises(TypeError, match="int8, uint8 and int16"):
+    s.dataType = 'float64'
+    with pytest.raises(TypeError, match="int8, uint8, int16 and float32"):
         m.TrackingResult(a, device=0).track(open(path, "rb"))
+
+
+def test_track_float32_record_matches_reference(tmp_path):
+    """The reference's own outputs for a float32 file (tests/golden/trk_float32.npz; made by tests/golden/make_golden.py):
+    block boundaries in bytes of the float file exactly, the series to rounding."""
+    g = load_golden("trk_float32.npz")
+    m = pkg()
+    rec8 = m.synth.generate(scene_from_json(g["scene"]), int(g["n_samples"]))
+    recf = ((rec8.astype(np.int32) * 200 + 7) / 32768.0).astype("<f4")
+    raw = np.concatenate([np.zeros(int(g["skip"]) // 4, "<f4"), recf])
+    s = m.Settings()
+    s.dataType = 'float32'
+    s.numberOfChannels, s.msToProcess, s.skipNumberOfBytes = len(g["PRN"]), float(g["ms"]), int(g["skip"])
+    a = m.AcquisitionResult(s, device=0)
+    a._channels = np.rec.fromarrays([g["PRN"], g["acquiredFreq"], g["codePhase"], ['T'] * len(g["PRN"])],
+                                    names='PRN,acquiredFreq,codePhase,status')
+    path = str(tmp_path / "ref.f32")
+    raw.tofile(path)
+    t = m.TrackingResult(a, device=0)
+    with open(path, "rb") as fid:
+        t.track(fid)
+    assert np.array_equal(t.series[:, 0], g["series"][:, 0]) and _trk_err(t.series, g["series"]) < TRK_TOL
+
+
+def test_track_float32_record_by_exact_narrowing(tmp_path):
+    """Settings.dataType = 'float32' (tracking.py:154): a record of floats that are integers times one power of two -
+    written from ADC samples, or normalised by 2^15 - is tracked through the int8 / int16 kernels and scaled back, which
+    is exact: against the oracle on the float bytes (positions in bytes of the float file, tracking.py:107, 255), and
+    against the integer record's own run.  Arbitrary floats, non-finite samples and a channel that starts
+    inside a sample are refused with a message."""
+    m = pkg()
+    ms = 40
+    s = m.Settings()
+    s.dataType = 'float32'
+    s.numberOfChannels = 3
+    s.msToProcess = float(ms)
+    n = s.samplesPerCode
+    rec8 = m.synth.generate(m.synth.Scene.default(), m.synth.record_length(n, ms))
+    a8 = orc.acquire(orc.OracleSettings(), rec8[:11 * n])
+    ch = orc.pre_run(orc.OracleSettings(numberOfChannels=3), a8)
+    # the reference seeks BYTES: a float channel starts on a sample of the file when its start byte is a multiple of four
+    skip = 4000
+    phase = (np.asarray(ch["codePhase"], dtype=np.int64) * 4 - 4).astype(np.float64)   # sample codePhase - 1 -> byte 4 (codePhase - 1)
+    ctx = m.engine.get_context(s, 0)
+    cases = {"adc": rec8.astype(np.float32),                                         # k = 0, eight bits
+             "normalised": ((rec8.astype(np.int32) * 200 + 7) / 32768.0).astype(np.float32)}   # k = 15, sixteen bits
+    for name, recf in cases.items():
+        raw = np.concatenate([np.zeros(skip // 4, np.float32), recf])
+        so = orc.OracleSettings(numberOfChannels=3, msToProcess=float(ms), dataType='float32', skipNumberOfBytes=skip)
+        want = orc.stack_series(orc.track(so, dict(PRN=ch["PRN"], acquiredFreq=ch["acquiredFreq"], codePhase=phase,
+                                                   status=['T'] * 3), raw))
+        s.skipNumberOfBytes = skip
+        a = m.AcquisitionResult(s, device=0)
+        a._channels = np.rec.fromarrays([ch["PRN"], ch["acquiredFreq"], phase, ['T'] * 3],
+                                        names='PRN,acquiredFreq,codePhase,status')
+        path = str(tmp_path / (name + ".f32"))
+        raw.tofile(path)
+        t = m.TrackingResult(a, device=0)
+        with open(path, "rb") as fid:
+            t.track(fid)                                   # a real file: streamed, then scanned and narrowed
+            assert fid.tell() == int(want[-1, 0, ms - 1])
+        assert np.array_equal(t.series[:, 0], want[:, 0]) and _trk_err(t.series, want) < TRK_TOL, name
+        t2 = m.TrackingResult(a, device=0)
+        t2.track(m.DeviceFile(ctx.upload_bytes(raw.view(np.int8)), 0))
+        assert np.array_equal(t2.series, t.series)
+    # the integers themselves through the int8 kernel: the float run is that run, positions in float bytes
+    s8 = m.Settings()
+    s8.numberOfChannels, s8.msToProcess, s8.skipNumberOfBytes = 3, float(ms), 0
+    a8g = m.AcquisitionResult(s8, device=0)
+    a8g._channels = np.rec.fromarrays([ch["PRN"], ch["acquiredFreq"], np.asarray(ch["codePhase"], dtype=np.float64) - 1.0, ['T'] * 3],
+                                      names='PRN,acquiredFreq,codePhase,status')
+    t8 = m.TrackingResult(a8g, device=0)
+    t8.track(m.DeviceFile(m.engine.get_context(s8, 0).upload(rec8), 0))
+    raw = np.concatenate([np.zeros(skip // 4, np.float32), cases["adc"]])
+    tf = m.TrackingResult(a, device=0)
+    tf.track(m.DeviceFile(ctx.upload_bytes(raw.view(np.int8)), 0))
+    # (the narrowed record starts at the first channel's first sample: other 16-sample groups, another order of the
+    # same additions)
+    assert np.array_equal(tf.series[:, 0], t8.series[:, 0] * 4 + skip)
+    same = t8.series.copy()
+    same[:, 0] = tf.series[:, 0]
+    assert _trk_err(tf.series, same) < 1e-10
+    # what is refused, and how
+    dev = lambda arr: m.DeviceFile(ctx.upload_bytes(np.ascontiguousarray(arr).view(np.int8)), 0)
+    with pytest.raises(m._native.SgxError, match="arbitrary floats"):
+        m.TrackingResult(a, device=0).track(dev(raw * np.float32(0.37)))
+    bad = raw.copy()
+    bad[skip // 4 + 5000] = np.nan
+    with pytest.raises(m._native.SgxError, match="NaN or infinite"):
+        m.TrackingResult(a, device=0).track(dev(bad))
+    a._channels.codePhase[1] += 1.0
+    with pytest.raises(m._native.SgxError, match="inside a sample"):
+        m.TrackingResult(a, device=0).track(dev(raw))
 
 
 @pytest.mark.parametrize("seed", list(range(31, 43)))

@@ -122,6 +122,22 @@ def test_track_int16_matches_reference():
         assert np.array_equal(orc.stack_series(out), g[case + "_series"]), case
 
 
+def test_track_float32_matches_reference():
+    """Settings.dataType = 'float32' (tracking.py:154): a record of floats (200 x + 7) / 32768 in a file with a
+    4000-byte header, channels on whole samples; byte seeks and byte positions as the reference has them."""
+    g = load_golden("trk_float32.npz")
+    synth = pkg("synth")
+    rec8 = synth.generate(scene_from_json(g["scene"]), int(g["n_samples"]))
+    recf = ((rec8.astype(np.int32) * 200 + 7) / 32768.0).astype("<f4")
+    raw = np.concatenate([np.zeros(int(g["skip"]) // 4, "<f4"), recf])
+    nch = len(g["PRN"])
+    s = orc.OracleSettings(numberOfChannels=nch, msToProcess=float(g["ms"]), dataType='float32', skipNumberOfBytes=int(g["skip"]))
+    ch = dict(PRN=g["PRN"], acquiredFreq=g["acquiredFreq"], codePhase=g["codePhase"], status=['T'] * nch)
+    out = orc.track(s, ch, raw)
+    assert out is not None
+    assert np.array_equal(orc.stack_series(out), g["series"])
+
+
 def test_track_short_read_returns_none(default_record):
     g = load_golden("trk_short.npz")
     gt = load_golden("trk_default.npz")
