@@ -1181,7 +1181,7 @@ def test_tiny_runs_and_unsupported_sample_type(default_record):
         assert np.array_equal(t.series[:, 0], g["series"][:, 0, :ms])
         assert _trk_err(t.series, g["series"][:, :, :ms]) < TRK_TOL
     s, t = _golden_tracker(m, g, ms=5)
-    s.dataType = 'float32'
+    s.dataType = 'complex64'
     with tempfile.NamedTemporaryFile(suffix=".bin") as f:
         default_record[:8 * 38192].tofile(f.name)
         with open(f.name, "rb") as fid:
