@@ -21,6 +21,11 @@ __device__ __forceinline__ cplx cmul(cplx a, cplx b) {
 }
 __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_double2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ cplx csub(cplx a, cplx b) { return make_double2(a.x - b.x, a.y - b.y); }
+// workgroup barrier that waits for LDS traffic only (__syncthreads() also waits for the wave's global loads - the next
+// tile's, requested ahead - and stores)
+__device__ __forceinline__ void lds_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 // multiply by -i (forward DFT quarter turn)
 __device__ __forceinline__ cplx mul_mi(cplx a) { return make_double2(a.y, -a.x); }
 
@@ -511,25 +516,42 @@ __device__ __forceinline__ cplx f4_twiddle(const F4Args& a, long long t) {
 
 // Sub-transform twiddles W_L^t in LDS: one table, or (long transforms) a product of two small ones.
 struct TwDirect {
+    static constexpr bool kPowers = false;
     const cplx* t;
     __device__ __forceinline__ cplx operator[](int i) const { return t[i]; }
 };
 struct TwTwoLevel {   // W_L^t = hi[t >> 6] * lo[t & 63]
+    // a butterfly's R - 1 twiddles are the powers of ONE: looked up once (two reads and a product), the others by
+    // squaring and multiplying (depth 4 for radix 16) - every look-up of this table costs a product anyway, and the
+    // 4096-point rows kernel spent more LDS reads on its twiddles than on its data
+    static constexpr bool kPowers = true;
     const cplx* hi;
     const cplx* lo;
     __device__ __forceinline__ cplx operator[](int i) const { return cmul(hi[i >> 6], lo[i & 63]); }
 };
 
+// w^1 .. w^(R-1) from w by squaring and multiplying (each power is one product of two lower ones, depth log2 R)
+template <int R>
+__device__ __forceinline__ void twiddle_powers(cplx w, cplx (&p)[R]) {
+    p[1] = w;
+#pragma unroll
+    for (int q = 2; q < R; ++q) p[q] = cmul(p[q / 2], p[q - q / 2]);
+}
+
 // One Stockham radix-R pass over C sequences of length L in LDS; element n of sequence c lives at buf[n * SN + c * SC].
 // CFAST: consecutive threads take consecutive sequences (use when SC == 1), else consecutive butterflies.
 // twl[t] = W_L^t, t < L (needed when NS > 1).
-template <int L, int R, int NS, int C, int SN, int SC, int TPB, bool CFAST, class TW>
+// PADSH > 0 (SN == 1 only): element n lives at n + (n >> PADSH) - one spare element per 2^PADSH, so that a pass whose
+// lanes write with a stride of 2^PADSH elements (radix 16, first pass) spreads over the banks; SC is the padded length.
+template <int L, int R, int NS, int C, int SN, int SC, int TPB, bool CFAST, int PADSH = 0, class TW>
 __device__ __forceinline__ void lds_radix_pass(cplx* __restrict__ buf, const TW twl,
                                                const cplx* __restrict__ wr, int tid) {
+    static_assert(PADSH == 0 || SN == 1, "padding is per element");
     constexpr int M = L / R;
     constexpr int TOTAL = M * C;
     constexpr int ROUNDS = (TOTAL + TPB - 1) / TPB;
     constexpr int TS = L / (NS * R);
+    auto at = [](int n) { return PADSH ? n + (n >> PADSH) : n; };
     cplx v[ROUNDS][R];
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; ++rd) {
@@ -537,14 +559,24 @@ __device__ __forceinline__ void lds_radix_pass(cplx* __restrict__ buf, const TW 
         if (w < TOTAL) {
             const int c = CFAST ? w % C : w / M, j = CFAST ? w / C : w % M;
             const int k = j % NS;
+            if constexpr (TW::kPowers && (NS > 1)) {
+                cplx pw[R];
+                twiddle_powers<R>(twl[k * TS], pw);
 #pragma unroll
-            for (int q = 0; q < R; ++q) {
-                v[rd][q] = buf[(j + q * M) * SN + c * SC];
-                if (NS > 1 && q > 0) v[rd][q] = cmul(v[rd][q], twl[q * k * TS]);   // q k TS < L
+                for (int q = 0; q < R; ++q) {
+                    v[rd][q] = buf[at(j + q * M) * SN + c * SC];
+                    if (q > 0) v[rd][q] = cmul(v[rd][q], pw[q]);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < R; ++q) {
+                    v[rd][q] = buf[at(j + q * M) * SN + c * SC];
+                    if (NS > 1 && q > 0) v[rd][q] = cmul(v[rd][q], twl[q * k * TS]);   // q k TS < L
+                }
             }
         }
     }
-    __syncthreads();
+    lds_sync();
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; ++rd) {
         const int w = tid + rd * TPB;
@@ -554,15 +586,15 @@ __device__ __forceinline__ void lds_radix_pass(cplx* __restrict__ buf, const TW 
             const int j0 = (j / NS) * NS * R + k;
             if constexpr ((R % 2 == 1) && (R >= 11)) {
                 // large odd radix: outputs go to LDS as they are produced (half the live registers)
-                dft_odd_emit<R>(v[rd], wr, [&](int q, cplx V) { buf[(j0 + q * NS) * SN + c * SC] = V; });
+                dft_odd_emit<R>(v[rd], wr, [&](int q, cplx V) { buf[at(j0 + q * NS) * SN + c * SC] = V; });
             } else {
                 dft_small<R>(v[rd], wr);
 #pragma unroll
-                for (int q = 0; q < R; ++q) buf[(j0 + q * NS) * SN + c * SC] = v[rd][q];
+                for (int q = 0; q < R; ++q) buf[at(j0 + q * NS) * SN + c * SC] = v[rd][q];
             }
         }
     }
-    __syncthreads();
+    lds_sync();
 }
 
 // An odd radix whose outputs are shared by PARTS waves: each produces a compile-time subset of the output pairs
@@ -1112,199 +1144,248 @@ struct FineArgs {
     const cplx* tw_n2_hi;     // W_4096^(64 h), h < 64
     const cplx* tw_n2_lo;     // W_4096^l, l < 64
     long long lo, hi;         // arg-max range [lo, hi)
-    double* pv;               // [n_det][FF_N1 / 2 + 1] per-workgroup maxima
+    double* pv;               // [n_det][FF_N1 / 2] per-workgroup maxima
     long long* pi;
 };
 
-__global__ __launch_bounds__(FF_TPB) void fine_cols_kernel(FineArgs a) {
+__global__ __launch_bounds__(FF_TPB) void fine_cols_kernel(FineArgs a, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) char f4_smem[];
     cplx* __restrict__ buf = reinterpret_cast<cplx*>(f4_smem);   // [FF_N1][FF_C]
     cplx* __restrict__ twl = buf + FF_N1 * FF_C;                 // [FF_N1]
     const int tid = threadIdx.x;
     static_assert(FF_N1 == 2 * FF_TPB, "two staging registers");
-    const cplx twa = a.tw_n1[tid], twb = a.tw_n1[tid + FF_TPB];   // (stored to LDS behind the input's loads)
-    const int c0 = blockIdx.x * FF_C;
-    const int r = blockIdx.y;
-    const int d0 = 2 * r, d1 = 2 * r + 1;
-    const long long pa = a.det_phase[d0];
-    const int8_t* __restrict__ ca = a.codes + a.det_prn[d0] * 1023;
-    const bool two = d1 < a.n_det;
-    const long long pb = two ? a.det_phase[d1] : pa;
-    const int8_t* __restrict__ cb = two ? a.codes + a.det_prn[d1] * 1023 : ca;
+    twl[tid] = a.tw_n1[tid];
+    twl[tid + FF_TPB] = a.tw_n1[tid + FF_TPB];
     const double mean = (a.x.f64 ? __longlong_as_double(a.d_sum[0]) : (double)a.d_sum[0]) / a.n_mean;
-    // Only the first len / FF_N2 (< 94 of 1024) rows of a column are non-zero: the rounds that can hold samples are
-    // unrolled with their loads in flight together, the rest is a zero fill.
-    constexpr int ROUNDS = FF_N1 * FF_C / FF_TPB;
-    const int live = (int)((a.len + FF_N2 - 1) / FF_N2) * FF_C;      // elements e < live may be non-zero
-    if (live <= 2 * FF_TPB) {
-        double xa[2], xb[2], sa[2], sb[2];
-        bool in_[2];
+    // Only the first len / FF_N2 (< 94 of 1024) rows of a column are non-zero.  `live` = elements of a tile that may be.
+    constexpr int TILES_PER_ROW = FF_N2 / FF_C;
+    const int live = (int)((a.len + FF_N2 - 1) / FF_N2) * FF_C;
+    const bool few = live <= 2 * FF_TPB;      // the usual case: two elements per thread, the rest of the tile is zero
+    // A workgroup holds one tile (128 KB of LDS: one workgroup per CU) and walks tiles t = blockIdx.x, + gridDim.x, ...
+    // (spectrum t / 512, columns 8 (t % 512) ...).  The NEXT tile's two samples and code chips per thread - a division,
+    // two dependent loads - are fetched during this tile's passes, and this tile's stores drain during the next one's.
+    // (named registers: an array that lives across the loop is left in scratch memory by the compiler)
+    double xa0 = 0.0, xa1 = 0.0, xb0 = 0.0, xb1 = 0.0, sa0 = 0.0, sa1 = 0.0, sb0 = 0.0, sb1 = 0.0;
+    bool in0 = false, in1 = false;
+#define FC_ONE(e_, c0_, pa_, pb_, ca_, cb_, two_, in_, xa_, xb_, sa_, sb_)                                    \
+    do {                                                                                                      \
+        const long long i_ = (long long)((e_) / FF_C) * FF_N2 + (c0_) + (e_) % FF_C;                          \
+        in_ = i_ < a.len;                                                                                     \
+        xa_ = xb_ = sa_ = sb_ = 0.0;                                                                          \
+        if (in_) {                                                                                            \
+            const double v_ = floor((a.ts * (double)(i_ + 1)) / a.tc1);       /* acquisition.py:172 (A9) */   \
+            const int chip_ = (int)((long long)v_ % 1023);                                                    \
+            xa_ = a.x.at((pa_) + i_);                                                                         \
+            sa_ = (double)(ca_)[chip_];                                                                       \
+            if (two_) {                                                                                       \
+                xb_ = a.x.at((pb_) + i_);                                                                     \
+                sb_ = (double)(cb_)[chip_];                                                                   \
+            }                                                                                                 \
+        }                                                                                                     \
+    } while (0)
+#define FC_REQUEST(t_)                                                                                        \
+    do {                                                                                                      \
+        const int r_ = (t_) / TILES_PER_ROW, c0_ = ((t_) % TILES_PER_ROW) * FF_C;                              \
+        const int d0_ = 2 * r_, d1_ = 2 * r_ + 1;                                                             \
+        const bool two_ = d1_ < a.n_det;                                                                      \
+        const long long pa_ = a.det_phase[d0_], pb_ = two_ ? a.det_phase[d1_] : pa_;                          \
+        const int8_t* __restrict__ ca_ = a.codes + a.det_prn[d0_] * 1023;                                    \
+        const int8_t* __restrict__ cb_ = two_ ? a.codes + a.det_prn[d1_] * 1023 : ca_;                        \
+        FC_ONE(tid, c0_, pa_, pb_, ca_, cb_, two_, in0, xa0, xb0, sa0, sb0);                                  \
+        FC_ONE(tid + FF_TPB, c0_, pa_, pb_, ca_, cb_, two_, in1, xa1, xb1, sa1, sb1);                         \
+    } while (0)
+    int t = blockIdx.x;
+    if (few && t < n_tiles) FC_REQUEST(t);
+    for (; t < n_tiles; t += gridDim.x) {
+        const int r = t / TILES_PER_ROW, c0 = (t % TILES_PER_ROW) * FF_C;
+        const bool two = 2 * r + 1 < a.n_det;
+        if (few) {
+            buf[tid] = in0 ? make_double2((xa0 - mean) * sa0, two ? (xb0 - mean) * sb0 : 0.0) : make_double2(0.0, 0.0);
+            buf[tid + FF_TPB] = in1 ? make_double2((xa1 - mean) * sa1, two ? (xb1 - mean) * sb1 : 0.0) : make_double2(0.0, 0.0);
+            if (t + (int)gridDim.x < n_tiles) FC_REQUEST(t + (int)gridDim.x);
+            lds_sync();
+            // first pass (radix 16, inputs n1 = j + 64 q): only q = 0, 1 can be non-zero (n1 < 128), so a butterfly is
+            // out[q'] = v0 + v1 W_16^q' - no zero fill, no reads of zeros, no 16-point transform
+            static_assert(FF_N1 / 16 * FF_C == FF_TPB, "one butterfly per thread");
+            const int c = tid % FF_C, j = tid / FF_C;
+            const cplx v0 = buf[j * FF_C + c], v1 = buf[(j + FF_N1 / 16) * FF_C + c];
+            lds_sync();
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int e = tid + k * FF_TPB;
-            const long long i = (long long)(e / FF_C) * FF_N2 + c0 + e % FF_C;
-            in_[k] = i < a.len;
-            xa[k] = xb[k] = sa[k] = sb[k] = 0.0;
-            if (in_[k]) {
-                const double v = floor((a.ts * (double)(i + 1)) / a.tc1);       // acquisition.py:172 (A9)
-                const int chip = (int)((long long)v % 1023);
-                xa[k] = a.x.at(pa + i);
-                sa[k] = (double)ca[chip];
-                if (two) {
-                    xb[k] = a.x.at(pb + i);
-                    sb[k] = (double)cb[chip];
+            for (int q = 0; q < 16; ++q) {
+                const cplx wq = a.wr16[q];
+                buf[(j * 16 + q) * FF_C + c] = (q == 0) ? cadd(v0, v1) : cadd(v0, cmul(v1, wq));
+            }
+            lds_sync();
+        } else {
+            const int d0 = 2 * r, d1 = 2 * r + 1;
+            const long long pa = a.det_phase[d0], pb = two ? a.det_phase[d1] : pa;
+            const int8_t* __restrict__ ca = a.codes + a.det_prn[d0] * 1023;
+            const int8_t* __restrict__ cb = two ? a.codes + a.det_prn[d1] * 1023 : ca;
+            for (int e = tid; e < FF_N1 * FF_C; e += FF_TPB) {
+                bool in_;
+                double xa_, xb_, sa_, sb_;
+                FC_ONE(e, c0, pa, pb, ca, cb, two, in_, xa_, xb_, sa_, sb_);
+                buf[e] = in_ ? make_double2((xa_ - mean) * sa_, two ? (xb_ - mean) * sb_ : 0.0) : make_double2(0.0, 0.0);
+            }
+            lds_sync();
+            const TwDirect tw1{twl};
+            lds_radix_pass<FF_N1, 16, 1, FF_C, FF_C, 1, FF_TPB, true>(buf, tw1, a.wr16, tid);
+        }
+        const TwDirect tw{twl};
+        lds_radix_pass<FF_N1, 16, 16, FF_C, FF_C, 1, FF_TPB, true>(buf, tw, a.wr16, tid);
+        lds_radix_pass<FF_N1, 4, 256, FF_C, FF_C, 1, FF_TPB, true>(buf, tw, a.wr4, tid);
+        // element (k1, n2) times W_M^(n2 k1): a thread keeps its column and advances k1 by FF_TPB / FF_C; table look-ups
+        // for its first element and for the step factor, the other 15 by recurrence (a rolled loop of look-ups runs one
+        // memory round trip per element)
+        cplx* __restrict__ out = a.work + (long long)r * FF_N1 * FF_N2;
+        static_assert(FF_TPB % FF_C == 0 && FF_N1 % (FF_TPB / FF_C) == 0, "a thread keeps its column");
+        constexpr int STEP = FF_TPB / FF_C;
+        const int n2 = c0 + tid % FF_C, k1b = tid / FF_C;
+        auto look = [&](long long tt) { return cmul(a.tw_hi[tt >> a.lo_bits], a.tw_lo[tt & ((1ll << a.lo_bits) - 1)]); };
+        cplx w = look((long long)n2 * k1b);
+        const cplx ws = look((long long)n2 * STEP);
+#pragma unroll
+        for (int i = 0; i < FF_N1 / STEP; ++i) {
+            const int k1 = k1b + i * STEP;
+            out[(long long)k1 * FF_N2 + n2] = cmul(buf[k1 * FF_C + tid % FF_C], w);
+            w = cmul(w, ws);
+        }
+        lds_sync();   // (the next tile's samples go where this one's spectrum is being read)
+    }
+#undef FC_REQUEST
+#undef FC_ONE
+}
+
+__global__ __launch_bounds__(FF_TPB) void fine_rows_kernel(FineArgs a, int n_pairs) {
+    extern __shared__ __attribute__((aligned(16))) char f4_smem[];
+    constexpr int RP = FF_N2 + FF_N2 / 16;                       // a row with one spare element per 16 (lds_radix_pass)
+    cplx* __restrict__ buf = reinterpret_cast<cplx*>(f4_smem);   // [2][RP]
+    cplx* __restrict__ thi = buf + 2 * RP;                       // [64]
+    cplx* __restrict__ tlo = thi + 64;                           // [64]
+    double* __restrict__ s_v = reinterpret_cast<double*>(tlo + 64);                  // [2][FF_TPB / 64]
+    long long* __restrict__ s_i = reinterpret_cast<long long*>(s_v + 2 * (FF_TPB / 64));
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        thi[tid] = a.tw_n2_hi[tid];
+        tlo[tid] = a.tw_n2_lo[tid];
+    }
+    // A workgroup holds two rows (128 KB of LDS: one workgroup per CU) and walks pairs p = blockIdx.x, + gridDim.x, ...:
+    // the NEXT pair's rows are requested as soon as this pair's have been handed to LDS and arrive during its three
+    // passes (one workgroup per pair loaded, transformed and reduced one after the other with nothing else on the CU).
+    // Pair p: spectrum r = p / 512, rows bx and 1024 - bx, bx = p % 512; rows 0 and 512 are their OWN mirrors and share
+    // bx = 0.
+    constexpr int PER = FF_N2 / FF_TPB;
+    static_assert(FF_N2 % FF_TPB == 0, "whole rounds");
+    constexpr int HALF = FF_N1 / 2;
+    static_assert(PER == 8, "sixteen staging registers");
+    // (named: an array that lives across the loop is left in scratch memory by the compiler)
+    cplx a0, a1, a2, a3, a4, a5, a6, a7, b0, b1, b2, b3, b4, b5, b6, b7;
+#define FR_REQUEST(p_)                                                                                       \
+    do {                                                                                                     \
+        const int r_ = (p_) / HALF, bx_ = (p_) % HALF;                                                       \
+        const cplx* __restrict__ pa_ = a.work + ((long long)r_ * FF_N1 + bx_) * FF_N2 + tid;                 \
+        const cplx* __restrict__ pb_ = a.work + ((long long)r_ * FF_N1 + (bx_ == 0 ? HALF : FF_N1 - bx_)) * FF_N2 + tid; \
+        a0 = pa_[0 * FF_TPB]; a1 = pa_[1 * FF_TPB]; a2 = pa_[2 * FF_TPB]; a3 = pa_[3 * FF_TPB];               \
+        a4 = pa_[4 * FF_TPB]; a5 = pa_[5 * FF_TPB]; a6 = pa_[6 * FF_TPB]; a7 = pa_[7 * FF_TPB];               \
+        b0 = pb_[0 * FF_TPB]; b1 = pb_[1 * FF_TPB]; b2 = pb_[2 * FF_TPB]; b3 = pb_[3 * FF_TPB];               \
+        b4 = pb_[4 * FF_TPB]; b5 = pb_[5 * FF_TPB]; b6 = pb_[6 * FF_TPB]; b7 = pb_[7 * FF_TPB];               \
+    } while (0)
+    int p = blockIdx.x;
+    a0 = a1 = a2 = a3 = a4 = a5 = a6 = a7 = b0 = b1 = b2 = b3 = b4 = b5 = b6 = b7 = make_double2(0.0, 0.0);
+    if (p < n_pairs) FR_REQUEST(p);
+    for (; p < n_pairs; p += gridDim.x) {
+        const int r = p / HALF, bx = p % HALF;
+        const bool single = (bx == 0);
+        const int rowA = bx, rowB = single ? HALF : FF_N1 - bx;
+        {
+            auto at = [](int n) { return n + (n >> 4); };
+            cplx* __restrict__ A = buf + at(tid);          // (FF_TPB is a multiple of 16: round i is 17 FF_TPB / 16 further on)
+            cplx* __restrict__ B = A + RP;
+            constexpr int ST = FF_TPB + FF_TPB / 16;
+            A[0 * ST] = a0; A[1 * ST] = a1; A[2 * ST] = a2; A[3 * ST] = a3; A[4 * ST] = a4; A[5 * ST] = a5; A[6 * ST] = a6; A[7 * ST] = a7;
+            B[0 * ST] = b0; B[1 * ST] = b1; B[2 * ST] = b2; B[3 * ST] = b3; B[4 * ST] = b4; B[5 * ST] = b5; B[6 * ST] = b6; B[7 * ST] = b7;
+        }
+        if (p + (int)gridDim.x < n_pairs) FR_REQUEST(p + (int)gridDim.x);
+        lds_sync();
+        const TwTwoLevel tw{thi, tlo};
+        lds_radix_pass<FF_N2, 16, 1, 2, 1, RP, FF_TPB, false, 4>(buf, tw, a.wr16, tid);
+        lds_radix_pass<FF_N2, 16, 16, 2, 1, RP, FF_TPB, false, 4>(buf, tw, a.wr16, tid);
+        lds_radix_pass<FF_N2, 16, 256, 2, 1, RP, FF_TPB, false, 4>(buf, tw, a.wr16, tid);
+        // Z[k1 + 1024 k2] = row k1, element k2;  Z[M - k] = row (1024 - k1) mod 1024, element 4095 - k2 (k1 > 0) or
+        // 4096 - k2 (k1 = 0, k2 > 0)
+        double best[2] = {-1.0, -1.0};
+        long long arg[2] = {a.lo, a.lo};
+        for (int rr = 0; rr < 2; ++rr) {
+            const int k1 = rr == 0 ? rowA : rowB;
+            const cplx* __restrict__ me = buf + rr * RP;
+            const cplx* __restrict__ other = buf + (single ? rr : (1 - rr)) * RP;
+            for (int k2 = tid; k2 < FF_N2; k2 += FF_TPB) {
+                const long long k = (long long)k1 + (long long)FF_N1 * k2;
+                if (k < a.lo || k >= a.hi) continue;
+                const int ko = (k1 == 0) ? FF_N2 - k2 : FF_N2 - 1 - k2;     // k >= 4 excludes k1 = 0, k2 = 0
+                const cplx z = me[k2 + (k2 >> 4)];
+                const cplx w = other[ko + (ko >> 4)];
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const double sgn = d ? -1.0 : 1.0;
+                    const double re = z.x + sgn * w.x, im = z.y - sgn * w.y;   // z +- conj(w)
+                    const double v = re * re + im * im;
+                    if (v > best[d] || (v == best[d] && k < arg[d])) {
+                        best[d] = v;
+                        arg[d] = k;
+                    }
                 }
             }
         }
-        twl[tid] = twa;
-        twl[tid + FF_TPB] = twb;
+        // (maximum, first index) of each detection: inside the waves by shuffles, across them by one LDS hop
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
-            buf[tid + k * FF_TPB] = in_[k] ? make_double2((xa[k] - mean) * sa[k], two ? (xb[k] - mean) * sb[k] : 0.0)
-                                           : make_double2(0.0, 0.0);
+        for (int d = 0; d < 2; ++d) {
+            double bv = best[d];
+            long long bi = arg[d];
 #pragma unroll
-        for (int k = 2; k < ROUNDS; ++k) buf[tid + k * FF_TPB] = make_double2(0.0, 0.0);
-    } else {
-        twl[tid] = twa;
-        twl[tid + FF_TPB] = twb;
-        for (int e = tid; e < FF_N1 * FF_C; e += FF_TPB) {
-            const int n1 = e / FF_C, c = e % FF_C;
-            const long long i = (long long)n1 * FF_N2 + c0 + c;
-            cplx val = make_double2(0.0, 0.0);
-            if (i < a.len) {
-                const double v = floor((a.ts * (double)(i + 1)) / a.tc1);       // acquisition.py:172 (A9)
-                const int chip = (int)((long long)v % 1023);
-                const double va = (a.x.at(pa + i) - mean) * (double)ca[chip];
-                const double vb = two ? (a.x.at(pb + i) - mean) * (double)cb[chip] : 0.0;
-                val = make_double2(va, vb);
+            for (int off = 32; off > 0; off >>= 1) {
+                const double ov = __shfl_down(bv, off);
+                const long long oi = __shfl_down(bi, off);
+                if (ov > bv || (ov == bv && oi < bi)) {
+                    bv = ov;
+                    bi = oi;
+                }
             }
-            buf[e] = val;
+            if ((tid & 63) == 0) {
+                s_v[d * (FF_TPB / 64) + (tid >> 6)] = bv;
+                s_i[d * (FF_TPB / 64) + (tid >> 6)] = bi;
+            }
         }
-    }
-    __syncthreads();
-    const TwDirect tw{twl};
-    lds_radix_pass<FF_N1, 16, 1, FF_C, FF_C, 1, FF_TPB, true>(buf, tw, a.wr16, tid);
-    lds_radix_pass<FF_N1, 16, 16, FF_C, FF_C, 1, FF_TPB, true>(buf, tw, a.wr16, tid);
-    lds_radix_pass<FF_N1, 4, 256, FF_C, FF_C, 1, FF_TPB, true>(buf, tw, a.wr4, tid);
-    // element (k1, n2) times W_M^(n2 k1): a thread keeps its column and advances k1 by FF_TPB / FF_C; table look-ups
-    // for its first element and for the step factor, the other 15 by recurrence (a rolled loop of look-ups runs one
-    // memory round trip per element)
-    cplx* __restrict__ out = a.work + (long long)r * FF_N1 * FF_N2;
-    static_assert(FF_TPB % FF_C == 0 && FF_N1 % (FF_TPB / FF_C) == 0, "a thread keeps its column");
-    constexpr int STEP = FF_TPB / FF_C;
-    const int n2 = c0 + tid % FF_C, k1b = tid / FF_C;
-    auto look = [&](long long t) { return cmul(a.tw_hi[t >> a.lo_bits], a.tw_lo[t & ((1ll << a.lo_bits) - 1)]); };
-    cplx w = look((long long)n2 * k1b);
-    const cplx ws = look((long long)n2 * STEP);
-#pragma unroll
-    for (int i = 0; i < FF_N1 / STEP; ++i) {
-        const int k1 = k1b + i * STEP;
-        out[(long long)k1 * FF_N2 + n2] = cmul(buf[k1 * FF_C + tid % FF_C], w);
-        w = cmul(w, ws);
+        lds_sync();
+        if (tid < 2) {
+            const int det = 2 * r + tid;
+            if (det < a.n_det) {
+                double bv = s_v[tid * (FF_TPB / 64)];
+                long long bi = s_i[tid * (FF_TPB / 64)];
+                for (int w = 1; w < FF_TPB / 64; ++w) {
+                    const double ov = s_v[tid * (FF_TPB / 64) + w];
+                    const long long oi = s_i[tid * (FF_TPB / 64) + w];
+                    if (ov > bv || (ov == bv && oi < bi)) {
+                        bv = ov;
+                        bi = oi;
+                    }
+                }
+                a.pv[(long long)det * HALF + bx] = bv;
+                a.pi[(long long)det * HALF + bx] = bi;
+            }
+        }
+        // (the next pair's rows overwrite buf and the slots: everybody is past both by the barrier of the next turn...
+        // which comes AFTER those stores; so one more here)
+        lds_sync();
     }
 }
 
-__global__ __launch_bounds__(FF_TPB) void fine_rows_kernel(FineArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char f4_smem[];
-    cplx* __restrict__ buf = reinterpret_cast<cplx*>(f4_smem);   // [2][FF_N2]
-    cplx* __restrict__ thi = buf + 2 * FF_N2;                    // [64]
-    cplx* __restrict__ tlo = thi + 64;                           // [64]
-    const int tid = threadIdx.x;
-    // (loaded now, stored to LDS behind the rows' own loads: no memory round trip of its own)
-    cplx th0 = make_double2(0.0, 0.0), tl0 = make_double2(0.0, 0.0);
-    if (tid < 64) {
-        th0 = a.tw_n2_hi[tid];
-        tl0 = a.tw_n2_lo[tid];
-    }
-    const int bx = blockIdx.x;                 // 0: row 0 alone; FF_N1 / 2: row 512 alone; else rows bx and FF_N1 - bx
-    const int r = blockIdx.y;
-    const bool single = (bx == 0 || bx == FF_N1 / 2);
-    const int rowA = bx, rowB = single ? bx : FF_N1 - bx;
-    const cplx* __restrict__ in = a.work + (long long)r * FF_N1 * FF_N2;
-    {
-        // both rows' loads in flight together (a single row is simply transformed twice)
-        constexpr int PER = FF_N2 / FF_TPB;
-        static_assert(FF_N2 % FF_TPB == 0, "whole rounds");
-        cplx ra[PER], rb[PER];
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            ra[i] = in[(long long)rowA * FF_N2 + tid + i * FF_TPB];
-            rb[i] = in[(long long)rowB * FF_N2 + tid + i * FF_TPB];
-        }
-        if (tid < 64) {
-            thi[tid] = th0;
-            tlo[tid] = tl0;
-        }
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            buf[tid + i * FF_TPB] = ra[i];
-            buf[FF_N2 + tid + i * FF_TPB] = rb[i];
-        }
-    }
-    __syncthreads();
-    const TwTwoLevel tw{thi, tlo};
-    lds_radix_pass<FF_N2, 16, 1, 2, 1, FF_N2, FF_TPB, false>(buf, tw, a.wr16, tid);
-    lds_radix_pass<FF_N2, 16, 16, 2, 1, FF_N2, FF_TPB, false>(buf, tw, a.wr16, tid);
-    lds_radix_pass<FF_N2, 16, 256, 2, 1, FF_N2, FF_TPB, false>(buf, tw, a.wr16, tid);
-    // Z[k1 + 1024 k2] = row k1, element k2;  Z[M - k] = row (1024 - k1) mod 1024, element 4095 - k2 (k1 > 0) or
-    // 4096 - k2 (k1 = 0, k2 > 0)
-    double best[2] = {-1.0, -1.0};
-    long long arg[2] = {a.lo, a.lo};
-    const int nrow = single ? 1 : 2;
-    for (int rr = 0; rr < nrow; ++rr) {
-        const int k1 = rr == 0 ? rowA : rowB;
-        const cplx* __restrict__ me = buf + rr * FF_N2;
-        const cplx* __restrict__ other = buf + (single ? 0 : (1 - rr)) * FF_N2;
-        for (int k2 = tid; k2 < FF_N2; k2 += FF_TPB) {
-            const long long k = (long long)k1 + (long long)FF_N1 * k2;
-            if (k < a.lo || k >= a.hi) continue;
-            const int ko = (k1 == 0) ? FF_N2 - k2 : FF_N2 - 1 - k2;     // k >= 4 excludes k1 = 0, k2 = 0
-            const cplx z = me[k2];
-            const cplx w = other[ko];
-#pragma unroll
-            for (int d = 0; d < 2; ++d) {
-                const double sgn = d ? -1.0 : 1.0;
-                const double re = z.x + sgn * w.x, im = z.y - sgn * w.y;   // z +- conj(w)
-                const double v = re * re + im * im;
-                if (v > best[d] || (v == best[d] && k < arg[d])) {
-                    best[d] = v;
-                    arg[d] = k;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    double* s_v = reinterpret_cast<double*>(f4_smem);
-    long long* s_i = reinterpret_cast<long long*>(f4_smem + sizeof(double) * FF_TPB);
-    for (int d = 0; d < 2; ++d) {
-        const int det = 2 * r + d;
-        if (det >= a.n_det) break;
-        s_v[tid] = best[d];
-        s_i[tid] = arg[d];
-        __syncthreads();
-        for (int st = FF_TPB / 2; st > 0; st >>= 1) {
-            if (tid < st) {
-                const double ov = s_v[tid + st];
-                const long long oi = s_i[tid + st];
-                if (ov > s_v[tid] || (ov == s_v[tid] && oi < s_i[tid])) {
-                    s_v[tid] = ov;
-                    s_i[tid] = oi;
-                }
-            }
-            __syncthreads();
-        }
-        if (tid == 0) {
-            a.pv[(long long)det * gridDim.x + bx] = s_v[0];
-            a.pi[(long long)det * gridDim.x + bx] = s_i[0];
-        }
-        __syncthreads();
-    }
-}
+#undef FR_REQUEST
 
 static cplx* g_ff_tab[SGX_MAX_DEVICES][3] = {{nullptr, nullptr, nullptr}};   // W_1024^t | W_4096^(64 h) | W_4096^l
 
 bool sgx_fft_fine_supported(int64_t npts) { return npts == (int64_t)FF_N1 * FF_N2; }
-int sgx_fft_fine_partials(void) { return FF_N1 / 2 + 1; }
+int sgx_fft_fine_partials(void) { return FF_N1 / 2; }
 
 // Fine search of n_det detections (two per complex row) on the 2^22-point two-kernel transform.  `plan` = the 2^22
 // plan (its two-level table of W_M is used for the inter-step twiddles).  Fills pv / pi [n_det][sgx_fft_fine_partials()].
@@ -1374,15 +1455,26 @@ int sgx_fft_fine_search(const FftPlan* plan, SgxSig x, const int8_t* codes, cons
     a.pi = pi;
     const int n_rows = (n_det + 1) / 2;
     const size_t lds_c = sizeof(cplx) * (FF_N1 * FF_C + FF_N1);
-    const size_t lds_r = sizeof(cplx) * (2 * FF_N2 + 128);
+    const size_t lds_r = sizeof(cplx) * (2 * (FF_N2 + FF_N2 / 16) + 128) + (sizeof(double) + sizeof(long long)) * 2 * (FF_TPB / 64);
     static std::atomic<bool> once[SGX_MAX_DEVICES];
     if (!once[dev].load()) {
         hipFuncSetAttribute((const void*)fine_cols_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
         hipFuncSetAttribute((const void*)fine_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
         once[dev].store(true);
     }
-    fine_cols_kernel<<<dim3(FF_N2 / FF_C, (unsigned)n_rows), FF_TPB, lds_c, st>>>(a);
-    fine_rows_kernel<<<dim3(FF_N1 / 2 + 1, (unsigned)n_rows), FF_TPB, lds_r, st>>>(a);
+    int cus = 256;
+    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    {
+        // persistent workgroups, one per CU (128 KB of LDS each), walking the (spectrum, column tile) list
+        const int n_tiles = (FF_N2 / FF_C) * n_rows;
+        fine_cols_kernel<<<n_tiles < cus ? n_tiles : cus, FF_TPB, lds_c, st>>>(a, n_tiles);
+    }
+    {
+        // persistent workgroups, one per CU (128 KB of LDS each), walking the (spectrum, row pair) list
+        const int n_pairs = (FF_N1 / 2) * n_rows;
+        const int grid = n_pairs < cus ? n_pairs : cus;
+        fine_rows_kernel<<<grid, FF_TPB, lds_r, st>>>(a, n_pairs);
+    }
     SGX_HIP(hipGetLastError());
     return SGX_OK;
 }
