@@ -1,9 +1,9 @@
 #!/bin/bash
-# (diagnosis) duration of the two fine-search kernels for side-by-side builds of the library: lib/libsgx_<name>.so. GPU box.
+# (diagnosis) duration of the two fine-search kernels for side-by-side builds of the library: lib/variants/libsgx_<name>.so (tools/build_variant.sh). GPU box.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for name in "$@"; do
   rm -rf gpurun_out/prof_var
-  export SGX_LIB=$GRAFT_REPO_ROOT/softgnss-python_amd/lib/libsgx_$name.so
+  export SGX_LIB=$GRAFT_REPO_ROOT/softgnss-python_amd/lib/variants/libsgx_$name.so
   rocprofv3 --kernel-trace -d gpurun_out/prof_var -- python3 tools/acq_once.py 4 > gpurun_out/var_$name.log 2>&1
   python3 - <<PY
 import glob, sqlite3
