@@ -286,6 +286,7 @@ struct T2Shared {
 #endif
 
 // a lane's 16 samples as loaded: one 16-byte word of int8, or two of int16
+typedef double t2_v2d __attribute__((ext_vector_type(2)));
 template <int SB> struct T2Raw;
 template <> struct T2Raw<1> { uint4 a; };
 template <> struct T2Raw<2> { uint4 a, b; };
@@ -674,6 +675,18 @@ __device__ __forceinline__ int t2_map1_role(T2Shared& S, const int8_t* __restric
         if (hd.y) break;
         T2_FP_TOP
         __builtin_amdgcn_s_setprio(2);
+        // the block's 16 sample phasors: requested NOW (the compiler sinks these reads to their uses, four ahead of the
+        // FMAs, with a wait in front of every pair), waited for once in front of the accumulation - they arrive while the
+        // ramp is located: 52.5 -> 51.4 ms.  (asm: the reads and their one wait are invisible to the compiler's own
+        // counting, which in-order LDS returns make safe; the registers are live from the read to the wait statement)
+        t2_v2d Bt[16];
+        {
+            const unsigned ba = (unsigned)(unsigned long long)&CR.T[T2_B];
+#define T2_BLD(i) asm volatile("ds_read_b128 %0, %1 offset:" #i "*16" : "=v"(Bt[i]) : "v"(ba))
+            T2_BLD(0); T2_BLD(1); T2_BLD(2); T2_BLD(3); T2_BLD(4); T2_BLD(5); T2_BLD(6); T2_BLD(7);
+            T2_BLD(8); T2_BLD(9); T2_BLD(10); T2_BLD(11); T2_BLD(12); T2_BLD(13); T2_BLD(14); T2_BLD(15);
+#undef T2_BLD
+        }
         const int blk = hd.x;
         const double inv_step = __hiloint2double(hd.w, hd.z);
         // next block's bytes: the address was prepared for the predicted length
@@ -719,9 +732,12 @@ __device__ __forceinline__ int t2_map1_role(T2Shared& S, const int8_t* __restric
         }
         T2PROBE(prof_on, 1);   // switch sample resolved, group phasor
         double Ac = 0.0, As = 0.0;
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Bt[0]), "+v"(Bt[1]), "+v"(Bt[2]), "+v"(Bt[3]), "+v"(Bt[4]), "+v"(Bt[5]), "+v"(Bt[6]),
+                     "+v"(Bt[7]), "+v"(Bt[8]), "+v"(Bt[9]), "+v"(Bt[10]), "+v"(Bt[11]), "+v"(Bt[12]), "+v"(Bt[13]), "+v"(Bt[14]),
+                     "+v"(Bt[15]));
 #pragma unroll
         for (int b = 0; b < 16; ++b) {
-            const double2 Bb = CR.T[T2_B + b];
+            const double2 Bb = make_double2(Bt[b].x, Bt[b].y);
             const unsigned h = (b >= bsw) ? (xh[b] ^ 0x80000000u) : xh[b];
             const double xs = __hiloint2double((int)h, 0);
             Ac = __builtin_fma(xs, Bb.x, Ac);
