@@ -423,6 +423,17 @@ __device__ __forceinline__ int t2_map3_role(T2Shared& S, const int8_t* __restric
         if (hd.y) break;
         T2_FP_TOP
         __builtin_amdgcn_s_setprio(2);
+        // the block's 16 sample phasors, once for all of the member's units: requested now, waited for in front of the
+        // first accumulation (as in the arm-split map below)
+        t2_v2d Bt[16];
+        {
+            const unsigned ba = (unsigned)(unsigned long long)&CR.T[T2_B];
+#define T2_BLD(i) asm volatile("ds_read_b128 %0, %1 offset:" #i "*16" : "=v"(Bt[i]) : "v"(ba))
+            T2_BLD(0); T2_BLD(1); T2_BLD(2); T2_BLD(3); T2_BLD(4); T2_BLD(5); T2_BLD(6); T2_BLD(7);
+            T2_BLD(8); T2_BLD(9); T2_BLD(10); T2_BLD(11); T2_BLD(12); T2_BLD(13); T2_BLD(14); T2_BLD(15);
+#undef T2_BLD
+        }
+        bool bt_landed = false;
         const int blk = hd.x;
         const long long pos_next = pos + blk;
         const T2Raw<SB> nraw = t2_load<SB>(rec, (pos_next & ~15ll) + lane_off, limit);   // next block's bytes (first unit)
@@ -477,12 +488,18 @@ __device__ __forceinline__ int t2_map3_role(T2Shared& S, const int8_t* __restric
             swmin = swL < swmin ? swL : swmin;
             const bool eS = (swE == swmin), pS = (swP == swmin), lS = (swL == swmin);
             const bool odd = (swE < iend && !eS) || (swP < iend && !pS) || (swL < iend && !lS);
+            if (!bt_landed) {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Bt[0]), "+v"(Bt[1]), "+v"(Bt[2]), "+v"(Bt[3]), "+v"(Bt[4]), "+v"(Bt[5]),
+                             "+v"(Bt[6]), "+v"(Bt[7]), "+v"(Bt[8]), "+v"(Bt[9]), "+v"(Bt[10]), "+v"(Bt[11]), "+v"(Bt[12]), "+v"(Bt[13]),
+                             "+v"(Bt[14]), "+v"(Bt[15]));
+                bt_landed = true;
+            }
             if (__builtin_expect(__any(odd), 0)) {
                 // exact per-sample path (a ramp switches at a second position inside the group)
 #pragma unroll
                 for (int b = 0; b < 16; ++b) {
                     const int i = gi0 + b;
-                    const double2 Bb = CR.T[T2_B + b];
+                    const double2 Bb = make_double2(Bt[b].x, Bt[b].y);
                     const double c = __builtin_fma(gc, Bb.x, -(gs * Bb.y));
                     const double s_ = __builtin_fma(gs, Bb.x, gc * Bb.y);
                     const double xs = s_ * x[b], xc = c * x[b];
@@ -504,7 +521,7 @@ __device__ __forceinline__ int t2_map3_role(T2Shared& S, const int8_t* __restric
                 double Ac = 0.0, As = 0.0, Tc = 0.0, Ts = 0.0;
 #pragma unroll
                 for (int b = 0; b < 16; ++b) {
-                    const double2 Bb = CR.T[T2_B + b];
+                    const double2 Bb = make_double2(Bt[b].x, Bt[b].y);
                     Ac = __builtin_fma(x[b], Bb.x, Ac);
                     As = __builtin_fma(x[b], Bb.y, As);
                     const int keep = ~((b - bsw) >> 31);                  // all ones iff b >= bsw
