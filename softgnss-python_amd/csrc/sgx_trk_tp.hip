@@ -46,6 +46,9 @@ __device__ __forceinline__ double tp_row_bcast15(double v) {
     return __hiloint2double(ohi, olo);
 }
 
+typedef double tp_v2d __attribute__((ext_vector_type(2)));
+typedef unsigned tp_v2u __attribute__((ext_vector_type(2)));
+
 // first sample above thr from real arithmetic; `near` is raised when a sample lies within 1e-7 samples of the boundary
 __device__ __forceinline__ int tp_bound(double start, double inv_step, double thr, bool& near) {
     const double u = (thr - start) * inv_step;
@@ -170,11 +173,11 @@ __device__ __forceinline__ int tp_dot4_first(int x, int w) {
 
 // Head and tail run of a chip (bytes beyond the runs already zero): sum_k x_k B_k of each by int8 dot products against
 // the digit dwords, the runs rotated by their start phasors, the three codes applied.
-__device__ __forceinline__ void tp_runs(const int (&wr)[2][4][5], const TpCarr& car, double2 gh, int tail_off,
+__device__ __forceinline__ void tp_runs(const int (&wr)[2][4][5], double2 gh, double2 b_tail,
                                         const unsigned (&wh)[5], const unsigned (&wt)[5], bool e_switched, bool l_switched,
                                         double cP, double cEh, double cEn, double cLh, double cLn, double& aIE, double& aQE,
                                         double& aIP, double& aQP, double& aIL, double& aQL) {
-    const double2 gt = cmul2(gh, car.B[tail_off]);
+    const double2 gt = cmul2(gh, b_tail);
     // weight dwords [cos, sin][digit][d]: dword d holds the digits of k = 4 d .. 4 d + 3; in registers for the whole block
     int hc[4], hs[4], tc[4], ts[4];
 #pragma unroll
@@ -331,20 +334,45 @@ __global__ __launch_bounds__(TP_THREADS, TP_OCC) void trk_kernel_tp(const int8_t
         // bytes are requested into yh / yt.  Called alternately with the two register sets swapped, so nothing is copied.
         auto chip = [&](const TpChip& ck, int cc_, unsigned (&wh)[5], unsigned (&wt)[5], TpChip& nk, int cn_, unsigned (&yh)[5],
                         unsigned (&yt)[5]) {
-            nk = bounds_of(cn_);
-            tp_load_raw(rec, pos + nk.s0, yh);
-            tp_load_raw(rec, pos + (nk.eE > nk.eL ? nk.eE : nk.eL), yt);
             const int s0 = ck.s0, s1 = ck.s1, eE = ck.eE, eL = ck.eL;
             const int e1 = eE < eL ? eE : eL, e2 = eE < eL ? eL : eE;
             const int len_h = e1 - s0, len_t = s1 - e2;
             const int kE = (int)ceil(ramp_at(s0, stepE, startE));
             const int kL = (int)ceil(ramp_at(s0, stepL, startL));
-            const double cP = __hiloint2double((int)s_code_hi[cc_], 0);
-            const double cEh = __hiloint2double((int)s_code_hi[kE], 0), cEn = __hiloint2double((int)s_code_hi[kE + 1], 0);
-            const double cLh = __hiloint2double((int)s_code_hi[kL], 0), cLn = __hiloint2double((int)s_code_hi[kL + 1], 0);
-            // run-start phasor of the head from the four tables
-            const double2 gh = cmul2(cmul2(s_car.W3[s0 >> 12], s_car.W2[(s0 >> 8) & 15]),
-                                     cmul2(s_car.W1[(s0 >> 4) & 15], s_car.B[s0 & 15]));
+            // everything this chip reads from LDS - five code signs, the four phasor tables' entries, the tail's offset
+            // phasor - requested HERE, in front of the next chip's boundary arithmetic, and waited for once (left to the
+            // compiler the reads sit next to their uses in three batches, a wait in front of each: 18.86 -> 18.69 ms)
+            unsigned hP;
+            tp_v2u hE, hL;
+            tp_v2d t3, t2, t1, t0, tb;
+            {
+                const unsigned ac = (unsigned)(unsigned long long)&s_code_hi[0];
+                const unsigned at = (unsigned)(unsigned long long)&s_car;
+                const unsigned aP = ac + 4u * (unsigned)cc_, aE = ac + 4u * (unsigned)kE, aL = ac + 4u * (unsigned)kL;
+                const unsigned a3 = at + (unsigned)offsetof(TpCarr, W3) + 16u * (unsigned)(s0 >> 12);
+                const unsigned a2 = at + (unsigned)offsetof(TpCarr, W2) + 16u * (unsigned)((s0 >> 8) & 15);
+                const unsigned a1 = at + (unsigned)offsetof(TpCarr, W1) + 16u * (unsigned)((s0 >> 4) & 15);
+                const unsigned a0 = at + (unsigned)offsetof(TpCarr, B) + 16u * (unsigned)(s0 & 15);
+                const unsigned ab = at + (unsigned)offsetof(TpCarr, B) + 16u * (unsigned)((e2 - s0) & 31);
+                asm volatile("ds_read_b32 %0, %1" : "=v"(hP) : "v"(aP));
+                asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(hE) : "v"(aE));
+                asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(hL) : "v"(aL));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(t3) : "v"(a3));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(t2) : "v"(a2));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(t1) : "v"(a1));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(t0) : "v"(a0));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(tb) : "v"(ab));
+            }
+            nk = bounds_of(cn_);
+            tp_load_raw(rec, pos + nk.s0, yh);
+            tp_load_raw(rec, pos + (nk.eE > nk.eL ? nk.eE : nk.eL), yt);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hP), "+v"(hE), "+v"(hL), "+v"(t3), "+v"(t2), "+v"(t1), "+v"(t0), "+v"(tb));
+            const double cP = __hiloint2double((int)hP, 0);
+            const double cEh = __hiloint2double((int)hE.x, 0), cEn = __hiloint2double((int)hE.y, 0);
+            const double cLh = __hiloint2double((int)hL.x, 0), cLn = __hiloint2double((int)hL.y, 0);
+            const double2 gh = cmul2(cmul2(make_double2(t3.x, t3.y), make_double2(t2.x, t2.y)),
+                                     cmul2(make_double2(t1.x, t1.y), make_double2(t0.x, t0.y)));
+            const double2 b_tail = make_double2(tb.x, tb.y);
             const double q30 = 9.3132257461547852e-10;   // 2^-30: the scale of the weight digits
             const double2 ghq = make_double2(gh.x * q30, gh.y * q30);
             // the usual chip: early and late switch at the same sample, both runs 17..20 samples long: only the fifth
@@ -385,7 +413,7 @@ __global__ __launch_bounds__(TP_THREADS, TP_OCC) void trk_kernel_tp(const int8_t
                 }
             }
             if (by_runs)
-                tp_runs(wr, s_car, ghq, (e2 - s0) & 31, wh, wt, eE <= e2, eL <= e2, cP, cEh, cEn, cLh, cLn, aIE, aQE, aIP, aQP, aIL, aQL);
+                tp_runs(wr, ghq, b_tail, wh, wt, eE <= e2, eL <= e2, cP, cEh, cEn, cLh, cLn, aIE, aQE, aIP, aQP, aIL, aQL);
         };
         TpChip nxt;
         unsigned nh[5], nt[5];
