@@ -308,8 +308,12 @@ __global__ void if_mark_kernel(unsigned long long* mark, unsigned long long valu
 
 #define SGX_STAGE_BYTES (32u << 20)   // a pinned staging buffer: two slots
 #define SGX_SLOT_BYTES (16u << 20)    // a multiple of every cache-line size: a line is never fetched half written
+#ifndef SGX_PIPE_SLOTS
 #define SGX_PIPE_SLOTS 4
+#endif
+#ifndef SGX_PIPE_READERS
 #define SGX_PIPE_READERS 3
+#endif
 
 struct FilePipe {
     int fd = -1;
@@ -318,8 +322,8 @@ struct FilePipe {
     int8_t* dst = nullptr;                // device
     int device = 0;
     hipStream_t stream = nullptr;
-    char* slot[SGX_PIPE_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev[SGX_PIPE_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    char* slot[SGX_PIPE_SLOTS] = {};
+    hipEvent_t ev[SGX_PIPE_SLOTS] = {};
     unsigned long long* d_mark = nullptr; // device watermark advanced in stream order after every chunk, or null
     std::atomic<size_t>* host_mark = nullptr;   // bytes whose copy is known to have completed, or null
     std::vector<std::atomic<int>> read_ok;      // per chunk: 1 read, -1 read error
