@@ -990,9 +990,12 @@ static int acquire_four_step(sgx_ctx* c, SgxSig x, size_t n_samples, const int32
     const int rows_fwd = n_blocks * n_phi;
     const int rows_per_prn = n_blocks * n_bins;
     SGX_CHECK_ARG(rows_per_prn <= ACQ_MAX_ROWS);
-    // PRN chunks: measured (tools/acq_chunk_probe.py), keeping a chunk's intermediate inside the 256 MiB Infinity Cache
-    // (~230 rows) buys nothing and costs launches; chunks are as large as the row limit allows
-    int chunk_rows = ACQ_MAX_ROWS;
+    // PRN chunks of ~350 rows: a chunk's intermediate (213 MB) then stays in the 256 MiB Infinity Cache between the
+    // columns kernel that writes it and the rows kernel that reads it, and the next chunk overwrites it there.  With the
+    // round-3 kernels - bound by their stores and by the dirty lines on their way out, not by instruction issue or LDS
+    // any more - that is 0.94 -> 0.80 ms for config 2 and 3.43 -> 3.24 ms for config 4 (tools/acq_chunk_probe.py; the
+    // round-2 kernels measured no difference).
+    int chunk_rows = 348;
     {
         const char* ce = getenv("SGX_ACQ_CHUNK_ROWS");
         if (ce && atoi(ce) > 0) chunk_rows = atoi(ce);

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 m = importlib.import_module("softgnss-python_amd")
 s = m.Settings(); ctx = m.engine.get_context(s, 0); n = s.samplesPerCode
 rec = ctx.synth(m.synth.Scene.default(), 21 * n)
-for rows in (58, 116, 232, 464, 928, 2048):
+for rows in (174, 232, 290, 348, 406, 2048):
     os.environ["SGX_ACQ_CHUNK_ROWS"] = str(rows)
     for nb, nc, label in ((2, False, "2x1ms"), (10, True, "10ms noncoh")):
         sig = m.DeviceSignal(rec, 0, (10 + nb) * n if nc else 11 * n)
