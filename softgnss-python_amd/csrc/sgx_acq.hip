@@ -794,45 +794,47 @@ static int acquire_fine(sgx_ctx* c, SgxSig x, size_t n_samples, const std::vecto
     return SGX_OK;
 }
 
-// Peak logic for one PRN (acquisition.py:129-162): block choice per bin (A7), global peak, first row / first column
-// attaining it (A8), exclusion list (A8b).  rowmax / rowarg: per (block, bin) row of this PRN, or per bin
-// (non-coherent).  Returns 1 where the reference raises IndexError (Q5), else 0.
-__host__ __device__ static inline int acq_peak_logic(const double* rowmax, const int* rowarg, int n_bins, int n_blocks,
-                                                     bool noncoh, long long N, int spc, double* peak, int* cph, int* fbi,
-                                                     int* best_block, int* lo0, int* hi0, int* lo1, int* hi1) {
-    double gmax = -1.0;
-    int gk = 0, gc = 0, gb = 0;
-    bool have = false;
-    for (int k = 0; k < n_bins; ++k) {
-        int row, bsel = 0;
-        if (noncoh) {
-            row = k;
-        } else {
-            int best = 0;   // acquisition.py:129-133 generalised left to right, later block wins ties
-            for (int b = 1; b < n_blocks; ++b) {
-                const double vb = rowmax[best * n_bins + k];
-                const double vn = rowmax[b * n_bins + k];
-                if (!(vb > vn)) best = b;
-            }
-            row = best * n_bins + k;
-            bsel = best;
+// Peak logic of one PRN (acquisition.py:129-162) in pieces a wave can share.
+// One bin's candidate: block choice (A7) and its row's maximum / first index.
+struct AcqCand {
+    double v;
+    int k, a, b;
+};
+__device__ static inline AcqCand acq_peak_bin(const double* __restrict__ rowmax, const int* __restrict__ rowarg, int n_bins,
+                                              int n_blocks, bool noncoh, int k) {
+    int row = k, bsel = 0;
+    if (!noncoh) {
+        int best = 0;   // acquisition.py:129-133 generalised left to right, later block wins ties
+        for (int b = 1; b < n_blocks; ++b) {
+            const double vb = rowmax[best * n_bins + k];
+            const double vn = rowmax[b * n_bins + k];
+            if (!(vb > vn)) best = b;
         }
-        const double v = rowmax[row];
-        const int a = rowarg[row];
-        if (!have || v > gmax) {
-            gmax = v;
-            gk = k;          // first row attaining the maximum (results.max(1).argmax())
-            gc = a;
-            gb = bsel;
-            have = true;
-        } else if (v == gmax && a < gc) {
-            gc = a;          // results.max(0).argmax(): first column attaining the maximum
-        }
+        row = best * n_bins + k;
+        bsel = best;
     }
-    *peak = gmax;
-    *cph = gc;
-    *fbi = gk;
-    *best_block = gb;
+    AcqCand c;
+    c.v = rowmax[row];
+    c.a = rowarg[row];
+    c.k = k;
+    c.b = bsel;
+    return c;
+}
+// A scan over the bins in ascending k keeps: the maximum, the FIRST bin attaining it (results.max(1).argmax()), that
+// bin's block, and the SMALLEST column among the bins attaining it (results.max(0).argmax()) - A8.  The same as a
+// combination of two partial scans (k < 0: an empty one):
+__device__ static inline AcqCand acq_peak_join(const AcqCand& x, const AcqCand& y) {
+    if (y.k < 0) return x;
+    if (x.k < 0) return y;
+    if (x.v > y.v) return x;
+    if (y.v > x.v) return y;
+    AcqCand c = (x.k < y.k) ? x : y;
+    c.a = x.a < y.a ? x.a : y.a;
+    return c;
+}
+// The exclusion list around the peak's code phase (A8b, acquisition.py:135-162).  Returns 1 where the reference raises
+// IndexError (Q5), else 0.
+__device__ static inline int acq_peak_ranges(int gc, long long N, int spc, int* lo0, int* hi0, int* lo1, int* hi1) {
     *lo0 = *hi0 = *lo1 = *hi1 = 0;
     const int e1 = gc - spc, e2 = gc + spc;
     if (e1 <= 0) {
@@ -908,34 +910,52 @@ static int coarse_look_wait(sgx_ctx* c, unsigned long long seq) {
     return SGX_OK;
 }
 
+// One WAVE per PRN, a lane per Doppler bin (one lane per PRN scanning its rows was a chain of dependent loads: 12 us).
 __global__ __launch_bounds__(64) void acq_peak_kernel(const double* __restrict__ rowmax, const int* __restrict__ rowarg,
                                                       int n_prn, int out_per_prn, int n_bins, int n_blocks, int noncoh,
                                                       long long N, int spc, PeakOut* __restrict__ po,
                                                       SecondArgs* __restrict__ sa, int2* __restrict__ row_map) {
-    const int pi = threadIdx.x;
+    const int pi = blockIdx.x, lane = threadIdx.x;
     if (pi >= 32) return;
-    sa->row[pi] = -1;
-    sa->lo0[pi] = sa->hi0[pi] = sa->lo1[pi] = sa->hi1[pi] = 0;
-    if (pi >= n_prn) return;
-    int bb = 0, lo0, hi0, lo1, hi1, cph, fbi;
-    double peak;
-    const int bad = acq_peak_logic(rowmax + (long long)pi * out_per_prn, rowarg + (long long)pi * out_per_prn, n_bins,
-                                   n_blocks, noncoh != 0, N, spc, &peak, &cph, &fbi, &bb, &lo0, &hi0, &lo1, &hi1);
-    po->peak[pi] = peak;
-    po->cph[pi] = cph;
-    po->fbi[pi] = fbi;
-    po->index_error[pi] = bad;
-    if (!bad) {
-        sa->row[pi] = pi;
-        sa->lo0[pi] = lo0;
-        sa->hi0[pi] = hi0;
-        sa->lo1[pi] = lo1;
-        sa->hi1[pi] = hi1;
+    if (pi >= n_prn) {
+        if (lane == 0) {
+            sa->row[pi] = -1;
+            sa->lo0[pi] = sa->hi0[pi] = sa->lo1[pi] = sa->hi1[pi] = 0;
+        }
+        return;
     }
+    const double* __restrict__ pm = rowmax + (long long)pi * out_per_prn;
+    const int* __restrict__ pa = rowarg + (long long)pi * out_per_prn;
+    AcqCand c;
+    c.v = -1.0;
+    c.k = -1;
+    c.a = c.b = 0;
+    for (int k = lane; k < n_bins; k += 64) c = acq_peak_join(c, acq_peak_bin(pm, pa, n_bins, n_blocks, noncoh != 0, k));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        AcqCand o;
+        o.v = __shfl_down(c.v, off);
+        o.k = __shfl_down(c.k, off);
+        o.a = __shfl_down(c.a, off);
+        o.b = __shfl_down(c.b, off);
+        c = acq_peak_join(c, o);
+    }
+    if (lane != 0) return;
+    int lo0, hi0, lo1, hi1;
+    const int bad = acq_peak_ranges(c.a, N, spc, &lo0, &hi0, &lo1, &hi1);
+    po->peak[pi] = c.v;
+    po->cph[pi] = c.a;
+    po->fbi[pi] = c.k;
+    po->index_error[pi] = bad;
+    sa->row[pi] = bad ? -1 : pi;
+    sa->lo0[pi] = bad ? 0 : lo0;
+    sa->hi0[pi] = bad ? 0 : hi0;
+    sa->lo1[pi] = bad ? 0 : lo1;
+    sa->hi1[pi] = bad ? 0 : hi1;
     if (noncoh) {
-        for (int b = 0; b < n_blocks; ++b) row_map[pi * n_blocks + b] = make_int2(b * n_bins + fbi, pi);
+        for (int b = 0; b < n_blocks; ++b) row_map[pi * n_blocks + b] = make_int2(b * n_bins + c.k, pi);
     } else {
-        row_map[pi] = make_int2(bb * n_bins + fbi, pi);
+        row_map[pi] = make_int2(c.b * n_bins + c.k, pi);
     }
 }
 
@@ -1090,7 +1110,7 @@ static int acquire_four_step(sgx_ctx* c, SgxSig x, size_t n_samples, const int32
     // ---- device: block choice, global peak, exclusion list of every PRN; the rows the second-peak search reads -------
     PeakOut* d_po = (PeakOut*)(dsm + 620000);
     SecondArgs* d_sa = (SecondArgs*)(dsm + 600000);
-    acq_peak_kernel<<<1, 64, 0, st>>>(d_rowmax, d_rowarg, n_prn, out_per_prn, n_bins, n_blocks, noncoh, N, spc, d_po, d_sa,
+    acq_peak_kernel<<<32, 64, 0, st>>>(d_rowmax, d_rowarg, n_prn, out_per_prn, n_bins, n_blocks, noncoh, N, spc, d_po, d_sa,
                                       d_map);
     {
         const int rows2 = n_prn * (noncoh ? n_blocks : 1);
