@@ -1122,18 +1122,16 @@ static int acquire_four_step(sgx_ctx* c, SgxSig x, size_t n_samples, const int32
         fu.n_bins = n_bins;
         fu.n_phi = n_phi;
         fu.n_blocks = n_blocks;
-        if (noncoh) {
-            fu.pout = d_power;
-            fu.inv_n = inv_n;
-            fu.sum_blocks = n_blocks;
-            rc = sgx_fft4_forward(&c->plan_code, nullptr, c->d_work[0], nullptr, rows2, st, &fu);
-            if (rc != SGX_OK) return rc;
-            acq_second_kernel<<<dim3((unsigned)n_prn, SEC_SPLIT), 256, 0, st>>>(d_power, d_second, N, d_sa);
-        } else {
-            rc = sgx_fft4_forward(&c->plan_code, nullptr, c->d_work[0], c->d_work[1], rows2, st, &fu);
-            if (rc != SGX_OK) return rc;
-            acq_second_cplx_kernel<<<dim3((unsigned)n_prn, SEC_SPLIT), 256, 0, st>>>(c->d_work[1], d_second, N, inv_n, d_sa);
-        }
+        // the rows kernel folds each row's maximum over the exclusion list into d_second itself (the same powers, formed
+        // by the same arithmetic, as the first pass: peak / second peak is a ratio of consistently rounded values);
+        // neither the rows nor their powers are stored
+        static_assert(sizeof(SecondArgs) == 5 * 32 * sizeof(int), "row / lo0 / hi0 / lo1 / hi1, 32 each");
+        fu.sec = reinterpret_cast<const int*>(d_sa);
+        fu.second_out = d_second;
+        fu.inv_n = inv_n;
+        fu.sum_blocks = noncoh ? n_blocks : 1;
+        rc = sgx_fft4_forward(&c->plan_code, nullptr, c->d_work[0], nullptr, rows2, st, &fu);
+        if (rc != SGX_OK) return rc;
     }
     // ---- the host's one look at the coarse search ------------------------------------------------------------------------
     const unsigned long long seq = ++c->look_seq;

@@ -506,6 +506,8 @@ struct F4Args {
     double* pout;           // [rows][n] powers (MODE 3)
     double inv_n;
     int sum_blocks;         // > 1: powers of this many consecutive input rows are added first (input row = row * sum_blocks + b)
+    const int* sec;         // rows kernel, MODE 4: [5][32] row / lo0 / hi0 / lo1 / hi1 of the second-peak search
+    double* second_out;     // [32]
 };
 
 __device__ __forceinline__ cplx f4_twiddle(const F4Args& a, long long t) {
@@ -955,6 +957,25 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(F4R_WAVES_N
         }
         return;
     }
+    if (MODE == 4) {
+        // second-peak search: the maximum over this row's allowed indices, into second_out[row]
+        double best = 0.0;
+        const int p = (int)row;
+        if (s2 && a.sec[p] >= 0) {
+            const int lo0 = a.sec[32 + p], hi0 = a.sec[64 + p], lo1 = a.sec[96 + p], hi1 = a.sec[128 + p];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const int idx = idx0 + N1 * 11 * c;
+                const bool in = (idx >= lo0 && idx < hi0) || (idx >= lo1 && idx < hi1);
+                best = in ? fmax(best, acc[c]) : best;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) best = fmax(best, __shfl_down(best, off));
+        if ((tid & 63) == 0 && best > 0.0)
+            atomicMax(reinterpret_cast<unsigned long long*>(&a.second_out[p]), (unsigned long long)__double_as_longlong(best));
+        return;
+    }
     if (MODE == 3) {
         double* __restrict__ po = a.pout + row * a.n;
         if (s2) {
@@ -1089,7 +1110,13 @@ int sgx_fft4_forward(const FftPlan* p, const cplx* in, cplx* work, cplx* out, in
     a.tw_sub = g_f4_sub[dev][1];
     a.wr[0] = g_wr[dev][16];
     a.wr[1] = g_wr[dev][11];
-    if (fuse && fuse->pmax) {
+    if (fuse && fuse->second_out) {
+        a.sec = fuse->sec;
+        a.second_out = fuse->second_out;
+        a.inv_n = fuse->inv_n;
+        a.sum_blocks = sum_blocks;
+        f4_launch_rows<4>(a, rows / sum_blocks, st);
+    } else if (fuse && fuse->pmax) {
         a.pmax = fuse->pmax;
         a.parg = fuse->parg;
         a.inv_n = fuse->inv_n;

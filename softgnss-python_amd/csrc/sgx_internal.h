@@ -153,6 +153,11 @@ struct Fft4Fuse {
     double* pout = nullptr;        // ... or the powers themselves, [rows / sum_blocks][n]
     double inv_n = 0.0;
     int sum_blocks = 1;            // powers of this many consecutive rows are added before the reduction / store
+    // ... or, per output row p, the maximum power over the index ranges [sec[32 + p], sec[64 + p]) and [sec[96 + p],
+    // sec[128 + p]) folded into second_out[p] (integer atomic max on the bit pattern; rows with sec[p] < 0 are skipped):
+    // the second-peak search (acquisition.py:162) without a stored row
+    const int* sec = nullptr;
+    double* second_out = nullptr;
 };
 bool sgx_fft_fine_supported(int64_t npts);
 int sgx_fft_fine_partials(void);
