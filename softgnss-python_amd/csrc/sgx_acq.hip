@@ -380,7 +380,7 @@ static int acquire_fine(sgx_ctx* c, SgxSig x, size_t n_samples, const std::vecto
 static int acquire_any(sgx_ctx* c, SgxSig x, size_t n_samples, const int32_t* prn0, int32_t n_prn, int32_t n_blocks,
                        int32_t noncoh, double* carrFreq, double* codePhase, double* peakMetric, int32_t* freqBin,
                        int32_t* fineIdx) {
-    // the four-step path (LDS-resident sub-transforms, shifted forward spectra) where it applies
+    // the four-step path (sub-transforms in registers and LDS, shifted forward spectra) where it applies
     bool handled = false;
     const int rc4 = acquire_four_step(c, x, n_samples, prn0, n_prn, n_blocks, noncoh, carrFreq, codePhase, peakMetric,
                                       freqBin, fineIdx, &handled);
@@ -959,7 +959,7 @@ __global__ __launch_bounds__(64) void acq_peak_kernel(const double* __restrict__
     }
 }
 
-// The acquisition on the four-step transform (sgx_fft.hip): every 38192-point transform is two kernels with LDS-resident
+// The acquisition on the four-step transform (sgx_fft.hip): every 38192-point transform is two kernels with register-resident
 // sub-transforms, the mixed-signal spectra are computed once per (block, phi) and read with a circular shift, results
 // land where they are needed (no device-to-device copies) and the host looks at the device twice before the fine search
 // (row maxima of ALL PRNs, then the second peaks) whatever the number of PRN chunks.
