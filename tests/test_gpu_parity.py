@@ -84,6 +84,30 @@ def test_acquire_all_prns_and_prerun_golden(default_record):
     assert [str(x) for x in a.channels.status] == [str(x) for x in g["ch_status"]]
 
 
+def test_acquire_search_bands_and_prn_lists_against_oracle(default_record):
+    """The default front end (the four-step kernels, their PRN chunks and tile order) with other Doppler grids and
+    satellite lists than the default's 29 bins x 32 PRNs: 17, 41 and 57 bins (rows per PRN that do and do not divide
+    the chunk, row counts that are and are not multiples of the XCD count), a list of 5 PRNs, and the 10-ms non-coherent
+    extension on a narrow band - codePhase, carrFreq and the bins exactly, peakMetric to 1e-9."""
+    m = pkg()
+    n = 38192
+    for band, prns, nb, nc in ((8.0, None, 2, False), (20.0, None, 2, False), (28.0, [1, 3, 7, 11, 30], 2, False),
+                               (6.0, [3, 7, 14, 19, 22, 25, 31], 10, True)):
+        s = m.Settings()
+        so = orc.OracleSettings()
+        for o in (s, so):
+            o.acqSearchBand = band
+            if prns is not None:
+                o.acqSatelliteList = prns
+        x = default_record[:(10 + nb) * n if nc else 11 * n]
+        a = m.AcquisitionResult(s, device=0)
+        a.acquire(x, n_blocks=nb, noncoh=nc)
+        w = orc.acquire(so, x, n_blocks=nb, noncoh=nc) if nc else orc.acquire(so, x)
+        assert np.array_equal(a.codePhase, w["codePhase"]), band
+        assert np.array_equal(a.carrFreq, w["carrFreq"]), band
+        assert np.allclose(a.peakMetric, w["peakMetric"], rtol=1e-9, atol=0), band
+
+
 def test_acquire_code_phase_edges_golden():
     g = load_golden("acq_edges.npz")
     m = pkg()
