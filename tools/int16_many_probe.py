@@ -1,3 +1,4 @@
+"""(GPU box) Tracking of 8 .. 1024 channels of an int8 and of an int16 record (200 ms): kernel, member layout, channel-seconds per second."""
 import importlib, os, sys
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
