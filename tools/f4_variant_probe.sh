@@ -13,7 +13,7 @@ c = sqlite3.connect(db)
 out = []
 for pat in ("%fft4_cols%", "%fft4_rows%"):
     r = list(c.execute("select duration from kernels where name like ? order by start", (pat,)))
-    big = sorted(x[0] for x in r if x[0] > 100000)
+    big = sorted(x[0] for x in r if x[0] > 30000)
     out.append((big[0] / 1e3, big[len(big) // 2] / 1e3) if big else (-1, -1))
 print("%-12s cols min %7.1f med %7.1f us   rows min %7.1f med %7.1f us" % ("$name", out[0][0], out[0][1], out[1][0], out[1][1]))
 PY
