@@ -8,8 +8,8 @@ out=gpurun_out/prof_$tag
 rm -rf $out && mkdir -p $out
 # the headline command alone: no concurrent-records or many-channel leg, so that trk2_kernel's average in the trace is the
 # duration of the launches the bench line's roofline is computed from
-BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --concurrent 0 --many-channels 0"
-BENCH1="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --concurrent 0 --no-config4"
+BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --concurrent 0 --many-channels 0 --no-from-file"
+BENCH1="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --concurrent 0 --no-config4 --no-from-file"
 rocprofv3 --kernel-trace --stats -d $out/trace -- $BENCH > $out/trace.json 2> $out/trace.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/fetch -- $BENCH1 > /dev/null 2> $out/fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/write -- $BENCH1 > /dev/null 2> $out/write.err

@@ -9,7 +9,7 @@ tail -5 $out/pytest1.log
 for v in "${@:-X=1}"; do
   echo "== variant [$v]"
   env $v SGX_TRK_PROFILE=1 timeout 300 python tools/step_profile.py 4000 2>&1 | grep "profile\] ch 0 member\|^step" | awk 'NR<=4 || /member  *(9|10|19|29) / || /^step/' | head -12
-  env $v timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --many-channels 0 --concurrent 0 --no-config4 2>/dev/null | python -c "
+  env $v timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --many-channels 0 --concurrent 0 --no-config4 --no-from-file 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('track_kernel_ms %.3f  us/period %.4f  acquire_ms %.3f  x_realtime %.1f' % (d['track_kernel_ms'], d['us_per_code_period'], d['acquire_ms'], d['x_realtime']))"
