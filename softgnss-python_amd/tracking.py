@@ -96,7 +96,12 @@ class TrackingResult(Result):
             n = settings.samplesPerCode
             first = int(settings.skipNumberOfBytes + min(c[2] for c in chans))
             last = int(settings.skipNumberOfBytes + max(c[2] for c in chans))
-            need = (last - first) + (ms * (n + 2) + n) * isz      # a block is at most samplesPerCode + 1 long
+            # the window starts on a 4 KiB boundary of the FILE: page-aligned reads, and every sample keeps the place
+            # inside its 16-byte group that it has in a record resident from file offset 0 - the kernel's lanes then
+            # add the same samples in the same order, and the series are bit-identical to the resident run's
+            first_al = (first // 4096) * 4096
+            need = (last - first_al) + (ms * (n + 2) + n) * isz   # a block is at most samplesPerCode + 1 long
+            first = first_al
             own = rec = self._window(fid, first, need)
             file_off = first
         try:
