@@ -33,6 +33,15 @@ void sgx_trk2_launch(int n_blocks, hipStream_t st, const int8_t* rec, const int8
 #define T2_XCH_STRIDE (((12 * T2_XLINE + 8 + 48) + 255) / 256 * 256)   // (as in sgx_trk2.hip)
 #define T2_PROF_STRIDE 192
 
+// sgx_trk3.hip: the speculative latency-mode kernel (round 4): one workgroup per unit of 128 groups serves all three
+// correlator arms, the map runs one block ahead of the loop filter and only corrections are on the per-block chain
+void sgx_trk3_launch(int n_blocks, hipStream_t st, const int8_t* rec, const int8_t* codes, const TrkChan* chans,
+                     double* out, int* done, const TrkConst& K, long long* prof, unsigned long long* xch, int* err,
+                     int lds_pad);
+#define T3_LANES 128
+#define T3_MAXP 32
+#define T3_XCH_STRIDE 512   // (as in sgx_trk3.hip)
+
 // sgx_trk_multi.hip: the cooperative kernel with a per-sample replica lookup, for low sampling rates
 void sgx_trk_multi_launch(int n_blocks, hipStream_t st, const int8_t* rec, const int8_t* codes, const TrkChan* chans,
                           double* out, int* done, const TrkConst& K, long long* prof, unsigned long long* xch,
@@ -171,7 +180,8 @@ static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
     // device-side call state lives in one cached allocation: [channels | done | exchange | err | profile]
     const size_t sz_ch = ((sizeof(TrkChan) * (size_t)n_ch + 255) / 256) * 256;
     const size_t sz_done = ((sizeof(int) * (size_t)n_ch + 255) / 256) * 256;
-    const size_t xch_words = (2 * TRK_MAX_SPLIT * 12 + 16) > T2_XCH_STRIDE ? (2 * TRK_MAX_SPLIT * 12 + 16) : T2_XCH_STRIDE;
+    size_t xch_words = (2 * TRK_MAX_SPLIT * 12 + 16) > T2_XCH_STRIDE ? (2 * TRK_MAX_SPLIT * 12 + 16) : T2_XCH_STRIDE;
+    if (xch_words < T3_XCH_STRIDE) xch_words = T3_XCH_STRIDE;
     const size_t xch_bytes = sizeof(unsigned long long) * (size_t)n_ch * xch_words;
     const size_t sz_xch = ((xch_bytes + 255) / 256) * 256;
     const size_t sz_prof = sizeof(long long) * T2_PROF_STRIDE * (size_t)n_ch;
@@ -206,6 +216,27 @@ static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
     const char* ae = getenv("SGX_TRK_ARMS");
     const bool arm_split = use_v2 && K.split == K.n_units && K.n_units >= 2 && 3 * ch8 * K.n_units <= cus_total &&
                            !getenv("SGX_TRK_SPLIT") && !(ae && ae[0] == '3');
+    // The speculative kernel (sgx_trk3.hip) serves all three arms from one lane, which rests on a 16-sample group (and one
+    // sample on either side of it) meeting at most ONE chip boundary of ANY arm: the arms' boundaries lie at code phases
+    // 0, d and 1 - d (mod 1 chip; d = dllCorrelatorSpacing), so the smallest gap between two DIFFERENT ones must exceed 18
+    // samples of code phase (1 % margin for the code NCO).  E and L sharing theirs (d = 1/2) is fine.  int8 / uint8
+    // records, one workgroup per unit of 128 groups, while 8-padded channels x units fit the CUs.
+    const int n_units2 = K.n_units;
+    const int n_units3 = (int)(((c->n_code + 64 + 15 + 15) / 16 + T3_LANES - 1) / T3_LANES);
+    bool use_v3 = false;
+    {
+        const double d = S.dllCorrelatorSpacing, e = 1.0 - d;
+        double pts[3] = {0.0, d < e ? d : e, d < e ? e : d};
+        double gap = 2.0;
+        for (int i = 0; i < 3; ++i) {
+            const double g = (i < 2 ? pts[i + 1] : pts[0] + 1.0) - pts[i];
+            if (g > 1e-9 && g < gap) gap = g;
+        }
+        const double stepn = S.codeFreqBasis / S.samplingFreq;
+        const char* v3e = getenv("SGX_TRK_V3");
+        use_v3 = use_v2 && sample_bytes == 1 && n_units3 >= 2 && n_units3 <= T3_MAXP && ch8 * n_units3 <= cus_total &&
+                 18.0 * stepn * 1.01 <= gap && !getenv("SGX_TRK_SPLIT") && !ae && !(v3e && v3e[0] == '0');
+    }
     const char* le = getenv("SGX_TRK_LDSPAD");   // dynamic LDS per workgroup (bytes); default: one workgroup per CU
     const int lds_pad_coop = le ? atoi(le) : 90112;
     const int split0 = K.split;
@@ -236,11 +267,21 @@ static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
         const bool want_stream = r->loader && !r->load_done.load() && attempt == 0 && !(se2 && se2[0] == '0') && v2;
         if (attempt == 0 || retry_resident) K.split = split0;
         else K.split = 1;                                        // a member timed out: no co-residency needed with one
+        K.n_units = n_units2;
+        bool v3 = use_v3 && (attempt == 0 || retry_resident);
+        if (v3) {
+            reserved.n = sgx_cu_reserve(c->device, cus_total, ch8 * n_units3);
+            if (reserved.n == 0) v3 = false;                     // (the CUs are taken: the layouts below need fewer)
+            else {
+                K.split = n_units3;
+                K.n_units = n_units3;
+            }
+        }
         int arms_now = (v2 && arm_split && K.split > 1) ? 1 : 3;
         // Cooperating workgroups wait for each other, so all of a launch must be resident at once: one workgroup per CU
         // out of a per-device budget shared by every context of this process (a launch that does not fit the CUs left
         // by the others runs with one workgroup per channel, which needs no co-residency).
-        if (K.split > 1) {
+        if (K.split > 1 && !v3) {
             reserved.n = sgx_cu_reserve(c->device, cus_total, ch8 * K.split * (arms_now == 1 ? 3 : 1));
             if (reserved.n == 0 && arms_now == 1) {
                 arms_now = 3;                                    // the CUs left may still hold one workgroup per unit
@@ -248,7 +289,7 @@ static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
             }
             if (reserved.n == 0) K.split = 1;
         }
-        const int members_now = K.split * ((v2 && K.split > 1 && arms_now == 1) ? 3 : 1);
+        const int members_now = v3 ? K.split : K.split * ((v2 && K.split > 1 && arms_now == 1) ? 3 : 1);
         const int n_blocks = ch8 * members_now;
         const bool streaming = want_stream;
         if (!streaming) {
@@ -258,7 +299,14 @@ static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
         K.mark = streaming ? r->d_mark : nullptr;
         if (want_prof) SGX_HIP(hipMemsetAsync(d_prof, 0, sz_prof, st));
         hipEventRecord(c->ev[3], st);
-        if (v2) {
+        if (v3) {
+            const char* wh = getenv("SGX_TRK_TEST_WITHHOLD");   // test hook: launch without each channel's last member
+            const int nb3 = (wh && wh[0] == '1') ? n_blocks - 8 : n_blocks;
+            sgx_trk3_launch(nb3, st, r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err, lds_pad_coop);
+            used_v2 = true;
+            used_members = members_now;
+            c->timing.track_kernel = 5.f;
+        } else if (v2) {
             const char* wh = getenv("SGX_TRK_TEST_WITHHOLD");   // test hook: launch without each channel's last member
             const int nb2 = (wh && wh[0] == '1' && K.split > 1) ? n_blocks - 8 : n_blocks;
             // (one workgroup per CU only matters while members wait for each other)

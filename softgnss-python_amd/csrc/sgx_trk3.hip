@@ -1,0 +1,1192 @@
+// TrackingResult.track on gfx950, the SPECULATIVE latency-mode kernel (reference tracking.py:13-295; SURVEY.md section 9
+// T1-T9).  Round 4.  What the per-block chain  sums -> discriminators -> NCOs -> next block's parameters -> sums  of
+// sgx_trk2.hip still held was the whole map: block k + 1's samples were multiplied and added only after block k's loop
+// filter had posted the block's code rate, carrier rate and length.  But those three move by tiny, bounded amounts from
+// block to block, and everything else about block k + 1 - its first sample, its code phase, its carrier start phase - is
+// known as soon as block k's OWN parameters are.  So here block k + 1 is accumulated in the SHADOW of block k's exchange
+// and loop filter with block k's rates, and the chain holds corrections only:
+//
+//   carrier   the lane's 16 sample phasors B_b were those of rate w_k; the true ones are B_b e^{j eps b}, eps = (w_{k+1} -
+//             w_k) / fs.  The lane keeps the moments M0 = sum x_b B_b and M1 = sum x_b B_b (b - 7.5); with the group
+//             phasor taken at the group's CENTRE (the PLL wave turns W3 by 7.5 samples more),
+//             sum x_b B_b e^{j eps (b - 7.5)} = M0 + j eps M1 - eps^2/2 M2 + ...,  |eps| 7.5 <= 1e-4.  The second-order
+//             term is 10.625 eps^2 M0 up to parts that cancel (the lock signal is constant over the group; the
+//             double-frequency term has sum (-1)^b (b - 7.5)^2 = 0): a factor common to every lane, arm and unit, which
+//             the discriminators (ratios) do not see and the RECORDED sums are multiplied by off the chain; third order
+//             < 1e-13.  The group phasor G' = W1' W2' W3' comes from the tables the PLL wave ROTATES by the rate step.
+//   code      at this sampling rate the chip boundaries of the three correlator arms, taken together, are half a chip
+//             = 18.7 samples apart, so a 16-sample group meets at most ONE boundary of ANY arm (the host checks the
+//             rate and the correlator spacing; otherwise sgx_trk2.hip runs).  One lane therefore serves all three arms
+//             at the price of one: it accumulates the moments of ALL its samples and of those IN FRONT of the boundary,
+//             and arm a's sum is alpha_a (all) + beta_a (front) with alpha, beta in {+-1, 0, +-2} from the arm's two chips.
+//             A rate step moves the boundary by a fraction of a sample (|d codeFreq| < 27 Hz: less than one), so at most
+//             one sample changes sides: the pass keeps the two candidates' terms and the final pass adds the one whose
+//             threshold the new boundary position u' = (K - t(ilo - 1)) / step crossed.
+//   fallback  a boundary within 1e-7 samples of a sample (1e-5 of the blocks; all of block 0), two arms switching at
+//             different samples of one group: the wave takes the DIRECT path - per-sample chips from the exact linspace
+//             ramps, this block's own sample phasors - on the chain.  A block whose length was mispredicted (~2 %; the
+//             wave that holds its end), a rate step beyond the rotation's range (the PLL wave evaluates the tables in
+//             full and says so): the wave accumulates again on the chain.  Chip indices are therefore bit-identical to
+//             code[int64(ceil(linspace(...)))] (tracking.py:166-188) always.
+//
+// Members: one workgroup per unit of 128 groups x 16 samples (19 units at 38.192 Msps): two SETS of two MAP waves, a PLL
+// wave, a DLL wave and a RECORD wave.  The sets take the blocks in turn: while one set runs the final pass of block k
+// (on the chain), the other accumulates block k + 1 (in the shadow) - a map wave's speculative pass and its final pass
+// are ~2 100 + ~1 000 cycles of instruction issue, more than a code period is meant to last, and this way neither waits
+// for the other.  With one third of the sample work of the arm-split layout the 8-channel launch occupies 152 CUs.  Exchange, loop filters, record path
+// and abort protocol are those of sgx_trk2.hip (granules {16-bit epoch | 48-bit fixed point}, order-free integer sums,
+// redundant filters in every member).
+#include "sgx_trk2_parts.h"
+
+#define T3_LANES 128               // map lanes = groups per unit (two waves)
+#define T3_UNIT (T3_LANES * 16)    // samples per unit
+#define T3_THREADS 448             // 2 x 2 map waves (two SETS, alternating blocks) + PLL wave (4) + DLL wave (5) + record wave (6)
+#define T3_MAXP 32                 // units per channel
+#define T3_XLINE 32                // granules per line: [2 parities][6 sums] lines of 32 units
+#define T3_XABORT (12 * T3_XLINE)
+#define T3_XPLACE (12 * T3_XLINE + 8)
+#define T3_XCH_STRIDE 512          // words per channel (sgx_trk.hip sizes the allocation with the same figure)
+
+struct __attribute__((aligned(128))) T3Code {   // code side of a block's parameters (DLL wave -> everybody), by block parity
+    // chain part: written right before the barrier that starts the block
+    int blk;
+    int stop;               // 1: the record ends inside this block (tracking.py:159-163); 2: a member gave up waiting;
+                            // 3: the block does not fit the units of the launch
+    double inv_step;        // ~1 / step (2^-40): distances to chip boundaries in samples
+    double step;            // codeFreq / fs to 3 ulp: the slope of the real ramps (the guards cover the difference)
+    double pad0;
+    // early part: posted right after the barrier that starts the PREVIOUS block
+    double start[3];        // ramp starts E, P, L (exact; T3)
+    int blk_pred;           // the block's length if its code rate were the previous block's
+    int eflag;              // block number + 1 once the early part is valid
+    long long pos;          // record index of the block's first sample
+    // exact part: posted right after the barrier that starts the block (the direct path reads it)
+    double stp[3];          // linspace steps E, P, L (tracking.py:166-188)
+    int xflag;              // block number + 1 once stp[] is valid
+    int pad1;
+};
+
+struct T3Carr {   // carrier side (PLL wave -> map waves), by block parity: (cos, sin)(2 pi r m), r = turns per sample
+    double2 T[64];    // [0..15] B: m = b;  [16..31] W1: m = 16 a;  [32..39] W2: m = 256 r;  [48] W3: m = 2048 u - head + 7.5 d
+    double eps;       // (w - w_prev) / fs: the block's moments were accumulated with the PREVIOUS block's B
+    double respec;    // != 0: the rate step was beyond the rotation's range: tables in full, eps = 0, accumulate again
+};
+
+struct T3Shared {
+    unsigned cbits[40];             // packed sign bits of the extended code: bit k + 1 set where chip k is -1
+    T3Code code[2];
+    T3Carr carr[2];
+    unsigned long long acc[2][8];   // {arrival count << 56 | 48-bit fixed-point sum} of the six sums, by block parity
+    uint4 scratch[256];             // a map lane's 16 bytes, for reading single samples back by a dynamic index
+    double rec[2][16];              // a block's 13 series values (member 0), stored one block later
+    int flag[4];                    // [0] same-XCD placement, [1] abort seen by this workgroup
+    int rflag[4];                   // [0] PLL wave, [1] DLL wave: number of blocks whose record values are in rec[]
+    long long tpub[2];              // (profiling) time stamp of the member's publish, by block parity
+};
+
+// rows 1 and 3 of the wave: v + (lane 15 of the row before) - joins two 16-lane row sums into a 32-lane sum
+__device__ __forceinline__ unsigned long long t3_addl_bc15(unsigned long long v) {
+    const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    unsigned olo, ohi;
+    asm volatile("s_nop 1\n\t"
+                 "v_add_co_u32_dpp %0, vcc, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "v_addc_co_u32_dpp %1, vcc, %3, %3, vcc row_bcast:15 row_mask:0xa bank_mask:0xf"
+                 : "=&v"(olo), "=&v"(ohi)
+                 : "v"(lo), "v"(hi)
+                 : "vcc");
+    return ((unsigned long long)ohi << 32) | olo;
+}
+
+// -DTRK_WAVEPROF: how long after the barrier's release each wave of (channel 0, member 0) arrives at the next one
+#ifdef TRK_WAVEPROF
+#ifndef T3_WB_UNIT
+#define T3_WB_UNIT 0
+#endif
+#define T3_WB_ON(unit, ch) ((unit) == T3_WB_UNIT && (ch) == 0)
+#define T3_WB_DECL long long wb_acc = 0, wb_t = (long long)__builtin_amdgcn_s_memtime();
+#define T3_WB(on)                                                                \
+    do {                                                                         \
+        if (on) wb_acc += (long long)__builtin_amdgcn_s_memtime() - wb_t;        \
+        wg_barrier();                                                            \
+        if (on) wb_t = (long long)__builtin_amdgcn_s_memtime();                  \
+    } while (0)
+#define T3_WB_PRINT(on, name, n)                                                 \
+    if ((on) && (threadIdx.x & 63) == 0) {                                       \
+        unsigned hw_;                                                            \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));        \
+        printf("[waveprof] %s wave %d (simd %u cu %u): %.1f cycles from release to arrival\n", name, (int)(threadIdx.x >> 6), (hw_ >> 4) & 3u, (hw_ >> 8) & 15u, (double)wb_acc / (n)); \
+    }
+#else
+#define T3_WB_ON(unit, ch) false
+#define T3_WB_DECL
+#define T3_WB(on) wg_barrier()
+#define T3_WB_PRINT(on, name, n)
+#endif
+
+__device__ __forceinline__ int t3_carr_mult(int lane, int unit, int head) {
+    const int sel = lane >> 4, idx = lane & 15;
+    return (sel == 3) ? (T3_UNIT * unit - head) : (idx << (4 * sel));
+}
+
+// ================================ MAP (waves 0-1: set 0, waves 2-3: set 1) ================================
+// A lone wave pays ~9 cycles per operation for a compare + select pair through VCC and ~5 for anything else
+// (tools/ubench_fp64.hip), so everything per-lane below is ARITHMETIC: masks from shifts and bit-field extracts, selects
+// on the high dwords of doubles whose low dwords are zero (+-1, +-2, 0, half-integers) by v_bfi, clamps by min / max.
+//
+// One ramp for the three arms (the correlator spacing is half a chip; the host checks): in HALF chips, h(i) = 2 (i step +
+// rem), the prompt ramp's boundaries are the even integers and the early and late ramps' (t -+ 1/2) the odd ones.  With
+// kh = ceil(h(ilo - 1)) the next boundary of any arm, u = (kh - h(ilo - 1)) / (2 step) samples behind the anchor,
+// kb = kh >> 1 and c0, c1, c2 the chips kb, kb + 1, kb + 2:
+//     kh even (a prompt boundary):      E = c0 (all)                  P = c1 (all) + (c0 - c1)(front)   L = c1 (all)
+//     kh odd  (early and late, shared): E = c1 (all) + (c0 - c1)(front)  P = c1 (all)                  L = c2 (all) + (c1 - c2)(front)
+// (the arms' own ramp starts differ from rem -+ 1/2 by a rounding, 1e-16 chips; the guard is 1e-7 samples = 2.7e-9 chips).
+
+// 3 x (I, Q) fixed-point values per lane -> row sums: after it lane r of a row of 16 holds the row's sum of word r
+// (r < 4: I_P Q_P I_E Q_E) in `pe` and lanes 4, 5 (every lane, by its parity) those of I_L, Q_L in `l`.  One block, the
+// steps of the three chains interleaved so that no DPP source was written by either of the two instructions before it.
+__device__ __forceinline__ void t3_reduce6(const unsigned long long (&q)[6], unsigned long long odd1, unsigned long long odd2,
+                                           unsigned long long& pe, unsigned long long& l) {
+    unsigned a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3, p0, p1, e0, e1, l0, l1, x0, x1, x2, x3;
+    const unsigned q0l = (unsigned)q[0], q0h = (unsigned)(q[0] >> 32), q1l = (unsigned)q[1], q1h = (unsigned)(q[1] >> 32);
+    const unsigned q2l = (unsigned)q[2], q2h = (unsigned)(q[2] >> 32), q3l = (unsigned)q[3], q3h = (unsigned)(q[3] >> 32);
+    const unsigned q4l = (unsigned)q[4], q4h = (unsigned)(q[4] >> 32), q5l = (unsigned)q[5], q5h = (unsigned)(q[5] >> 32);
+    asm volatile(
+        // xor 1, transposing: even lanes keep the I of a pair, odd lanes its Q (a: what the neighbour needs, b: own)
+        "v_cndmask_b32 %0, %23, %21, %33\n\t"  "v_cndmask_b32 %1, %24, %22, %33\n\t"
+        "v_cndmask_b32 %2, %21, %23, %33\n\t"  "v_cndmask_b32 %3, %22, %24, %33\n\t"
+        "v_cndmask_b32 %4, %27, %25, %33\n\t"  "v_cndmask_b32 %5, %28, %26, %33\n\t"
+        "v_cndmask_b32 %6, %25, %27, %33\n\t"  "v_cndmask_b32 %7, %26, %28, %33\n\t"
+        "v_cndmask_b32 %8, %31, %29, %33\n\t"  "v_cndmask_b32 %9, %32, %30, %33\n\t"
+        "v_cndmask_b32 %10, %29, %31, %33\n\t" "v_cndmask_b32 %11, %30, %32, %33\n\t"
+        "v_add_co_u32_dpp %12, vcc, %0, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_addc_co_u32_dpp %13, vcc, %1, %3, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_co_u32_dpp %14, vcc, %4, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_addc_co_u32_dpp %15, vcc, %5, %7, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_co_u32_dpp %16, vcc, %8, %10 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_addc_co_u32_dpp %17, vcc, %9, %11, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        // xor 2: (prompt, early) transposing by bit 1 of the lane; late plainly
+        "v_cndmask_b32 %18, %14, %12, %34\n\t" "v_cndmask_b32 %19, %15, %13, %34\n\t"
+        "v_cndmask_b32 %20, %12, %14, %34\n\t" "v_cndmask_b32 %0, %13, %15, %34\n\t"
+        "v_add_co_u32_dpp %2, vcc, %16, %16 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_addc_co_u32_dpp %3, vcc, %17, %17, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_co_u32_dpp %4, vcc, %18, %20 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_addc_co_u32_dpp %5, vcc, %19, %0, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        // rotations by 4 and 8 inside the row keep the low two lane bits
+        "v_add_co_u32_dpp %6, vcc, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_addc_co_u32_dpp %7, vcc, %3, %3, vcc row_ror:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_co_u32_dpp %8, vcc, %4, %4 row_ror:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_addc_co_u32_dpp %9, vcc, %5, %5, vcc row_ror:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_co_u32_dpp %16, vcc, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_addc_co_u32_dpp %17, vcc, %7, %7, vcc row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_co_u32_dpp %12, vcc, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_addc_co_u32_dpp %13, vcc, %9, %9, vcc row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(c0), "=&v"(c1),
+          "=&v"(c2), "=&v"(c3), "=&v"(p0), "=&v"(p1), "=&v"(e0), "=&v"(e1), "=&v"(l0), "=&v"(l1), "=&v"(x0), "=&v"(x1),
+          "=&v"(x2)
+        : "v"(q0l), "v"(q0h), "v"(q1l), "v"(q1h), "v"(q2l), "v"(q2h), "v"(q3l), "v"(q3h), "v"(q4l), "v"(q4h), "v"(q5l),
+          "v"(q5h), "s"(odd1), "s"(odd2)
+        : "vcc");
+    (void)x3;
+    pe = ((unsigned long long)p1 << 32) | p0;
+    l = ((unsigned long long)l1 << 32) | l0;
+}
+
+template <int SB>
+__device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict__ rec, long long rec_alloc, int ms,
+                                           long long pos0, int unit, int set, int tid, unsigned long long* __restrict__ xbase,
+                                           bool fast, double step_nom, double spacing, bool uns, bool prof_on,
+                                           bool prof_any, bool wb_on) {
+    static_assert(SB == 1, "one-byte samples");
+    const int lane = tid & 63;
+    const long long limit = rec_alloc - 16;                  // bytes: the last 16-byte word that may be loaded
+    const int g = (tid & (T3_LANES - 1)) + unit * T3_LANES;  // the lane's group inside the block's aligned window
+    const long long lane_off = (long long)g * 16;
+    T2_FP_DECL
+    T3_WB_DECL
+    (void)wb_on;
+    (void)prof_on;
+    (void)spacing;
+    // The chips this lane can meet: kb = ceil(2 t) >> 1 >= floor(t) for the anchor's code phase t >= (16 g - 16) step - 0.05
+    // (head in [0, 15], rem in [0, step), the code NCO within 0.4 % of its basis); eight sign bits from chip `ws` on.
+    int ws;
+    unsigned win;
+    {
+        const int kf = (int)floor((double)(16 * g - 16) * step_nom - 0.05);
+        ws = kf < -1 ? -1 : kf;
+        const int bi = ws + 1;                               // bit k + 1 of the packed table is chip k
+        const unsigned lo = S.cbits[bi >> 5], hi = S.cbits[(bi >> 5) + 1];
+        win = (unsigned)((((unsigned long long)hi << 32) | lo) >> (bi & 31)) & 0xFFu;
+    }
+    signed char* const scr = reinterpret_cast<signed char*>(S.scratch) + (tid & 255) * 16;   // the lane's 16 bytes in LDS
+    const unsigned long long odd1 = 0xAAAAAAAAAAAAAAAAull, odd2 = 0xCCCCCCCCCCCCCCCCull;       // lanes with bit 0 / bit 1 set
+    double magic = T2_MAGIC;
+    T2_PIN(magic);
+    // ---- what the speculative pass of a block leaves for its final pass ----
+    double tc = 0.0, ts = 0.0, t1c = 0.0, t1s = 0.0;         // moments of ALL samples (cos, sin parts; order 0 and 1)
+    double fc = 0.0, fs_ = 0.0, f1c = 0.0, f1s = 0.0;        // moments of the samples IN FRONT of the boundary
+    double pmc = 0.0, pms = 0.0, pm1c = 0.0, pm1s = 0.0;     // added to the front when the boundary comes one sample EARLIER
+    double ppc = 0.0, pps = 0.0, pp1c = 0.0, pp1s = 0.0;     // ... one sample LATER
+    double alE = 0.0, alP = 0.0, alL = 0.0;                  // arm a's sum = al_a (all) + be_a (front)
+    double beE = 0.0, beP = 0.0, beL = 0.0;
+    double khd = 0.0;                // the half-chip boundary the lane follows
+    double mid = 0.0;                // floor(u) + 0.5 of the pass; NaN: nothing of this lane can change sides
+    double im1d = 0.0;               // (double)(ilo - 1): the anchor sample of the boundary position
+    int i0 = 0;                      // block index of the lane's first sample
+    int cut = 0;                     // block length the pass was cut for
+    T2Raw<SB> nraw;                  // the lane's 16 samples of this set's NEXT block (requested two blocks ahead)
+    long long pos = pos0;            // first sample of the block the loop is at
+    long long npos_pred = 0;         // first sample the bytes in nraw were requested for
+
+    // The speculative pass over the lane's 16 samples `rw` of a block that starts at record sample POS with prompt code
+    // phase REM, slope STEP (1 / STEP ~ INV) and length CUT, with the sample phasors of table CARR.  NEXT >= 0: once the
+    // samples are converted, the bytes of this set's next block are requested INTO `nraw` for a block start NEXT (rw may
+    // be nraw itself: its registers are free by then, so nothing is copied at the loop's end - a copy there would wait
+    // for the request that was just made).
+    auto spec = [&](const T2Raw<SB>& rw, long long POS, double REM, double STEP, double INV, int CUT, const T3Carr& CARR,
+                    long long NEXT) {
+        const int head = (int)(POS & 15);
+        i0 = g * 16 - head;
+        const int ilo = i0 < 0 ? 0 : i0;
+        const int dlo = ilo - i0;
+        cut = CUT;
+        im1d = (double)(ilo - 1);
+        // the block's 16 sample phasors (one batch of reads, one wait)
+        t2_v2d Bt[16];
+        {
+            const unsigned ba = (unsigned)(unsigned long long)&CARR.T[T2_B];
+#define T3_BLD(i) asm volatile("ds_read_b128 %0, %1 offset:" #i "*16" : "=v"(Bt[i]) : "v"(ba))
+            T3_BLD(0); T3_BLD(1); T3_BLD(2); T3_BLD(3); T3_BLD(4); T3_BLD(5); T3_BLD(6); T3_BLD(7);
+            T3_BLD(8); T3_BLD(9); T3_BLD(10); T3_BLD(11); T3_BLD(12); T3_BLD(13); T3_BLD(14); T3_BLD(15);
+#undef T3_BLD
+        }
+        // the lane's bytes with everything outside the block zeroed (only the block's first and last groups are cut)
+        unsigned r0 = rw.a.x, r1 = rw.a.y, r2 = rw.a.z, r3 = rw.a.w;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(i0 < 0 || i0 + 16 > CUT) != 0, 0)) {
+            const int lo = i0 < 0 ? -i0 : 0;                 // first byte inside the block
+            int hi = CUT - i0;                               // one past the last byte inside it
+            hi = hi < 0 ? 0 : (hi > 16 ? 16 : hi);
+            const unsigned keep = ((1u << hi) - 1u) & ~((1u << lo) - 1u);   // one bit per byte
+            auto expand = [](unsigned n4) { return (((n4 & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu; };   // 4 bits -> 4 bytes
+            r0 &= expand(keep);
+            r1 &= expand(keep >> 4);
+            r2 &= expand(keep >> 8);
+            r3 &= expand(keep >> 12);
+        }
+        *reinterpret_cast<uint4*>(scr) = make_uint4(r0, r1, r2, r3);
+        // the half-chip boundary behind the anchor
+        const double hm = __builtin_fma(im1d, STEP + STEP, REM + REM);
+        khd = ceil(hm);
+        const double fu = floor((khd - hm) * (0.5 * INV));
+        const int khi = (int)khd;
+        const int kb = khi >> 1;
+        int bsw = dlo + (int)fu;                              // the lane's sample b lies behind the boundary iff b >= bsw
+        bsw = bsw > 17 ? 17 : bsw;
+        const int sh = kb - ws;
+        unsigned bits;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(i0 < CUT && (unsigned)sh > 5u) != 0, 0)) {
+            const int kk = (kb < -1 ? -1 : (kb > 1022 ? 1022 : kb)) + 1;
+            const unsigned lo = S.cbits[kk >> 5], hi = S.cbits[(kk >> 5) + 1];
+            bits = (unsigned)((((unsigned long long)hi << 32) | lo) >> (kk & 31)) & 7u;
+        } else {
+            bits = (win >> (sh & 7)) & 7u;
+        }
+        // chips as the high dwords of +-1.0, their differences (0, +-2), the arms' coefficients by the boundary's parity
+        const unsigned c0h = 0x3FF00000u | (bits << 31), c1h = 0x3FF00000u | ((bits >> 1) << 31), c2h = 0x3FF00000u | ((bits >> 2) << 31);
+        const double c0 = __hiloint2double((int)c0h, 0), c1 = __hiloint2double((int)c1h, 0), c2 = __hiloint2double((int)c2h, 0);
+        const unsigned d01h = (unsigned)__double2hiint(c0 - c1), d12h = (unsigned)__double2hiint(c1 - c2);
+        const unsigned odd = (unsigned)(-(khi & 1));          // all ones: an early / late boundary
+        alE = __hiloint2double((int)((odd & c1h) | (~odd & c0h)), 0);
+        alP = c1;
+        alL = __hiloint2double((int)((odd & c2h) | (~odd & c1h)), 0);
+        beE = __hiloint2double((int)(odd & d01h), 0);
+        beP = __hiloint2double((int)(~odd & d01h), 0);
+        beL = __hiloint2double((int)(odd & d12h), 0);
+        // this lane can change only if the boundary is in reach of the group and the group has samples inside the block
+        const unsigned lv = (unsigned)(((bsw - 17) & (i0 - CUT)) >> 31);          // all ones: live
+        {
+            const double m_ = fu + 0.5;
+            mid = __hiloint2double((int)((lv & (unsigned)__double2hiint(m_)) | (~lv & 0x7FF80000u)), __double2loint(m_));
+        }
+        // the two candidates: sample bsw - 1 (leaves the front when the boundary comes one sample earlier) and sample
+        // bsw (joins it when the boundary comes one later); bytes outside the block are zero already
+        const int bm = bsw - 1;
+        const int bmc = bm < 0 ? 0 : (bm > 15 ? 15 : bm), bpc = bsw > 15 ? 15 : bsw;
+        const unsigned vm = lv & ~(unsigned)(bm >> 31), vp = lv & (unsigned)((bsw - 16) >> 31);
+        const double2 Bm = CARR.T[T2_B + bmc], Bp = CARR.T[T2_B + bpc];
+        int xmi, xpi;
+        if (uns) {
+            xmi = (int)reinterpret_cast<const unsigned char*>(scr)[bmc];
+            xpi = (int)reinterpret_cast<const unsigned char*>(scr)[bpc];
+        } else {
+            xmi = (int)scr[bmc];
+            xpi = (int)scr[bpc];
+        }
+        // samples -> high dwords of their fp64 values
+        unsigned xh[16];
+        {
+            const unsigned rr[4] = {r0, r1, r2, r3};
+            if (uns) {   // (a wave-uniform branch instead of a select per sample)
+#pragma unroll
+                for (int b = 0; b < 16; ++b) xh[b] = (unsigned)__double2hiint((double)(int)__builtin_amdgcn_ubfe(rr[b >> 2], 8 * (b & 3), 8));
+            } else {
+#pragma unroll
+                for (int b = 0; b < 16; ++b) xh[b] = (unsigned)__double2hiint((double)(int)__builtin_amdgcn_sbfe((int)rr[b >> 2], 8 * (b & 3), 8));
+            }
+        }
+        double xm = -(double)(int)((unsigned)xmi & vm);
+        double xp = (double)(int)((unsigned)xpi & vp);
+        if (NEXT >= 0) {
+            // (everything that reads rw is above; the asm statements keep it there)
+#pragma unroll
+            for (int b = 0; b < 16; ++b) asm volatile("" : "+v"(xh[b]));
+            npos_pred = NEXT;
+            nraw = t2_load<SB>(rec, (NEXT & ~15ll) + lane_off, limit);
+        }
+        T2STAMP(prof_on && NEXT >= 0, 1);   // boundary, chips, samples converted (waits for the bytes), next request made
+        const int fmask = (1 << bsw) - 1;                     // bit b set: sample b lies in front of the boundary
+        double a0c = 0.0, a0s = 0.0, a1c = 0.0, a1s = 0.0, g0c = 0.0, g0s = 0.0, g1c = 0.0, g1s = 0.0;
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Bt[0]), "+v"(Bt[1]), "+v"(Bt[2]), "+v"(Bt[3]), "+v"(Bt[4]), "+v"(Bt[5]), "+v"(Bt[6]),
+                     "+v"(Bt[7]), "+v"(Bt[8]), "+v"(Bt[9]), "+v"(Bt[10]), "+v"(Bt[11]), "+v"(Bt[12]), "+v"(Bt[13]), "+v"(Bt[14]),
+                     "+v"(Bt[15]));
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            const double xs = __hiloint2double((int)xh[b], 0);
+            const double xf = __hiloint2double((int)(xh[b] & (unsigned)__builtin_amdgcn_sbfe(fmask, b, 1)), 0);
+            const double x1 = xs * ((double)b - 7.5);
+            const double xf1 = xf * ((double)b - 7.5);
+            a0c = __builtin_fma(xs, Bt[b].x, a0c);
+            a0s = __builtin_fma(xs, Bt[b].y, a0s);
+            a1c = __builtin_fma(x1, Bt[b].x, a1c);
+            a1s = __builtin_fma(x1, Bt[b].y, a1s);
+            g0c = __builtin_fma(xf, Bt[b].x, g0c);
+            g0s = __builtin_fma(xf, Bt[b].y, g0s);
+            g1c = __builtin_fma(xf1, Bt[b].x, g1c);
+            g1s = __builtin_fma(xf1, Bt[b].y, g1s);
+        }
+        T2STAMP(prof_on && NEXT >= 0, 3);   // accumulation
+        tc = a0c; ts = a0s; t1c = a1c; t1s = a1s;
+        fc = g0c; fs_ = g0s; f1c = g1c; f1s = g1s;
+        pmc = xm * Bm.x;
+        pms = xm * Bm.y;
+        ppc = xp * Bp.x;
+        pps = xp * Bp.y;
+        const double dbm = (double)bmc - 7.5, dbp = (double)bpc - 7.5;
+        pm1c = pmc * dbm;
+        pm1s = pms * dbm;
+        pp1c = ppc * dbp;
+        pp1s = pps * dbp;
+    };
+
+    {
+        // set 0 owns the even blocks: block 0's pass runs here; set 1 requests the bytes of block 1
+        const T3Code& C0 = S.code[0];
+        if (set == 0) {
+            nraw = t2_load<SB>(rec, (pos0 & ~15ll) + lane_off, limit);
+            spec(nraw, pos0, C0.start[1], C0.step, C0.inv_step, C0.blk, S.carr[0], pos0 + 2ll * C0.blk);
+        } else {
+            npos_pred = pos0 + C0.blk;
+            nraw = t2_load<SB>(rec, (npos_pred & ~15ll) + lane_off, limit);
+        }
+    }
+    int it = 0;
+    for (; it < ms; ++it) {
+        const int par = it & 1;
+        const T3Code& C = S.code[par];
+        const T3Carr& CR = S.carr[par];
+        // one batch of LDS reads: the chain part, the block's code phase, the rotated tables, the rate step
+        const int4 hd = *reinterpret_cast<const int4*>(&C.blk);          // blk, stop, inv_step
+        const double step = C.step;
+        const double rem = C.start[1];                                   // (exact; posted a block ago)
+        const double2 w1 = CR.T[T2_W1 + (tid & 15)], w2 = CR.T[T2_W2 + ((tid >> 4) & 7)], w3 = CR.T[T2_W3];
+        const double2 ep = *reinterpret_cast<const double2*>(&CR.eps);   // eps, respec
+        T2_USE(hd.z); T2_USE(step); T2_USE(rem); T2_USE(w1.x); T2_USE(w2.x); T2_USE(w3.x); T2_USE(ep.x);   // one batch, one wait
+        if (hd.y) break;
+        T2_FP_TOP
+        const int blk = hd.x;
+        const double inv_step = __hiloint2double(hd.w, hd.z);
+        if ((it & 1) == set) {
+        // ======== this set's block: the final pass (on the chain) ========
+        __builtin_amdgcn_s_setprio(2);
+        const double eps = ep.x;
+        // group phasor G' = W1'[tid & 15] * W2'[(tid >> 4) & 7] * W3' (rotated tables)
+        double gc, gs;
+        {
+            const double lc = __builtin_fma(w1.x, w2.x, -(w1.y * w2.y));
+            const double ls = __builtin_fma(w1.x, w2.y, w1.y * w2.x);
+            gc = __builtin_fma(lc, w3.x, -(ls * w3.y));
+            gs = __builtin_fma(lc, w3.y, ls * w3.x);
+        }
+        // ---- where the boundary is now: u' = (kh - h'(ilo - 1)) / (2 step'); r = u' - (floor(u) + 1/2) ----
+        double r = (khd - __builtin_fma(im1d, step + step, rem + rem)) * (0.5 * inv_step) - mid;
+        double aI0, aQ0, aI1, aQ1, aI2, aQ2;                  // the lane's six sums: arm 0 early, 1 prompt, 2 late
+        bool direct = false;
+        {
+            const double a = fabs(r) - 0.5;                   // > 0: the boundary crossed a sample; NaN: this lane cannot change
+            const bool bad = (fabs(a) < 1e-7) || (a > 1.0);   // within 1e-7 samples of a sample / moved by two
+            const unsigned long long mb = __builtin_amdgcn_ballot_w64(bad);
+            unsigned long long me = 0;
+            if (__builtin_expect(blk != cut, 0))              // (wave-uniform: all lanes were cut for the same length)
+                me = __builtin_amdgcn_ballot_w64((i0 < (blk > cut ? blk : cut)) && (i0 + 16 > (blk < cut ? blk : cut)));
+            if (__builtin_expect((mb | me) != 0 || ep.y != 0.0, 0)) {
+                const T2Raw<SB> again = t2_load<SB>(rec, (pos & ~15ll) + lane_off, limit);   // (an L2 hit: read a block ago)
+                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) HERE: left to the compiler, a path that does not read every
+                                                      // register of `again` costs every block a full wait at the loop's top
+                if (mb != 0) {
+                    // DIRECT: per-sample chips from the exact linspace ramps (tracking.py:166-188), this block's own
+                    // sample phasors; the group phasor less the 7.5 samples of rate step the PLL wave turned W3 by
+                    direct = true;
+                    int budget = 1 << 20;
+                    while (lds_peek(&C.xflag) != it + 1 && --budget) __builtin_amdgcn_s_sleep(1);
+                    const double stE = C.stp[0], stP = C.stp[1], stL = C.stp[2];
+                    const double sE = C.start[0], sP = C.start[1], sL = C.start[2];
+                    const double e75 = 7.5 * eps;
+                    const double hc = __builtin_fma(e75, gs, gc), hs = __builtin_fma(-e75, gc, gs);   // G' (1 - j 7.5 eps)
+                    double dI0 = 0.0, dQ0 = 0.0, dI1 = 0.0, dQ1 = 0.0, dI2 = 0.0, dQ2 = 0.0;
+                    const int head = (int)(pos & 15);
+                    const int j0 = g * 16 - head;
+#pragma unroll 1
+                    for (int b = 0; b < 16; ++b) {
+                        const int i = j0 + b;
+                        if ((unsigned)i < (unsigned)blk) {
+                            const double x = (double)t2_sample<SB>(again, b, uns);
+                            const double2 Bb = CR.T[T2_B + b];
+                            const double pc = __builtin_fma(hc, Bb.x, -(hs * Bb.y));
+                            const double ps = __builtin_fma(hs, Bb.x, hc * Bb.y);
+                            const double xs = ps * x, xc = pc * x;
+                            const int kE = (int)ceil(ramp_at(i, stE, sE)), kP = (int)ceil(ramp_at(i, stP, sP)),
+                                      kL = (int)ceil(ramp_at(i, stL, sL));
+                            const double cE = (chip_bits2(S.cbits, kE) & 1u) ? -1.0 : 1.0;
+                            const double cP = (chip_bits2(S.cbits, kP) & 1u) ? -1.0 : 1.0;
+                            const double cL = (chip_bits2(S.cbits, kL) & 1u) ? -1.0 : 1.0;
+                            dI0 = __builtin_fma(cE, xs, dI0);
+                            dQ0 = __builtin_fma(cE, xc, dQ0);
+                            dI1 = __builtin_fma(cP, xs, dI1);
+                            dQ1 = __builtin_fma(cP, xc, dQ1);
+                            dI2 = __builtin_fma(cL, xs, dI2);
+                            dQ2 = __builtin_fma(cL, xc, dQ2);
+                        }
+                    }
+                    aI0 = dI0; aQ0 = dQ0; aI1 = dI1; aQ1 = dQ1; aI2 = dI2; aQ2 = dQ2;
+                } else {
+                    // accumulate again with the true code phase, rate and length.  The sample phasors stay those of the
+                    // speculative pass - the table of the previous block, which the PLL wave overwrites only after
+                    // this member has published - so that eps and the rotated W3 still apply; only when the PLL wave
+                    // says so (respec: it evaluated this block's tables in full, eps = 0) are they this block's own.
+                    spec(again, pos, rem, step, inv_step, blk, (it == 0 || ep.y != 0.0) ? CR : S.carr[par ^ 1], -1ll);
+                    r = (khd - __builtin_fma(im1d, step + step, rem + rem)) * (0.5 * inv_step) - mid;   // (no move left)
+                }
+            }
+        }
+        if (!direct) {
+            // 1.0 where the boundary crossed a sample downwards / upwards (arithmetic on the sign bit; the candidates of a
+            // lane that cannot change are zero, whatever r is)
+            const double dm = __hiloint2double((__double2hiint(r + 0.5) >> 31) & 0x3FF00000, 0);
+            const double dp = __hiloint2double((__double2hiint(0.5 - r) >> 31) & 0x3FF00000, 0);
+            // ---- the front's patch, first-order carrier correction of both sets ----
+            const double z0c = __builtin_fma(dp, ppc, __builtin_fma(dm, pmc, fc));
+            const double z0s = __builtin_fma(dp, pps, __builtin_fma(dm, pms, fs_));
+            const double z1c = __builtin_fma(dp, pp1c, __builtin_fma(dm, pm1c, f1c));
+            const double z1s = __builtin_fma(dp, pp1s, __builtin_fma(dm, pm1s, f1s));
+            const double Fc = __builtin_fma(-eps, z1s, z0c), Fs = __builtin_fma(eps, z1c, z0s);
+            const double Tc = __builtin_fma(-eps, t1s, tc), Ts = __builtin_fma(eps, t1c, ts);
+            // rotate by the group phasor: cos part -> Q, sin part -> I (tracking.py:205-207)
+            const double tQ = __builtin_fma(gc, Tc, -(gs * Ts)), tI = __builtin_fma(gs, Tc, gc * Ts);
+            const double fQ = __builtin_fma(gc, Fc, -(gs * Fs)), fI = __builtin_fma(gs, Fc, gc * Fs);
+            aI0 = __builtin_fma(beE, fI, alE * tI);
+            aQ0 = __builtin_fma(beE, fQ, alE * tQ);
+            aI1 = __builtin_fma(beP, fI, alP * tI);
+            aQ1 = __builtin_fma(beP, fQ, alP * tQ);
+            aI2 = __builtin_fma(beL, fI, alL * tI);
+            aQ2 = __builtin_fma(beL, fQ, alL * tQ);
+        }
+#ifdef T3_CHECK
+        // (diagnosis build) every lane's six sums against the direct evaluation
+        if (!direct) {
+            const T2Raw<SB> again = t2_load<SB>(rec, (pos & ~15ll) + lane_off, limit);
+            int budget = 1 << 20;
+            while (lds_peek(&C.xflag) != it + 1 && --budget) __builtin_amdgcn_s_sleep(1);
+            const double stE = C.stp[0], stP = C.stp[1], stL = C.stp[2];
+            const double sE = C.start[0], sP = C.start[1], sL = C.start[2];
+            const double e75 = 7.5 * eps;
+            const double hc = __builtin_fma(e75, gs, gc), hs = __builtin_fma(-e75, gc, gs);
+            double dI0 = 0.0, dQ0 = 0.0, dI1 = 0.0, dQ1 = 0.0, dI2 = 0.0, dQ2 = 0.0;
+            const int j0 = g * 16 - (int)(pos & 15);
+            for (int b = 0; b < 16; ++b) {
+                const int i = j0 + b;
+                if ((unsigned)i < (unsigned)blk) {
+                    const double x = (double)t2_sample<SB>(again, b, uns);
+                    const double2 Bb = CR.T[T2_B + b];
+                    const double pc = __builtin_fma(hc, Bb.x, -(hs * Bb.y));
+                    const double ps = __builtin_fma(hs, Bb.x, hc * Bb.y);
+                    const double xs = ps * x, xc = pc * x;
+                    const int kE = (int)ceil(ramp_at(i, stE, sE)), kP = (int)ceil(ramp_at(i, stP, sP)), kL = (int)ceil(ramp_at(i, stL, sL));
+                    const double cE = (chip_bits2(S.cbits, kE) & 1u) ? -1.0 : 1.0;
+                    const double cP = (chip_bits2(S.cbits, kP) & 1u) ? -1.0 : 1.0;
+                    const double cL = (chip_bits2(S.cbits, kL) & 1u) ? -1.0 : 1.0;
+                    dI0 = __builtin_fma(cE, xs, dI0); dQ0 = __builtin_fma(cE, xc, dQ0);
+                    dI1 = __builtin_fma(cP, xs, dI1); dQ1 = __builtin_fma(cP, xc, dQ1);
+                    dI2 = __builtin_fma(cL, xs, dI2); dQ2 = __builtin_fma(cL, xc, dQ2);
+                }
+            }
+            const double e_ = fabs(aI0 - dI0) + fabs(aQ0 - dQ0) + fabs(aI1 - dI1) + fabs(aQ1 - dQ1) + fabs(aI2 - dI2) + fabs(aQ2 - dQ2);
+            if (e_ > 1e-3 && blockIdx.x < 8 * 19 && (blockIdx.x & 7) == 0 && it < 6)
+                printf("[t3 check] it %d unit %d tid %d i0 %d cut %d blk %d khd %.1f mid %.3f r %.6f | E %.4f/%.4f P %.4f/%.4f L %.4f/%.4f | al %.0f %.0f %.0f be %.0f %.0f %.0f | t %.3f f %.3f eps %.3e\n",
+                       it, unit, tid, i0, cut, blk, khd, mid, r, aI0, dI0, aI1, dI1, aI2, dI2, alE, alP, alL, beE, beP, beL, tc, fc, eps);
+        }
+#endif
+        // fixed point: the raw bits of fma(a, 2^28, 1.5 2^52) are bias + round(a 2^28); sums of them carry the sum of the
+        // integers in their low 48 bits whatever the biases add up to
+        const double lane_fix = uns ? T2_FIX * 0.5 : T2_FIX;
+        constexpr unsigned long long res_mask = 0xFFFFFFFFFFFFull;
+        unsigned long long q[6];
+        {
+            double t_[6];
+            asm("v_fma_f64 %0, %1, %2, %3" : "=v"(t_[0]) : "v"(aI1), "s"(lane_fix), "v"(magic));
+            asm("v_fma_f64 %0, %1, %2, %3" : "=v"(t_[1]) : "v"(aQ1), "s"(lane_fix), "v"(magic));
+            asm("v_fma_f64 %0, %1, %2, %3" : "=v"(t_[2]) : "v"(aI0), "s"(lane_fix), "v"(magic));
+            asm("v_fma_f64 %0, %1, %2, %3" : "=v"(t_[3]) : "v"(aQ0), "s"(lane_fix), "v"(magic));
+            asm("v_fma_f64 %0, %1, %2, %3" : "=v"(t_[4]) : "v"(aI2), "s"(lane_fix), "v"(magic));
+            asm("v_fma_f64 %0, %1, %2, %3" : "=v"(t_[5]) : "v"(aQ2), "s"(lane_fix), "v"(magic));
+#pragma unroll
+            for (int k = 0; k < 6; ++k) q[k] = (unsigned long long)__double_as_longlong(t_[k]);
+        }
+        // transposing reduction inside each row of 16 lanes; exchange order I_P Q_P I_E Q_E I_L Q_L
+        unsigned long long vpe, vl;
+        t3_reduce6(q, odd1, odd2, vpe, vl);
+        {
+            const int rl = lane & 15;
+            if (rl < 6) {
+                const int word = rl < 4 ? rl : 4 + (rl & 1);
+                const unsigned long long mine = ((rl < 4 ? vpe : vl) & res_mask) | (1ull << 56);
+                const unsigned long long prev = atomicAdd(&S.acc[par][word], mine);
+                if ((prev >> 56) == 7ull) {
+                    // the eighth arrival (2 waves x 4 rows): this lane holds the member's total of its word
+                    const unsigned long long tot = prev + mine;
+                    S.acc[par][word] = 0ull;
+                    const unsigned long long gran = ((unsigned long long)((unsigned)(it + 1) & 0xFFFFu) << 48) | (tot & 0xFFFFFFFFFFFFull);
+                    granule_store(xbase + (par * 6 + word) * T3_XLINE + unit, gran, fast);
+                    if (prof_any && word == 0) S.tpub[par] = (long long)__builtin_amdgcn_s_memtime();
+                }
+            }
+        }
+        T2STAMP(prof_on, 5);   // published (or handed to the lanes that publish)
+        __builtin_amdgcn_s_setprio(0);
+        } else if (it + 1 < ms) {
+            // ======== the other set's block: this set accumulates the NEXT block with this block's rates (in the shadow).
+            // Its first sample is pos + blk; its code phase is rem + blk step - 1023 up to the roundings of the
+            // reference's linspace (1e-12 chips: the final pass sees the exact value, its guard is 2.7e-9); its length
+            // the one this code phase gives at this block's rate.
+            const double nrem = __builtin_fma((double)blk, step, rem) - 1023.0;
+            int nblk = (int)ceil((1023.0 - nrem) * inv_step);
+            nblk = nblk < 1 ? 1 : nblk;
+            const long long npos = pos + blk;
+            if (__builtin_expect((npos & ~15ll) != (npos_pred & ~15ll), 0))    // (the bytes were requested for a block start
+                nraw = t2_load<SB>(rec, (npos & ~15ll) + lane_off, limit);     //  in another 16-byte window: once in ~100 blocks)
+            spec(nraw, npos, nrem, step, inv_step, nblk, CR, npos + 2ll * nblk);
+        }
+        pos += blk;
+        T2STAMP(prof_on, 6);   // next block's speculative pass
+        __builtin_amdgcn_sched_barrier(0);
+        T3_WB(wb_on);
+        __builtin_amdgcn_sched_barrier(0);
+        T2STAMP(prof_on, 7);   // waiting for the loop filter
+    }
+    T2_FP_PRINT(prof_on && lane == 0, 0, 8)
+    T3_WB_PRINT(wb_on, "map", ms)
+    return it;
+}
+
+// ================================ PLL (wave 4) ================================
+// Lane = 32 word + unit polls that unit's granule of I_P (word 0) / Q_P (word 1).  The next block's tables are computed
+// IN FULL for the current rate while the wave waits for the sums; the rate step then turns every entry (W3 by 7.5
+// samples more: the map's moments are taken about the group's centre).
+__device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const TrkChan& cc, int unit, bool owner, int lane,
+                                           int P, int ch, unsigned long long* __restrict__ xbase, int* __restrict__ err,
+                                           bool prof_on, long long* __restrict__ prof, bool wb_on) {
+    (void)wb_on;
+    // tracking.py:123-130
+    long long acc_map = 0, acc_xch = 0, acc_flt = 0, t_top = 0, t_arr = 0;   // SGX_TRK_PROFILE=1: per-member phase times
+    double carrBasis = cc.acquiredFreq;
+    double remCarr = 0.0, w_cur = (cc.acquiredFreq * 2.0) * M_PI, oldCarrNco = 0.0, oldCarrErr = 0.0;
+    const double two_pi = 2 * M_PI;
+    double k_a = K.k_carr_a, k_b = K.k_carr_b, inv_2pi = K.inv_2pi, c_hi = K.inv_2pifs_hi, c_lo = K.inv_2pifs_lo,
+           inv_fs = K.inv_fs, fs = K.fs;
+    T2_PIN(k_a); T2_PIN(k_b); T2_PIN(inv_2pi); T2_PIN(c_hi); T2_PIN(c_lo); T2_PIN(inv_fs); T2_PIN(carrBasis);
+    T2_PIN(fs);
+    // the largest rate step the rotation takes: the farthest table entry is sample n_units * UNIT of the block
+    double dw_max = SGX_ROT_MAX / ((double)(K.n_units * T3_UNIT) * K.inv_fs);
+    T2_PIN(dw_max);
+    const int ms = K.ms;
+    SgxAtanCoef ak = sgx_atan_coef();
+    SgxRotCoef rk = sgx_rot_coef();
+    T2_PIN(ak.c0); T2_PIN(ak.c1); T2_PIN(ak.c2); T2_PIN(ak.c3); T2_PIN(ak.c4); T2_PIN(ak.c5); T2_PIN(ak.c6); T2_PIN(ak.c7); T2_PIN(ak.c8);
+    T2_PIN(rk.s0); T2_PIN(rk.s1); T2_PIN(rk.s2); T2_PIN(rk.s3); T2_PIN(rk.s4); T2_PIN(rk.s5);
+    T2_PIN(rk.c0); T2_PIN(rk.c1); T2_PIN(rk.c2); T2_PIN(rk.c3); T2_PIN(rk.c4); T2_PIN(rk.c5);
+    // lane 0 of a 32-lane half adds the bits of 1.5 2^52 to its payload: the half's integer sum then IS the double
+    const int bias_hi = ((lane & 31) == 0) ? 0x43380000 : 0;
+    double unfix = 1.0 / t2_fix_of<1>(P, K.n_units, K.uns != 0);
+    T2_PIN(unfix);
+    const bool w3 = lane >= 48;
+    const double ctr = w3 ? 7.5 : 0.0;
+    const bool mine = (lane & 31) < P;
+    unsigned long long* const xabort = xbase + T3_XABORT;
+    // record values of the block just finished (member 0), posted after the barrier: carrFreq I_P Q_P pllDiscr pllDiscrFilt
+    double r_cf = 0.0, r_ip = 0.0, r_qp = 0.0, r_err = 0.0, r_nco = 0.0;
+    double s2_blk = 1.0;             // 1 - 10.625 eps^2 of the block being processed
+    T2_FP_DECL
+    T3_WB_DECL
+    (void)prof_on;
+    __builtin_amdgcn_s_setprio(3);
+    int it = 0;
+    for (; it < ms; ++it) {
+        const int par = it & 1;
+        const T3Code& C = S.code[par];
+        const int4 hd = *reinterpret_cast<const int4*>(&C.blk);
+        const long long pos = C.pos;
+        if (owner && it > 0) {
+            if (lane == 0) {
+                double* R = S.rec[par ^ 1];      // T9 record (tracking.py:255-275) of block it - 1, stored by the record wave
+                R[2] = r_cf;
+                R[3] = r_ip;
+                R[7] = r_qp;
+                R[11] = r_err;
+                R[12] = r_nco;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            if (lane == 0) lds_poke(&S.rflag[0], it);
+        }
+        if (hd.y) break;
+        T2_FP_TOP
+        if (prof) t_top = (long long)__builtin_amdgcn_s_memtime();
+        // ---- before the sums arrive ----
+        // carrier phase at the end of this block (T5), exact remainder by FMA
+        const int blk = hd.x;
+        const int head_next = (int)((pos + blk) & 15);
+        double rc;
+        {
+            const double arg_end = w_cur * div_rn((double)blk, fs, inv_fs) + remCarr;   // blk / fs, correctly rounded
+            const double kq = floor(arg_end * inv_2pi);
+            rc = __builtin_fma(-kq, two_pi, arg_end);
+            if (rc < 0.0) rc += two_pi;
+            if (rc >= two_pi) rc -= two_pi;
+        }
+        // the next block's table entry of this lane at the CURRENT rate, in full; the sums then only turn it
+        const int mi = t3_carr_mult(lane, unit, head_next);
+        double mf = ((double)mi + ctr) * inv_fs;     // m / fs: the rate step dw turns the entry by dw * mf radians
+        double cs_p, sn_p;
+        t2_carr_entry(c_hi, c_lo, inv_2pi, w_cur, rc, mi, w3, cs_p, sn_p);
+        T2_PIN(cs_p); T2_PIN(sn_p); T2_PIN(mf); T2_PIN(rc);   // (keeps all of this ahead of the wait)
+        const unsigned long long* gp = xbase + (par * 6 + (lane >> 5)) * T3_XLINE + (lane & 31);
+        const unsigned long long tag = (unsigned long long)((unsigned)(it + 1) & 0xFFFFu);
+        unsigned long long x = 0;
+        int budget = T2_POLL_BUDGET;
+        bool gave_up = false;
+        for (;;) {
+            if (mine) x = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all(!mine || (x >> 48) == tag)) break;
+            if ((--budget & 31) == 0) {
+                if (budget == 0 || lds_peek(&S.flag[1]) != 0) {
+                    gave_up = true;
+                    break;
+                }
+            }
+        }
+        T2STAMP(prof_on, 8);   // waiting for the sums
+        if (prof) {
+            t_arr = (long long)__builtin_amdgcn_s_memtime();
+            const long long tp = lds_peek64(&S.tpub[par]);
+            acc_map += tp - t_top;       // barrier release -> this member's publish
+            acc_xch += t_arr - tp;       // this member's publish -> every member's sums visible
+        }
+        // sum of the units' payloads (integers: exact, order-free); lanes that poll nothing hold 0
+        unsigned long long q = ((unsigned long long)(unsigned)((int)(short)(unsigned short)(x >> 32) + bias_hi) << 32) | (unsigned)x;
+        q = dpp_addl_xor1(q, q);
+        q = dpp_addl_xor2(q, q);
+        q = dpp_addl_hmir(q, q);
+        q = dpp_addl_mir(q, q);
+        q = t3_addl_bc15(q);             // rows 1 and 3: the sums over lanes 0..31 / 32..63
+        const double v = (__longlong_as_double((long long)q) - T2_MAGIC) * unfix;
+        const double I_P = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16),
+                                            __builtin_amdgcn_readlane(__double2loint(v), 16));
+        const double Q_P = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 48),
+                                            __builtin_amdgcn_readlane(__double2loint(v), 48));
+        // T7 PLL (tracking.py:223-235); atan(Q/I) / 2 / pi as one multiplication by RN(1 / (2 pi)) (1.5 ulp)
+        const double carrError = sgx_atan_ratio_k(Q_P, I_P, ak) * inv_2pi;
+        const double carrNco = oldCarrNco + k_a * (carrError - oldCarrErr) + carrError * k_b;
+        const double carrFreq = carrBasis + carrNco;
+        const double w_new = (carrFreq * 2.0) * M_PI;
+        oldCarrNco = carrNco;
+        oldCarrErr = carrError;
+        T2PROBE(prof_on, 9);   // discriminator + NCO
+        // carrier tables of the next block: the prepared entry turned by the rate step (exact: w_new - w_cur is)
+        double s2_next = 1.0;
+        if (it + 1 < ms) {
+            const double dw = w_new - w_cur;
+            double cs, sn, eps_n, respec_n;
+            if (__builtin_expect(fabs(dw) <= dw_max, 1)) {
+                double es, ec;
+                sgx_rot_small(dw * mf, rk, es, ec);
+                cs = __builtin_fma(cs_p, ec, -(sn_p * es));
+                sn = __builtin_fma(cs_p, es, sn_p * ec);
+                eps_n = dw * inv_fs;
+                respec_n = 0.0;
+            } else {
+                t2_carr_entry(c_hi, c_lo, inv_2pi, w_new, rc, mi, w3, cs, sn);
+                eps_n = 0.0;
+                respec_n = 1.0;
+            }
+            S.carr[par ^ 1].T[lane] = make_double2(cs, sn);
+            if (lane == 0) *reinterpret_cast<double2*>(&S.carr[par ^ 1].eps) = make_double2(eps_n, respec_n);
+            s2_next = __builtin_fma(-10.625 * eps_n, eps_n, 1.0);
+        }
+        w_cur = w_new;
+        remCarr = rc;
+        r_cf = carrFreq;
+        r_ip = I_P * s2_blk;
+        r_qp = Q_P * s2_blk;
+        s2_blk = s2_next;
+        r_err = carrError;
+        r_nco = carrNco;
+        if (gave_up && lane == 0) {
+            S.flag[1] = 1;
+            atomicCAS(err, 0, 1 + ch);
+            __hip_atomic_store(xabort, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        T2STAMP(prof_on, 10);  // carrier tables
+        T3_WB(wb_on);
+        if (prof) acc_flt += (long long)__builtin_amdgcn_s_memtime() - t_arr;   // sums visible -> barrier released
+        T2STAMP(prof_on, 11);
+    }
+    if (owner && it > 0 && it == ms) {
+        // (when the loop ran out of blocks, the last block's record values are still in registers)
+        if (lane == 0) {
+            double* R = S.rec[(it - 1) & 1];
+            R[2] = r_cf;
+            R[3] = r_ip;
+            R[7] = r_qp;
+            R[11] = r_err;
+            R[12] = r_nco;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        if (lane == 0) lds_poke(&S.rflag[0], it);
+    }
+    if (prof && lane == 0) {
+        prof[ch * T2_PROF_STRIDE + unit] = acc_map;
+        prof[ch * T2_PROF_STRIDE + 64 + unit] = acc_xch;
+        prof[ch * T2_PROF_STRIDE + 128 + unit] = acc_flt;
+    }
+    T2_FP_PRINT(prof_on && lane == 0, 8, 12)
+    T3_WB_PRINT(wb_on, "pll", ms)
+    return it;
+}
+
+// ================================ DLL (wave 5) ================================
+// Lanes work in parallel on the three ramps: lane & 3 = 0 early, 1 prompt, 2 late (3 repeats prompt); uniform results
+// come from lane 1 / lane 0.  Two polls: lane = 32 w + unit reads word 2 + w (I_E, Q_E) and word 4 + w (I_L, Q_L).
+struct T3DllConst {
+    double fs, inv_fs, code_len, spacing;
+    double inv_nb_lane;     // RN(1 / (nb_base + (lane & 7))): reciprocals of the plausible block lengths, one per lane
+    int nb_base;
+    long long rec_len;
+};
+
+__device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const T3DllConst& D, long long pos0, int blk0,
+                                           int stop0, bool owner, int lane, int P, int ch,
+                                           unsigned long long* __restrict__ xbase, int* __restrict__ err, bool prof_on,
+                                           long long file_off, bool wb_on) {
+    (void)wb_on;
+    // tracking.py:114-121; block 0's chain part and ramp starts were posted before the loop
+    double oldCodeNco = 0.0, oldCodeErr = 0.0;
+    double k_a = K.k_code_a, k_b = K.k_code_b, basis = K.code_basis;
+    T2_PIN(k_a); T2_PIN(k_b); T2_PIN(basis);
+    const int ms = K.ms;
+    double rem = 0.0, cf = K.code_basis;
+    long long pos = pos0;
+    int blk = blk0, stop = stop0;
+    const int l4 = lane & 3;
+    const double off = (l4 == 0) ? -D.spacing : ((l4 == 2) ? D.spacing : 0.0);   // rem - spc == rem + (-spc) exactly
+    const int lim3 = K.n_units * T3_UNIT - 15;             // the longest block the units of the launch hold
+    const int bias_hi = ((lane & 31) == 0) ? 0x43380000 : 0;   // (see the PLL wave)
+    double unfix = 1.0 / t2_fix_of<1>(P, K.n_units, K.uns != 0);
+    T2_PIN(unfix);
+    const bool mine = (lane & 31) < P;
+    unsigned long long* const xabort = xbase + T3_XABORT;
+    // record values of the block just finished (member 0), posted after the barrier
+    double r_ve = 0.0, r_vl = 0.0, r_cf = 0.0, r_err = 0.0, r_nco = 0.0;
+    T2_FP_DECL
+    T3_WB_DECL
+    (void)prof_on;
+    __builtin_amdgcn_s_setprio(3);
+    int it = 0;
+    for (; it < ms; ++it) {
+        const int par = it & 1;
+        T3Code& C = S.code[par];
+        T3Code& N = S.code[par ^ 1];
+        if (owner && it > 0) {
+            double* R = S.rec[par ^ 1];
+            // rows 1 / 3 hold I / Q of early (r_ve) and late (r_vl) -> series 4 (I_E), 6 (Q_E), 5 (I_L), 8 (Q_L)
+            if (lane == 16) { R[4] = r_ve; R[5] = r_vl; }
+            if (lane == 48) { R[6] = r_ve; R[8] = r_vl; }
+            if (lane == 0) {
+                R[0] = (double)(pos + file_off);   // position after block it - 1 = first sample of block it
+                R[1] = r_cf;
+                R[9] = r_err;
+                R[10] = r_nco;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            if (lane == 0) lds_poke(&S.rflag[1], it);
+        }
+        if (stop) break;
+        T2_FP_TOP
+        // (the sums of this block carry the factor 1 - 10.625 eps^2 in what is recorded)
+        const double e_ = S.carr[par].eps;
+        const double s2_blk = __builtin_fma(-10.625 * e_, e_, 1.0);
+        // ---- before the sums arrive: the exact arithmetic of this block (T1, T3) and the next block's early part ----
+        const double step = div_rn(cf, D.fs, D.inv_fs);                             // codeFreq / fs
+        const double nb = (double)blk;
+        const double span = nb * step;                                              // blksize * codePhaseStep
+        const int ki = blk - D.nb_base;
+        const bool known = (ki >= 0 && ki < 8);
+        const int kq = __builtin_amdgcn_readfirstlane(ki) & 7;
+        const double ynb = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(D.inv_nb_lane), kq),
+                                            __builtin_amdgcn_readlane(__double2loint(D.inv_nb_lane), kq));
+        // np.linspace(start, stop, blk, endpoint=False): delta = stop - start; step = delta / blk
+        const double start = rem + off;
+        const double d = ((span + rem) + off) - start;
+        double stp;
+        if (__builtin_expect(known, 1)) stp = div_rn(d, nb, ynb);
+        else stp = d / nb;
+        if (lane < 3) C.stp[lane] = stp;
+        // code phase and first sample of the next block (T4) and that block's ramp starts
+        const double t_last = ramp_at(blk - 1, stp, start);
+        const double rn_lane = (t_last + step) - 1023.0;                            // meaningful in the prompt lane
+        const double rem_next = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rn_lane), 1),
+                                                 __builtin_amdgcn_readlane(__double2loint(rn_lane), 1));
+        const long long pos_next = pos + blk;
+        if (lane < 3) N.start[lane] = rem_next + off;
+        if (lane == 0) N.pos = pos_next;
+        double a_next = D.code_len - rem_next;                                      // (1023 - rem) of T1
+        {
+            // the next block's length if the code rate stayed (the speculative pass cuts its samples there; the true
+            // length differs in ~2 % of the blocks, and then by one sample)
+            double sa_, is_;
+            const int bp = sgx_block_length(a_next, cf, D.fs, D.inv_fs, sa_, is_);
+            if (lane == 0) N.blk_pred = bp;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        if (lane == 0) {
+            lds_poke(&N.eflag, it + 2);
+            lds_poke(&C.xflag, it + 1);
+        }
+        // the longest next block the record (stop 1 beyond it) and the units of the launch (stop 3) hold: ONE compare on
+        // the chain, which of the two it was is sorted out in the (rare) branch
+        const long long room = D.rec_len - pos_next;
+        const int lim1 = room > (long long)0x3FFFFFFF ? 0x3FFFFFFF : (room < 0 ? 0 : (int)room);
+        unsigned lim = (unsigned)(lim1 < lim3 ? lim1 : lim3);
+        T2_PIN(a_next); T2_PIN(lim);
+        const unsigned long long* gp1 = xbase + (par * 6 + 2 + (lane >> 5)) * T3_XLINE + (lane & 31);
+        const unsigned long long* gp2 = gp1 + 2 * T3_XLINE;
+        const unsigned long long tag = (unsigned long long)((unsigned)(it + 1) & 0xFFFFu);
+        unsigned long long x1 = 0, x2 = 0, xa = 0;
+        int budget = T2_POLL_BUDGET;
+        bool gave_up = false;
+        for (;;) {
+            if (mine) {
+                x1 = __hip_atomic_load(gp1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                x2 = __hip_atomic_load(gp2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (__all(!mine || ((x1 >> 48) == tag && (x2 >> 48) == tag))) break;
+            if ((--budget & 15) == 0) {
+                xa = __hip_atomic_load(xabort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (xa != 0 || budget == 0) {
+                    gave_up = true;
+                    break;
+                }
+            }
+        }
+        T2STAMP(prof_on, 12);  // waiting for the sums
+        // T8 DLL (tracking.py:238-251).  Integer sums over the units (exact, order-free; lanes that poll nothing hold 0):
+        // rows 1 and 3 then hold I and Q of the early (q1) and of the late arm (q2)
+        unsigned long long q1 = ((unsigned long long)(unsigned)((int)(short)(unsigned short)(x1 >> 32) + bias_hi) << 32) | (unsigned)x1;
+        unsigned long long q2 = ((unsigned long long)(unsigned)((int)(short)(unsigned short)(x2 >> 32) + bias_hi) << 32) | (unsigned)x2;
+        q1 = dpp_addl_xor1(q1, q1);
+        q2 = dpp_addl_xor1(q2, q2);
+        q1 = dpp_addl_xor2(q1, q1);
+        q2 = dpp_addl_xor2(q2, q2);
+        q1 = dpp_addl_hmir(q1, q1);
+        q2 = dpp_addl_hmir(q2, q2);
+        q1 = dpp_addl_mir(q1, q1);
+        q2 = dpp_addl_mir(q2, q2);
+        q1 = t3_addl_bc15(q1);
+        q2 = t3_addl_bc15(q2);
+        const double ve = (__longlong_as_double((long long)q1) - T2_MAGIC) * unfix;   // row 1: I_E, row 3: Q_E
+        const double vl = (__longlong_as_double((long long)q2) - T2_MAGIC) * unfix;   // row 1: I_L, row 3: Q_L
+        const double sqe = ve * ve, sql = vl * vl;
+        const double e2 = sqe + dpp_bcast<0x143, 0xC>(sqe);  // row 3: I_E^2 + Q_E^2 (row_bcast:31: lane 31 to rows 2, 3)
+        const double l2 = sql + dpp_bcast<0x143, 0xC>(sql);  // row 3: I_L^2 + Q_L^2
+        const double mE = sgx_sqrt1_pos(e2), mL = sgx_sqrt1_pos(l2);   // (two zero envelopes: NaN, as in the reference)
+        const double ce_lane = sgx_div1(mE - mL, mE + mL);   // row 3: (E - L) / (E + L)
+        const double codeError = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ce_lane), 48),
+                                                  __builtin_amdgcn_readlane(__double2loint(ce_lane), 48));
+        const double codeNco = oldCodeNco + k_a * (codeError - oldCodeErr) + codeError * k_b;
+        const double cf_new = basis - codeNco;
+        oldCodeNco = codeNco;
+        oldCodeErr = codeError;
+        T2PROBE(prof_on, 13);  // discriminator + NCO
+        // chain part of the next block: its length, the ramps' slope and the slope's reciprocal
+        double step_a, inv_step;
+        const int blk_n = sgx_block_length(a_next, cf_new, D.fs, D.inv_fs, step_a, inv_step);
+        int stop_n = 0;
+        if (__builtin_expect((unsigned)(blk_n - 1) >= lim || gave_up, 0)) {      // (blk <= 0 wraps to a huge number)
+            stop_n = gave_up ? 2 : ((blk_n <= 0 || blk_n > lim1) ? 1 : 3);
+            if (lane == 0 && stop_n == 3) {
+                atomicOr(err, TRK_ERR_RANGE);
+                atomicCAS(err + 1, 0, 1 + ch);
+            }
+        }
+        if (lane == 0) {
+            *reinterpret_cast<int4*>(&N.blk) = make_int4(blk_n, stop_n, __double2loint(inv_step), __double2hiint(inv_step));
+            N.step = step_a;
+        }
+        rem = rem_next;
+        pos = pos_next;
+        cf = cf_new;
+        blk = blk_n;
+        stop = stop_n;
+        r_ve = ve * s2_blk;
+        r_vl = vl * s2_blk;
+        r_cf = cf_new;
+        r_err = codeError;
+        r_nco = codeNco;
+        if (gave_up && lane == 0) {
+            S.flag[1] = 1;
+            if (xa == 0) {
+                atomicCAS(err, 0, 1 + ch);
+                __hip_atomic_store(xabort, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        T2STAMP(prof_on, 14);  // next block's code parameters
+        T3_WB(wb_on);
+        T2STAMP(prof_on, 15);
+    }
+    if (owner && it > 0 && it == ms) {
+        double* R = S.rec[(it - 1) & 1];
+        if (lane == 16) { R[4] = r_ve; R[5] = r_vl; }
+        if (lane == 48) { R[6] = r_ve; R[8] = r_vl; }
+        if (lane == 0) {
+            R[0] = (double)(pos + file_off);
+            R[1] = r_cf;
+            R[9] = r_err;
+            R[10] = r_nco;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        if (lane == 0) lds_poke(&S.rflag[1], it);
+    }
+    T2_FP_PRINT(prof_on && lane == 0, 12, 16)
+    T3_WB_PRINT(wb_on, "dll", ms)
+    return it;
+}
+
+// ================================ RECORD (wave 6) ================================
+// Stores block k's 13 series values once both filter waves have posted them (rflag >= k + 1): one block behind.  A
+// stalled filter wave is an error, never stale rows (the host repeats the launch).
+__device__ __forceinline__ void t3_rec_store(T3Shared& S, int k, long long m, int lane, double* __restrict__ o,
+                                             int* __restrict__ err, int ch) {
+    int budget = 1 << 18;
+    while ((lds_peek(&S.rflag[0]) < k + 1 || lds_peek(&S.rflag[1]) < k + 1) && --budget) __builtin_amdgcn_s_sleep(2);
+    if (budget == 0) {
+        if (lane == 0) atomicCAS(err, 0, 1 + ch);
+        return;
+    }
+    if (lane < SGX_NUM_SERIES) o[lane * m + k] = S.rec[k & 1][lane];
+}
+
+// (a record that is still streaming in: see t2_rec_role in sgx_trk2.hip)
+// PREFETCH: a unit reads 2 KB of every block - a new page for the CU's address translation and a miss all the way to
+// HBM every time, 1.5-2 us from request to data, as long as a whole code period.  The map waves request a block's bytes
+// one block ahead and cannot afford more registers in flight; this wave, idle otherwise, touches the unit's cache lines
+// THREE blocks ahead (one dword per 128-byte line, one load instruction per block, result never read), so that the map
+// waves' requests find the lines in L2 and the translation cached.
+__device__ __forceinline__ int t3_rec_role(T3Shared& S, const TrkConst& K, const int8_t* __restrict__ rec, int unit, int ch,
+                                           bool owner, int lane, double* __restrict__ o, int* __restrict__ err,
+                                           unsigned long long mark_seen, bool wb_on) {
+    (void)wb_on;
+    const long long m = K.ms;
+    const int ms = K.ms;
+    const long long span = 2ll * K.n_units * T3_UNIT + 64;   // bytes: a block and the window of the prefetch behind it
+    const long long limit = K.rec_alloc - 16;
+    unsigned dummy = 0;
+    T3_WB_DECL
+    int it = 0;
+    for (; it < ms; ++it) {
+        const int par = it & 1;
+        const T3Code& C = S.code[par];
+        if (C.stop) break;
+        if (lane < 20) {
+            long long a = ((C.pos + 3ll * C.blk) & ~127ll) + (long long)unit * T3_UNIT + 128ll * (lane - 1);
+            a = a < 0 ? 0 : (a > limit ? limit : a);
+            if (K.mark == nullptr || (unsigned long long)(a + 128) <= mark_seen)   // (a streaming record: only what is resident)
+                asm volatile("global_load_dword %0, %1, off" : "+v"(dummy) : "v"(rec + a) : "memory");
+        }
+        if (owner && it > 0) t3_rec_store(S, it - 1, m, lane, o, err, ch);
+        {   // (a resident record: mark_seen is all ones and this returns at once)
+            const long long need = C.pos + 4 * span;
+            wait_mark(K.mark, need < K.rec_len ? need : K.rec_len, mark_seen, err, ch);
+        }
+        T3_WB(wb_on);
+    }
+    T3_WB_PRINT(wb_on, "rec", ms)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(dummy) : : "memory");   // (no request outlives the wave's registers)
+    return it;
+}
+
+// A channel has P = K.split = K.n_units members, member = unit.
+__global__ __launch_bounds__(T3_THREADS) void trk3_kernel(const int8_t* __restrict__ rec, const int8_t* __restrict__ codes,
+                                                          const TrkChan* __restrict__ chans, double* __restrict__ out,
+                                                          int* __restrict__ ms_done, TrkConst K,
+                                                          long long* __restrict__ prof,
+                                                          unsigned long long* __restrict__ xch, int* __restrict__ err) {
+    __shared__ T3Shared S;
+    const int P = K.split;
+    const int bq = blockIdx.x >> 3, br = blockIdx.x & 7;
+    const int ch = br + 8 * (bq / P);
+    const int unit = bq % P;
+    const bool owner = unit == 0;              // the member that records the channel's series
+    if (ch >= K.n_ch) return;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const TrkChan cc = chans[ch];
+    if (cc.prn == 0) {
+        if (tid == 0 && owner) ms_done[ch] = 0;
+        return;
+    }
+    unsigned long long* __restrict__ xbase = xch + (long long)ch * T3_XCH_STRIDE;   // granules, abort word, placement granules
+    unsigned long long* const xabort = xbase + T3_XABORT;
+    const bool prof_on = (owner && ch == 0 && prof != nullptr && (wave == 0 || wave == 4 || wave == 5));
+
+    if (tid < 4) {
+        S.flag[tid] = 0;
+        S.rflag[tid] = 0;
+    }
+    if (tid < 16) S.acc[tid >> 3][tid & 7] = 0ull;
+    if (tid < 2) {
+        S.code[tid].xflag = 0;
+        S.code[tid].eflag = 0;
+        S.code[tid].blk_pred = 0;
+        S.carr[tid].eps = 0.0;
+        S.carr[tid].respec = 0.0;
+    }
+    // sign bits of the extended code [c1022, c0 .. c1022, c0] (tracking.py:111): bit k + 1 is set where chip k is -1
+    for (int base = wave * 64; base < 40 * 32; base += (T3_THREADS / 64) * 64) {   // (T3_THREADS / 64 = 7 waves)
+        const int i = base + lane;
+        const int j = (i - 2 + 2 * 1023) % 1023;             // chip k = i - 1 of the extended code is code[(k - 1) mod 1023]
+        const bool neg = i < 1032 && codes[(cc.prn - 1) * 1023 + j] < 0;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(neg);
+        if (lane == 0) {
+            S.cbits[base >> 5] = (unsigned)m;
+            S.cbits[(base >> 5) + 1] = (unsigned)(m >> 32);
+        }
+    }
+    __syncthreads();
+    // ---- placement: are all members of the channel on one XCD (one L2)?  Then the exchange may stay in that L2.
+    if (wave == 4) {
+        unsigned long long* pl = xbase + T3_XPLACE;
+        const unsigned me = xcc_id();
+        if (lane == 0) __hip_atomic_store(pl + unit, 0xC0DE000000000000ull | me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long x = 0;
+        int budget = T2_POLL_BUDGET;
+        bool gave_up = false;
+        for (;;) {
+            if (lane < P) x = __hip_atomic_load(pl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool ok = lane >= P || (x >> 48) == 0xC0DE;
+            if (__all(ok)) break;
+            if (--budget == 0) {
+                gave_up = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        const bool same = __all(lane >= P || (unsigned)(x & 0xF) == me);
+        if (lane == 0) {
+            S.flag[0] = (same && !gave_up && K.fast_xcd != 0) ? 1 : 0;
+            if (gave_up) {   // a member is not resident: give the channel up at once (the host repeats with split 1)
+                S.flag[1] = 1;
+                atomicCAS(err, 0, 1 + ch);
+                __hip_atomic_store(xabort, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    __syncthreads();
+    const bool fast = S.flag[0] != 0;
+    const bool dead = S.flag[1] != 0;
+
+    // block 0 parameters (tracking.py:114-130): chain part and ramp starts
+    T3DllConst D;
+    int blk0 = 0, stop0 = 0;
+    if (wave == 5) {
+        D.fs = K.fs;
+        D.inv_fs = K.inv_fs;
+        D.code_len = K.code_len;
+        D.spacing = K.spacing;
+        D.inv_nb_lane = 1.0 / (double)(K.nb_base + (lane & 7));
+        D.nb_base = K.nb_base;
+        D.rec_len = K.rec_len;
+        double step_a, inv_step;
+        blk0 = sgx_block_length(K.code_len - 0.0, K.code_basis, D.fs, D.inv_fs, step_a, inv_step);
+        const int lim3 = K.n_units * T3_UNIT - 15;
+        stop0 = dead ? 2 : ((blk0 <= 0 || cc.pos0 + blk0 > D.rec_len) ? 1 : ((blk0 > lim3) ? 3 : 0));
+        const double off = ((lane & 3) == 0) ? -K.spacing : (((lane & 3) == 2) ? K.spacing : 0.0);
+        if (lane < 3) S.code[0].start[lane] = 0.0 + off;
+        if (lane == 0) {
+            *reinterpret_cast<int4*>(&S.code[0].blk) = make_int4(blk0, stop0, __double2loint(inv_step), __double2hiint(inv_step));
+            S.code[0].step = step_a;
+            S.code[0].pos = cc.pos0;
+            if (blk0 > lim3) {
+                atomicOr(err, TRK_ERR_RANGE);
+                atomicCAS(err + 1, 0, 1 + ch);
+            }
+        }
+    }
+    if (wave == 4) {
+        double cs, sn;
+        t2_carr_entry(K.inv_2pifs_hi, K.inv_2pifs_lo, K.inv_2pi, (cc.acquiredFreq * 2.0) * M_PI, 0.0,
+                      t3_carr_mult(lane, unit, (int)(cc.pos0 & 15)), lane >= 48, cs, sn);
+        S.carr[0].T[lane] = make_double2(cs, sn);
+    }
+    // a streaming record: block 0 and the requests made for blocks 1 and 2 must be resident before the first loads
+    unsigned long long mark_seen = K.mark ? 0ull : ~0ull;
+    if (wave == 6 && K.mark) {
+        const long long need = cc.pos0 + 4 * (2ll * K.n_units * T3_UNIT + 64);
+        wait_mark(K.mark, need < K.rec_len ? need : K.rec_len, mark_seen, err, ch);
+    }
+    __syncthreads();
+
+    double* __restrict__ o = out + (long long)ch * SGX_NUM_SERIES * K.ms;
+    const bool wb_on = T3_WB_ON(unit, ch);
+    int done;
+    if (wave < 4)
+        done = t3_map_role<1>(S, rec, K.rec_alloc, K.ms, cc.pos0, unit, wave >> 1, tid, xbase, fast, K.code_basis / K.fs,
+                              K.spacing, K.uns != 0, prof_on, prof != nullptr, wb_on);
+    else if (wave == 4)
+        done = t3_pll_role(S, K, cc, unit, owner, lane, P, ch, xbase, err, prof_on, prof, wb_on);
+    else if (wave == 5)
+        done = t3_dll_role(S, K, D, cc.pos0, blk0, stop0, owner, lane, P, ch, xbase, err, prof_on, K.file_off, wb_on);
+    else
+        done = t3_rec_role(S, K, rec, unit, ch, owner, lane, o, err, mark_seen, wb_on);
+
+    // a channel that was given up reports the blocks completed before the abort
+    const bool aborted = S.code[done & 1].stop == 2;
+    if (wave == 6 && owner && done > 0 && !aborted) t3_rec_store(S, done - 1, (long long)K.ms, lane, o, err, ch);
+    if (aborted && done > 0) done -= 1;
+    if (tid == 0 && owner) ms_done[ch] = done;
+}
+
+// n_blocks = 8-padded channels x K.split workgroups; lds_pad: extra dynamic LDS per workgroup, so that a CU holds ONE
+// workgroup of the launch (members must not share a CU: they would share its issue ports)
+void sgx_trk3_launch(int n_blocks, hipStream_t st, const int8_t* rec, const int8_t* codes, const TrkChan* chans,
+                     double* out, int* done, const TrkConst& K, long long* prof, unsigned long long* xch, int* err,
+                     int lds_pad) {
+    if (lds_pad > 0)
+        (void)hipFuncSetAttribute((const void*)trk3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pad);
+    trk3_kernel<<<n_blocks, T3_THREADS, (size_t)(lds_pad > 0 ? lds_pad : 0), st>>>(rec, codes, chans, out, done, K, prof, xch, err);
+}

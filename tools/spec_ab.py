@@ -1,4 +1,4 @@
-"""(round 4 diagnosis) the speculative map (SGX_TRK_SPEC=1) against the round-3 map (SGX_TRK_SPEC=0) on the same record:
+"""(round 4 diagnosis) the speculative kernel (sgx_trk3.hip, SGX_TRK_V3=1) against the round-3 kernel (SGX_TRK_V3=0) on the same record:
 first block whose boundary differs, largest difference of the sums before it.  GPU box: python tools/spec_ab.py [ms] [seed]"""
 import importlib, os, sys
 import numpy as np
@@ -12,7 +12,7 @@ a = m.AcquisitionResult(s, device=0); a.acquire(m.DeviceSignal(rec, 0, 11 * n));
 chans = [(int(c.PRN), float(c.acquiredFreq), float(c.codePhase)) for c in a.channels if c.PRN != 0]
 out = {}
 for spec in ("0", "1"):
-    os.environ["SGX_TRK_SPEC"] = spec
+    os.environ["SGX_TRK_V3"] = spec
     ser, dn = ctx.track(rec, chans, ms)
     out[spec] = np.array(ser)
     print("spec", spec, "kernel_ms %.3f" % ctx.timing()["track_ms"], "done", dn.tolist())
