@@ -222,7 +222,7 @@ static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
     // samples of code phase (1 % margin for the code NCO).  E and L sharing theirs (d = 1/2) is fine.  int8 / uint8
     // records, one workgroup per unit of 128 groups, while 8-padded channels x units fit the CUs.
     const int n_units2 = K.n_units;
-    const int n_units3 = (int)(((c->n_code + 64 + 15 + 15) / 16 + T3_LANES - 1) / T3_LANES);
+    const int n_units3 = 2 * n_units2;   // (units of half the size: the same room for a code NCO that left its basis)
     bool use_v3 = false;
     {
         const double d = S.dllCorrelatorSpacing, e = 1.0 - d;

@@ -221,6 +221,7 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
     const unsigned long long odd1 = 0xAAAAAAAAAAAAAAAAull, odd2 = 0xCCCCCCCCCCCCCCCCull;       // lanes with bit 0 / bit 1 set
     double magic = T2_MAGIC;
     T2_PIN(magic);
+    const double step_max = 0.5 / 18.0;
     // ---- what the speculative pass of a block leaves for its final pass ----
     double tc = 0.0, ts = 0.0, t1c = 0.0, t1s = 0.0;         // moments of ALL samples (cos, sin parts; order 0 and 1)
     double fc = 0.0, fs_ = 0.0, f1c = 0.0, f1s = 0.0;        // moments of the samples IN FRONT of the boundary
@@ -351,7 +352,9 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
 #pragma unroll
         for (int b = 0; b < 16; ++b) {
             const double xs = __hiloint2double((int)xh[b], 0);
-            const double xf = __hiloint2double((int)(xh[b] & (unsigned)__builtin_amdgcn_sbfe(fmask, b, 1)), 0);
+            unsigned mb_;                                     // all ones iff b < bsw (asm: the compiler turns the
+            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(mb_) : "v"(fmask), "n"(b));   // builtin into a compare + select through VCC)
+            const double xf = __hiloint2double((int)(xh[b] & mb_), 0);
             const double x1 = xs * ((double)b - 7.5);
             const double xf1 = xf * ((double)b - 7.5);
             a0c = __builtin_fma(xs, Bt[b].x, a0c);
@@ -400,9 +403,9 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
         const double2 w1 = CR.T[T2_W1 + (tid & 15)], w2 = CR.T[T2_W2 + ((tid >> 4) & 7)], w3 = CR.T[T2_W3];
         const double2 ep = *reinterpret_cast<const double2*>(&CR.eps);   // eps, respec
         T2_USE(hd.z); T2_USE(step); T2_USE(rem); T2_USE(w1.x); T2_USE(w2.x); T2_USE(w3.x); T2_USE(ep.x);   // one batch, one wait
-        if (hd.y) break;
+        if (__builtin_amdgcn_readfirstlane(hd.y)) break;      // (wave-uniform values as scalars: the loop stays a scalar loop)
         T2_FP_TOP
-        const int blk = hd.x;
+        const int blk = __builtin_amdgcn_readfirstlane(hd.x);
         const double inv_step = __hiloint2double(hd.w, hd.z);
         if ((it & 1) == set) {
         // ======== this set's block: the final pass (on the chain) ========
@@ -423,7 +426,9 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
         {
             const double a = fabs(r) - 0.5;                   // > 0: the boundary crossed a sample; NaN: this lane cannot change
             const bool bad = (fabs(a) < 1e-7) || (a > 1.0);   // within 1e-7 samples of a sample / moved by two
-            const unsigned long long mb = __builtin_amdgcn_ballot_w64(bad);
+            // (a code rate at which 18 samples span half a chip or more - a code NCO driven percents off by a kHz-wide DLL
+            // on a channel without signal -: a group can meet two boundaries, every wave takes the direct path)
+            const unsigned long long mb = __builtin_amdgcn_ballot_w64(bad) | (step > step_max ? ~0ull : 0ull);
             unsigned long long me = 0;
             if (__builtin_expect(blk != cut, 0))              // (wave-uniform: all lanes were cut for the same length)
                 me = __builtin_amdgcn_ballot_w64((i0 < (blk > cut ? blk : cut)) && (i0 + 16 > (blk < cut ? blk : cut)));
@@ -655,12 +660,12 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
             __builtin_amdgcn_s_waitcnt(0xc07f);
             if (lane == 0) lds_poke(&S.rflag[0], it);
         }
-        if (hd.y) break;
+        if (__builtin_amdgcn_readfirstlane(hd.y)) break;
         T2_FP_TOP
         if (prof) t_top = (long long)__builtin_amdgcn_s_memtime();
         // ---- before the sums arrive ----
         // carrier phase at the end of this block (T5), exact remainder by FMA
-        const int blk = hd.x;
+        const int blk = __builtin_amdgcn_readfirstlane(hd.x);
         const int head_next = (int)((pos + blk) & 15);
         double rc;
         {
@@ -676,6 +681,7 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
         double cs_p, sn_p;
         t2_carr_entry(c_hi, c_lo, inv_2pi, w_cur, rc, mi, w3, cs_p, sn_p);
         T2_PIN(cs_p); T2_PIN(sn_p); T2_PIN(mf); T2_PIN(rc);   // (keeps all of this ahead of the wait)
+        __builtin_amdgcn_s_setprio(3);
         const unsigned long long* gp = xbase + (par * 6 + (lane >> 5)) * T3_XLINE + (lane & 31);
         const unsigned long long tag = (unsigned long long)((unsigned)(it + 1) & 0xFFFFu);
         unsigned long long x = 0;
@@ -705,7 +711,7 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
         q = dpp_addl_hmir(q, q);
         q = dpp_addl_mir(q, q);
         q = t3_addl_bc15(q);             // rows 1 and 3: the sums over lanes 0..31 / 32..63
-        const double v = (__longlong_as_double((long long)q) - T2_MAGIC) * unfix;
+        const double v = __longlong_as_double((long long)q) - T2_MAGIC;   // (in units of the fixed point: the discriminator is a ratio)
         const double I_P = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16),
                                             __builtin_amdgcn_readlane(__double2loint(v), 16));
         const double Q_P = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 48),
@@ -742,8 +748,8 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
         w_cur = w_new;
         remCarr = rc;
         r_cf = carrFreq;
-        r_ip = I_P * s2_blk;
-        r_qp = Q_P * s2_blk;
+        r_ip = I_P * (s2_blk * unfix);
+        r_qp = Q_P * (s2_blk * unfix);
         s2_blk = s2_next;
         r_err = carrError;
         r_nco = carrNco;
@@ -754,6 +760,8 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
         }
         T2STAMP(prof_on, 10);  // carrier tables
         T3_WB(wb_on);
+        __builtin_amdgcn_s_setprio(1);   // what follows until the next poll is off the chain: the final pass (2) issues first,
+                                         // the speculative pass (0) after it
         if (prof) acc_flt += (long long)__builtin_amdgcn_s_memtime() - t_arr;   // sums visible -> barrier released
         T2STAMP(prof_on, 11);
     }
@@ -884,6 +892,7 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
         const int lim1 = room > (long long)0x3FFFFFFF ? 0x3FFFFFFF : (room < 0 ? 0 : (int)room);
         unsigned lim = (unsigned)(lim1 < lim3 ? lim1 : lim3);
         T2_PIN(a_next); T2_PIN(lim);
+        __builtin_amdgcn_s_setprio(3);
         const unsigned long long* gp1 = xbase + (par * 6 + 2 + (lane >> 5)) * T3_XLINE + (lane & 31);
         const unsigned long long* gp2 = gp1 + 2 * T3_XLINE;
         const unsigned long long tag = (unsigned long long)((unsigned)(it + 1) & 0xFFFFu);
@@ -919,8 +928,8 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
         q2 = dpp_addl_mir(q2, q2);
         q1 = t3_addl_bc15(q1);
         q2 = t3_addl_bc15(q2);
-        const double ve = (__longlong_as_double((long long)q1) - T2_MAGIC) * unfix;   // row 1: I_E, row 3: Q_E
-        const double vl = (__longlong_as_double((long long)q2) - T2_MAGIC) * unfix;   // row 1: I_L, row 3: Q_L
+        const double ve = __longlong_as_double((long long)q1) - T2_MAGIC;   // row 1: I_E, row 3: Q_E (in units of the fixed
+        const double vl = __longlong_as_double((long long)q2) - T2_MAGIC;   // row 1: I_L, row 3: Q_L  point: the discriminator is a ratio)
         const double sqe = ve * ve, sql = vl * vl;
         const double e2 = sqe + dpp_bcast<0x143, 0xC>(sqe);  // row 3: I_E^2 + Q_E^2 (row_bcast:31: lane 31 to rows 2, 3)
         const double l2 = sql + dpp_bcast<0x143, 0xC>(sql);  // row 3: I_L^2 + Q_L^2
@@ -953,8 +962,8 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
         cf = cf_new;
         blk = blk_n;
         stop = stop_n;
-        r_ve = ve * s2_blk;
-        r_vl = vl * s2_blk;
+        r_ve = ve * (s2_blk * unfix);
+        r_vl = vl * (s2_blk * unfix);
         r_cf = cf_new;
         r_err = codeError;
         r_nco = codeNco;
@@ -967,6 +976,7 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
         }
         T2STAMP(prof_on, 14);  // next block's code parameters
         T3_WB(wb_on);
+        __builtin_amdgcn_s_setprio(1);
         T2STAMP(prof_on, 15);
     }
     if (owner && it > 0 && it == ms) {
