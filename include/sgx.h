@@ -98,8 +98,8 @@ typedef struct sgx_timing {
     float acq_fine_ms;       /* fine-frequency FFTs */
     float track_ms;          /* the tracking kernel */
     float synth_ms;          /* the generator kernel */
-    float track_kernel;      /* which tracking kernel the last sgx_track ran: 1 one-workgroup-per-channel / round-1
-                                cooperative, 2 latency-mode (sgx_trk2.hip), 3 throughput-mode, 4 low-rate */
+    float track_kernel;      /* which tracking kernel the last sgx_track ran: 2 latency-mode (sgx_trk2.hip), 3 throughput-mode
+                                (sgx_trk_tp.hip), 4 low-rate (sgx_trk_multi.hip), 5 speculative latency-mode (sgx_trk3.hip) */
     float track_members;     /* workgroups per channel of that launch */
     float track_streamed;    /* 1: the kernel followed the watermark of a record that was still streaming in */
 } sgx_timing;

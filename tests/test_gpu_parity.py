@@ -342,14 +342,16 @@ def test_full_length_tracking_locks_onto_the_scene(full_run):
 
 
 def test_split_variants_agree_on_the_full_run(full_run):
-    """The decompositions of the latency-mode kernel against the default (30 members per channel: one per unit and
-    correlator arm): one workgroup per channel owning all ten units, ten members of one unit with all three arms and the
-    placement-independent exchange path, three members owning four / three / three units, and the arm split switched
-    off.  Identical block boundaries, sums equal to rounding (different summation order only)."""
+    """The decompositions of the round-3 latency-mode kernel against the default (the speculative kernel, 20 members per
+    channel): 30 members per channel (one per unit and correlator arm), one workgroup per channel owning all ten units,
+    ten members of one unit with all three arms and the placement-independent exchange path, three members owning
+    four / three / three units, and the arm split switched off.  Identical block boundaries, sums equal to rounding
+    (different summation order only)."""
     m, s, ctx, sc, rec, a, chans, series, done = full_run
-    old = {k: os.environ.get(k) for k in ("SGX_TRK_SPLIT", "SGX_TRK_FASTX", "SGX_TRK_ARMS")}
+    assert ctx.timing()["track_kernel"] == 5 and ctx.timing()["track_members"] == 20      # (what full_run ran)
+    old = {k: os.environ.get(k) for k in ("SGX_TRK_SPLIT", "SGX_TRK_FASTX", "SGX_TRK_ARMS", "SGX_TRK_V3")}
     try:
-        for env, members in (({"SGX_TRK_SPLIT": "1"}, 1), ({"SGX_TRK_SPLIT": "10", "SGX_TRK_FASTX": "0"}, 10),
+        for env, members in (({"SGX_TRK_V3": "0"}, 30), ({"SGX_TRK_SPLIT": "1"}, 1), ({"SGX_TRK_SPLIT": "10", "SGX_TRK_FASTX": "0"}, 10),
                              ({"SGX_TRK_SPLIT": "3"}, 3), ({"SGX_TRK_ARMS": "3"}, 10)):
             os.environ.update(env)
             ms = 6000
@@ -416,16 +418,19 @@ def test_one_workgroup_per_channel_agrees_on_a_long_run(full_run):
     assert np.max(np.abs(s2[:, 1:3] - series[:, 1:3, :ms])) < 1e-6
 
 
-@pytest.mark.parametrize("layout", ["arms", "units"])
+@pytest.mark.parametrize("layout", ["spec", "arms", "units"])
 def test_a_withheld_member_aborts_the_channel_quickly(full_run, capfd, layout):
     """The launch really lacks one member per channel (SGX_TRK_TEST_WITHHOLD=1): the others must give the channel up
     within one poll budget - not spin block after block - and the host's repeat with one workgroup per channel must
-    deliver the usual results.  Both member layouts of the latency-mode kernel (30 per channel: unit x arm; 10: units)."""
+    deliver the usual results.  The speculative kernel (20 members per channel) and both member layouts of the round-3
+    latency-mode kernel (30 per channel: unit x arm; 10: units)."""
     import time
     m, s, ctx, sc, rec, a, chans, series, done = full_run
     os.environ["SGX_TRK_TEST_WITHHOLD"] = "1"
     if layout == "units":
         os.environ["SGX_TRK_ARMS"] = "3"
+    if layout == "arms":
+        os.environ["SGX_TRK_V3"] = "0"
     try:
         t0 = time.perf_counter()
         s2, d2 = ctx.track(rec, chans, 500)
@@ -433,13 +438,14 @@ def test_a_withheld_member_aborts_the_channel_quickly(full_run, capfd, layout):
     finally:
         os.environ.pop("SGX_TRK_TEST_WITHHOLD", None)
         os.environ.pop("SGX_TRK_ARMS", None)
+        os.environ.pop("SGX_TRK_V3", None)
     assert "repeating the launch with one workgroup per channel" in capfd.readouterr().err
     assert dt < 20.0, dt
     assert np.all(d2 == 500) and np.array_equal(s2[:, 0], series[:, 0, :500])
     assert _trk_err(s2, series[:, :, :500]) < 1e-9
 
 
-@pytest.mark.parametrize("layout", ["arms", "units", "one"])
+@pytest.mark.parametrize("layout", ["spec", "arms", "units", "one"])
 def test_a_block_beyond_the_units_of_the_launch_is_an_error_not_a_silent_truncation(layout):
     """A DLL bandwidth of 6 kHz on a channel without a signal drives the code NCO tens of kHz off: blocks become longer than
     the ten 4096-sample units of the launch.  Every member layout must say so (SGX_E_RANGE) instead of dropping the tail
@@ -450,6 +456,8 @@ def test_a_block_beyond_the_units_of_the_launch_is_an_error_not_a_silent_truncat
         os.environ["SGX_TRK_ARMS"] = "3"
     if layout == "one":
         os.environ["SGX_TRK_SPLIT"] = "1"
+    if layout == "arms":
+        os.environ["SGX_TRK_V3"] = "0"
     try:
         for bw, fits in ((2000.0, True), (6000.0, False)):
             s = m.Settings()
@@ -467,6 +475,7 @@ def test_a_block_beyond_the_units_of_the_launch_is_an_error_not_a_silent_truncat
     finally:
         os.environ.pop("SGX_TRK_ARMS", None)
         os.environ.pop("SGX_TRK_SPLIT", None)
+        os.environ.pop("SGX_TRK_V3", None)
 
 
 def test_second_front_end_golden():
@@ -983,7 +992,7 @@ def test_streaming_record_overlaps_tracking_with_identical_results(full_run, tmp
     path = str(tmp_path / "stream.bin")
     n_bytes = m.synth.record_length(s.samplesPerCode, 6000)
     rec.download(0, n_bytes).tofile(path)
-    for env in ({}, {"SGX_TRK_STREAM": "0"}, {"SGX_TRK_SPLIT": "1"}):
+    for env in ({}, {"SGX_TRK_STREAM": "0"}, {"SGX_TRK_V3": "0"}, {"SGX_TRK_SPLIT": "1"}):
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:
@@ -991,10 +1000,14 @@ def test_streaming_record_overlaps_tracking_with_identical_results(full_run, tmp
             s2, d2 = ctx.track(r, chans, 6000)           # starts while the file is still being read
             assert np.all(d2 == 6000) and np.array_equal(s2[:, 0], series[:, 0, :6000])
             tm = ctx.timing()
-            if "SGX_TRK_SPLIT" not in env:
+            if "SGX_TRK_V3" in env:
+                # the round-3 kernel (30 members per channel) following the watermark: another reduction order
+                assert tm["track_kernel"] == 2 and tm["track_members"] == 30 and tm["track_streamed"] == 1
+                assert _trk_err(s2, series[:, :, :6000]) < 1e-9
+            elif "SGX_TRK_SPLIT" not in env:
                 # the resident run's kernel (its record wave follows the watermark, or - SGX_TRK_STREAM=0 - the host
                 # waits for the whole record first): bit-identical
-                assert tm["track_kernel"] == 2 and tm["track_members"] == 30
+                assert tm["track_kernel"] == 5 and tm["track_members"] == 20
                 assert tm["track_streamed"] == (0 if env else 1)
                 assert np.array_equal(s2, series[:, :, :6000])
             else:
@@ -1360,7 +1373,8 @@ def test_track_uint8_record_against_the_oracle(tmp_path):
     ctx = m.engine.get_context(s, 0)
     rec = ctx.upload_bytes(recu)
     chans = [(int(ch["PRN"][i]), float(ch["acquiredFreq"][i]), float(ch["codePhase"][i])) for i in range(3)]
-    for env, members in (({}, 30), ({"SGX_TRK_SPLIT": "1"}, 1), ({"SGX_TRK_SPLIT": "3"}, 3), ({"SGX_TRK_ARMS": "3"}, 10)):
+    for env, members in (({}, 20), ({"SGX_TRK_V3": "0"}, 30), ({"SGX_TRK_SPLIT": "1"}, 1), ({"SGX_TRK_SPLIT": "3"}, 3),
+                         ({"SGX_TRK_ARMS": "3"}, 10)):
         os.environ.update(env)
         try:
             s2, d2 = ctx.track(rec, chans, ms, data_type=m._native.DT_UINT8)
