@@ -57,8 +57,6 @@ struct __attribute__((aligned(128))) T3Code {   // code side of a block's parame
     double pad0;
     // early part: posted right after the barrier that starts the PREVIOUS block
     double start[3];        // ramp starts E, P, L (exact; T3)
-    int blk_pred;           // the block's length if its code rate were the previous block's
-    int eflag;              // block number + 1 once the early part is valid
     long long pos;          // record index of the block's first sample
     // exact part: posted right after the barrier that starts the block (the direct path reads it)
     double stp[3];          // linspace steps E, P, L (tracking.py:166-188)
@@ -383,6 +381,7 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
     {
         // set 0 owns the even blocks: block 0's pass runs here; set 1 requests the bytes of block 1
         const T3Code& C0 = S.code[0];
+        T2_FP_TOP
         if (set == 0) {
             nraw = t2_load<SB>(rec, (pos0 & ~15ll) + lane_off, limit);
             spec(nraw, pos0, C0.start[1], C0.step, C0.inv_step, C0.blk, S.carr[0], pos0 + 2ll * C0.blk);
@@ -874,18 +873,8 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
         if (lane < 3) N.start[lane] = rem_next + off;
         if (lane == 0) N.pos = pos_next;
         double a_next = D.code_len - rem_next;                                      // (1023 - rem) of T1
-        {
-            // the next block's length if the code rate stayed (the speculative pass cuts its samples there; the true
-            // length differs in ~2 % of the blocks, and then by one sample)
-            double sa_, is_;
-            const int bp = sgx_block_length(a_next, cf, D.fs, D.inv_fs, sa_, is_);
-            if (lane == 0) N.blk_pred = bp;
-        }
         __builtin_amdgcn_s_waitcnt(0xc07f);
-        if (lane == 0) {
-            lds_poke(&N.eflag, it + 2);
-            lds_poke(&C.xflag, it + 1);
-        }
+        if (lane == 0) lds_poke(&C.xflag, it + 1);
         // the longest next block the record (stop 1 beyond it) and the units of the launch (stop 3) hold: ONE compare on
         // the chain, which of the two it was is sorted out in the (rare) branch
         const long long room = D.rec_len - pos_next;
@@ -1081,8 +1070,6 @@ __global__ __launch_bounds__(T3_THREADS) void trk3_kernel(const int8_t* __restri
     if (tid < 16) S.acc[tid >> 3][tid & 7] = 0ull;
     if (tid < 2) {
         S.code[tid].xflag = 0;
-        S.code[tid].eflag = 0;
-        S.code[tid].blk_pred = 0;
         S.carr[tid].eps = 0.0;
         S.carr[tid].respec = 0.0;
     }
