@@ -87,10 +87,11 @@ def launch_ranks(n, argv):
                          % (n, have, n))
         return 3
     port = _free_port()
+    token = os.urandom(16).hex()   # the ranks' rendezvous admits only holders of it (softgnss-python_amd/rendezvous.py)
     procs = []
     for r in range(n):
         env = dict(os.environ)
-        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), SGX_DEVICE=str(r), MASTER_ADDR="127.0.0.1",
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), SGX_DEVICE=str(r), MASTER_ADDR="127.0.0.1", SGX_RDV_TOKEN=token,
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))

@@ -183,6 +183,73 @@ def _stub_env():
     return env
 
 
+def _rdv_rank0(key, q):
+    import importlib
+    rv = importlib.import_module("softgnss-python_amd.rendezvous")
+    os.environ["SGX_RDV_TOKEN"] = "sesame"
+    g = rv.HostGroup(0, 2, key=key, timeout=60)
+    q.put(g.gather({"r": 0, "blob": b"\x00\xff"}))
+    g.close()
+
+
+def test_socket_rendezvous_admits_only_its_own_ranks():
+    """Rank 0 listens in the abstract AF_UNIX name space, which has no file permissions: a connection that sends
+    something that is not the hello (a pickle, say), one without the launcher's token, one that claims a rank outside
+    1 .. world-1 are all dropped; the real rank 1 then completes the group.  Nothing is ever unpickled."""
+    import importlib
+    import json
+    import multiprocessing as mp
+    import pickle
+    import socket
+    import struct
+    import time
+    rv = importlib.import_module("softgnss-python_amd.rendezvous")
+    key = "t%d" % os.getpid()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p0 = ctx.Process(target=_rdv_rank0, args=(key, q))
+    p0.start()
+    addr = "\0sgx-rendezvous-%s-%s" % (key, os.environ.get("TORCHELASTIC_RUN_ID", "x"))
+
+    def rogue(payload):
+        deadline = time.time() + 60
+        while True:
+            c = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+            try:
+                c.connect(addr)
+                break
+            except (ConnectionRefusedError, FileNotFoundError):
+                c.close()
+                assert time.time() < deadline
+                time.sleep(0.05)
+        c.sendall(struct.pack("<Q", len(payload)) + payload)
+        c.settimeout(10)
+        try:
+            assert c.recv(1) == b""          # dropped: the server closes the connection
+        except (ConnectionError, socket.timeout):
+            pass
+        c.close()
+
+    class Boom(object):
+        def __reduce__(self):
+            return (os.system, ("touch /tmp/sgx_rdv_pwned_%d" % os.getpid(),))
+
+    rogue(pickle.dumps(Boom()))
+    rogue(json.dumps({"rank": 1, "token": "guess"}).encode())
+    rogue(json.dumps({"rank": 7, "token": "sesame"}).encode())
+    assert not os.path.exists("/tmp/sgx_rdv_pwned_%d" % os.getpid())
+    os.environ["SGX_RDV_TOKEN"] = "sesame"
+    try:
+        g = rv.HostGroup(1, 2, key=key, timeout=60)
+        got = g.gather({"r": 1, "blob": b"abc"})
+        g.close()
+    finally:
+        os.environ.pop("SGX_RDV_TOKEN", None)
+    assert got == [{"r": 0, "blob": b"\x00\xff"}, {"r": 1, "blob": b"abc"}] and q.get(timeout=60) == got
+    p0.join(60)
+    assert p0.exitcode == 0
+
+
 def test_bench_two_ranks_end_to_end_against_a_stand_in_package():
     """`bench.py --gpus 2` from the self-launch to the JSON line, with tests/bench_stub.py answering for the GPU
     package: two ranks rendezvous, search 16 PRNs each, the RCCL transport is refused (the stand-in has none) so
