@@ -454,6 +454,23 @@ def main():
             dev_one = ctx.timing()["acquire_ms"]
             same = bool(np.array_equal(a1.codePhase, a4.codePhase) and np.array_equal(a1.carrFreq, a4.carrFreq) and
                         np.array_equal(a1.internals["freqBin"], a4.internals["freqBin"]))
+            emu = None
+            if world == 1:
+                # what the slowest rank of an 8-GPU run executes, timed on THIS GPU: each 4-PRN shard alone (device
+                # time of the whole sgx_acquire call, best of three), the slowest of the eight; no gather in it
+                worst = 0.0
+                for rk in range(8):
+                    prns = list(shard.plan_shards(32, 8)[rk])
+                    ae = pkg.AcquisitionResult(s, device=local)
+                    ae.acquire(sig4, n_blocks=10, noncoh=True, prn_indices=prns)
+                    ts = []
+                    for _ in range(3):
+                        ae.acquire(sig4, n_blocks=10, noncoh=True, prn_indices=prns)
+                        ts.append(ctx.timing()["acquire_ms"])
+                    worst = max(worst, min(ts))
+                emu = {"emulated_8rank_ms": worst, "emulated_speedup": dev_one / worst,
+                       "emulated_note": "device time of the slowest 4-PRN shard of an 8-rank run, timed on this one GPU, against "
+                                        "device_ms_n1; the ncclAllGather of 160 bytes per rank is not in it"}
             cfg4 = {"workload": "configs[3]: 32 PRNs x 10 ms non-coherent, %d PRN/GPU, peaks all-gathered (%s)"
                                 % (len(shard.plan_shards(32, world)[0]), gather.name),
                     "ms": t_sharded, "ms_n1": t_one, "speedup_vs_n1": t_one / t_sharded,
@@ -461,6 +478,8 @@ def main():
                     "sharded_result_equals_single_gpu": same,
                     "note": "wall time per search incl. host glue and the gather, max over ranks; ms_n1 = the whole "
                             "search on rank 0's GPU in the same run"}
+            if emu:
+                cfg4.update(emu)
         barrier()
 
     # ---- accounting ----------------------------------------------------------------------------
@@ -477,7 +496,9 @@ def main():
 
     if rank == 0:
         traffic = pmc_file("_pmc_trk_kernel.json", {"channels": args.channels, "ms": args.ms})
-        prof_avg = trace_avg_ms("trk2_kernel") if (args.channels, args.ms) == (8, 37000) else None
+        tk = ctx.timing()
+        trk_name = {2: "trk2_kernel", 3: "trk_kernel_tp", 4: "trk_kernel_multi", 5: "trk3_kernel"}.get(tk["track_kernel"], "trk2_kernel")
+        prof_avg = trace_avg_ms(trk_name) if (args.channels, args.ms) == (8, 37000) else None
         read_gbs, copy_gbs = ctx.stream_rates(1 << 30, 5)
         out = {
             "metric": "IF Msamples/s through acquisition + tracking (x real-time = value / 38.192)",
@@ -496,7 +517,7 @@ def main():
             "per_rank": {k: {"min": min(r[k] for r in per_rank), "max": max(r[k] for r in per_rank)}
                          for k in ("step_ms", "track_kernel_ms", "acquire_ms")},
             "per_rank_peak_gather": sorted(set(r["peak_gather"] for r in per_rank)),
-            "roofline": {"kernel": "trk2_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"kernel": trk_name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic[0]["hbm_bytes_per_launch"] if traffic else None,
                          "traffic_source": (traffic[1] + " (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes of this "
@@ -506,8 +527,10 @@ def main():
                          "kernel_avg_ms_profile_source": prof_avg[1] if prof_avg else None,
                          "measured_stream_read_gbs": read_gbs, "measured_stream_copy_gbs": copy_gbs,
                          "frac_of_measured_read": achieved / read_gbs,
-                         "note": "37 000 dependent steps per channel; 8 channels x 10 units x 3 correlator arms = 240 of "
-                                 "256 CUs busy, each on a latency-bound chain: not bandwidth-bound (DESIGN.md section 4.1)"},
+                         "workgroups_per_channel": tk["track_members"],
+                         "note": "37 000 dependent steps per channel; %d channels x %d workgroups on as many of the 256 CUs, "
+                                 "each on a latency-bound chain (final pass -> exchange -> loop filter): not bandwidth-bound "
+                                 "(DESIGN.md section 4.1)" % (args.channels, tk["track_members"])},
         }
         if cfg4 is not None:
             out["acq_config4"] = cfg4

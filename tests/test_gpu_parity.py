@@ -397,6 +397,35 @@ def test_many_channels_throughput_mode(full_run):
     assert _trk_err(s2[:8], series[:, :, :ms]) < 1e-9
 
 
+def test_many_channels_at_staggered_offsets_against_the_oracle(full_run):
+    """The shape the many-channel bench leg runs: throughput-mode channels (one workgroup per channel, trk_kernel_tp)
+    that start at DIFFERENT places of the record.  256 channels = 32 groups of the 8 acquired inits, group j started j
+    code periods (j x 38 192 samples) behind the acquired code phase - the code drifts by at most 0.1 chip in 31 ms, so
+    every replica pulls in - and eight of them, one per PRN and each at another offset, are compared with the oracle
+    itself: block boundaries identical, sums to 1e-9."""
+    from concurrent.futures import ProcessPoolExecutor
+    from oracle_helpers import oracle_channel
+    m, s, ctx, sc, rec, a, chans, series, done = full_run
+    n = s.samplesPerCode
+    ms = 300
+    many = [(chans[i % 8][0], chans[i % 8][1], chans[i % 8][2] + (i // 8) * n) for i in range(256)]
+    s2, d2 = ctx.track(rec, many, ms)
+    tm = ctx.timing()
+    assert tm["track_kernel"] == 3 and tm["track_members"] == 1 and np.all(d2 == ms)
+    picks = [8 * (4 * j + 1) + j for j in range(8)]          # PRN j of group 4 j + 1: offsets 1, 5, .. 29 code periods
+    assert len({many[i][2] - chans[i % 8][2] for i in picks}) == 8 and sorted(i % 8 for i in picks) == list(range(8))
+    host = rec.download(0, (32 + ms + 3) * n)
+    with ProcessPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        want = np.stack(list(ex.map(oracle_channel, [(host,) + many[i] + (ms,) for i in picks])))
+    got = s2[picks]
+    assert np.array_equal(got[:, 0], want[:, 0])
+    assert _trk_err(got, want) < 1e-9
+    assert np.max(np.abs(got[:, 1] - want[:, 1])) < 1e-6 and np.max(np.abs(got[:, 2] - want[:, 2])) < 1e-5
+    # a start shifted by whole code periods sees the same signal a few periods later: locked like the unshifted replica
+    for i in picks:
+        assert np.mean(np.abs(got[picks.index(i), 3, 100:])) > 8 * np.mean(np.abs(got[picks.index(i), 7, 100:]))
+
+
 def test_one_workgroup_per_channel_agrees_on_a_long_run(full_run):
     """One workgroup per channel (every member-to-member exchange degenerate, all units in one map) against the default
     30-member launch over a long run including the pull-in transient: identical block boundaries, sums equal to
@@ -1044,10 +1073,8 @@ def test_streaming_record_overlaps_tracking_with_identical_results(full_run, tmp
 def test_full_config3_run_against_the_oracle(full_run):
     """BASELINE config 3 at its full size against the oracle itself (not only through properties): 8 channels x
     37 000 ms = 296 000 dependent blocks; the numpy restatement runs in eight host processes (about 40 s)."""
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     from concurrent.futures import ProcessPoolExecutor
-    from full_parity import oracle_channel
+    from oracle_helpers import oracle_channel
     m, s, ctx, sc, rec, a, chans, series, done = full_run
     host = rec.download()
     with ProcessPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:

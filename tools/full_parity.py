@@ -6,14 +6,8 @@ from concurrent.futures import ProcessPoolExecutor
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import softgnss_oracle as orc   # checker only
-
-
-def oracle_channel(args):
-    host, prn, freq, phase, ms = args
-    so = orc.OracleSettings(numberOfChannels=1, msToProcess=float(ms))
-    ch = dict(PRN=np.array([prn]), acquiredFreq=np.array([freq]), codePhase=np.array([phase]), status=np.array(['T']))
-    return orc.stack_series(orc.track(so, ch, host))[0]
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle_helpers import oracle_channel   # (the tests' helper; tests never import from tools/)
 
 
 def random_scene(m, seed):

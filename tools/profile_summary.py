@@ -63,9 +63,12 @@ def main():
         ks = [k for k in d if prefix in k]          # (template instances are named "void name<...>(...)")
         return max(max(d[k]) for k in ks) * 1024.0 if ks else None
 
-    f_trk, w_trk = big(fetch, "trk2_kernel"), big(write, "trk2_kernel")
+    # the headline launch's kernel: the speculative latency-mode kernel (trk3_kernel) where it applies, else trk2_kernel
+    trk = "trk3_kernel" if any("trk3_kernel" in k for k in fetch) else "trk2_kernel"
+    occupied = 160.0 if trk == "trk3_kernel" else 240.0
+    f_trk, w_trk = big(fetch, trk), big(write, trk)
     if f_trk is not None:
-        rec = {"kernel": "trk2_kernel", "fetch_size_raw_bytes_per_launch": f_trk,
+        rec = {"kernel": trk, "fetch_size_raw_bytes_per_launch": f_trk,
                "write_size_raw_bytes_per_launch": w_trk, "correction": corr,
                "hbm_bytes_per_launch": 2.0 * f_trk + w_trk,
                "note": "the 13 series per block go straight to pinned host memory and are not HBM writes",
@@ -74,13 +77,14 @@ def main():
         if vdb and gdb:
             def largest(db, counter):
                 d = by_kernel(per_dispatch(db, counter))
-                ks = [k for k in d if "trk2_kernel" in k]
+                ks = [k for k in d if trk in k]
                 return max(max(d[k]) for k in ks) if ks else None
             insts, act, gui = largest(vdb, "SQ_INSTS_VALU"), largest(vdb, "SQ_ACTIVE_INST_VALU"), largest(gdb, "GRBM_GUI_ACTIVE")
             if insts and act and gui:
                 rec["valu_insts_per_sample"] = insts * 64.0 / (8 * 37000 * 38192.0)
                 rec["valu_busy_frac_chip"] = act * 4.0 / 1024.0 / (gui / 8.0)
-                rec["valu_busy_frac_on_the_240_occupied_cus"] = rec["valu_busy_frac_chip"] * 256.0 / 240.0
+                rec["occupied_cus"] = occupied
+                rec["valu_busy_frac_on_the_occupied_cus"] = rec["valu_busy_frac_chip"] * 256.0 / occupied
                 rec["valu_formula"] = ("SQ_INSTS_VALU * 64 lanes / (8 channels * 37000 ms * 38192 samples); SQ_ACTIVE_INST_VALU * 4 / "
                                        "1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs)")
         with open(os.path.join(dst, "%s_pmc_trk_kernel.json" % tag), "w") as f:
