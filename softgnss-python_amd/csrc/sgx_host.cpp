@@ -211,6 +211,9 @@ extern "C" int sgx_ctx_destroy(sgx_ctx* c) {
     hipFree(c->d_small);
     hipFree(c->d_trk_out);
     hipFree(c->d_trk_aux);
+    if (c->spare_d) hipFree(c->spare_d);
+    if (c->spare_mark) hipFree(c->spare_mark);
+    if (c->spare_copy_stream) hipStreamDestroy(c->spare_copy_stream);
     if (c->h_small) hipHostFree(c->h_small);
     if (c->h_look) hipHostFree(c->h_look);
     for (int i = 0; i < 6; ++i)
@@ -257,7 +260,21 @@ static int if_alloc(sgx_ctx* c, size_t n, sgx_if** out) {
     sgx_if* r = new sgx_if();
     r->n = n;
     r->device = c->device;
-    hipError_t e = hipMalloc((void**)&r->d, n + SGX_IF_PAD);
+    hipError_t e = hipSuccess;
+    {
+        // the allocation the last freed record left behind, when it is large enough (and not absurdly larger)
+        std::lock_guard<std::mutex> g(c->spare_mu);
+        if (c->spare_d && c->spare_cap >= n + SGX_IF_PAD && c->spare_cap <= 2 * (n + SGX_IF_PAD) + (1u << 20)) {
+            r->d = c->spare_d;
+            r->cap = c->spare_cap;
+            c->spare_d = nullptr;
+            c->spare_cap = 0;
+        }
+    }
+    if (!r->d) {
+        e = hipMalloc((void**)&r->d, n + SGX_IF_PAD);
+        r->cap = n + SGX_IF_PAD;
+    }
     if (e != hipSuccess) {
         delete r;
         sgx_set_error("hipMalloc(%zu) for an IF record failed: %s", n + SGX_IF_PAD, hipGetErrorString(e));
@@ -555,14 +572,26 @@ extern "C" int sgx_if_open_file(sgx_ctx* c, const char* path, uint64_t file_offs
         const char* pe = getenv("SGX_STREAM_PRIO");   // test hook: "0" = a normal-priority copy stream
         if (pe && pe[0] == '0') hi = 0;
         if (c->priority < 0) hi = 0;   // the context itself runs at the highest priority: copies go one level below
-        if (e == hipSuccess) e = hipStreamCreateWithPriority(&r->copy_stream, hipStreamNonBlocking, hi);
+        {
+            std::lock_guard<std::mutex> g(c->spare_mu);
+            if (c->spare_copy_stream && !(pe && pe[0] == '0')) {
+                r->copy_stream = c->spare_copy_stream;
+                c->spare_copy_stream = nullptr;
+            }
+            if (c->spare_mark) {
+                r->d_mark = c->spare_mark;
+                c->spare_mark = nullptr;
+            }
+        }
+        if (e == hipSuccess && !r->copy_stream) e = hipStreamCreateWithPriority(&r->copy_stream, hipStreamNonBlocking, hi);
         if (e != hipSuccess) {   // no stream priorities here: an ordinary stream (the kernel's bounded wait covers it)
             (void)hipGetLastError();
             e = hipStreamCreateWithFlags(&r->copy_stream, hipStreamNonBlocking);
         }
     }
-    if (e == hipSuccess) e = hipMalloc((void**)&r->d_mark, 256);
-    if (e == hipSuccess) e = hipMemset(r->d_mark, 0, 256);
+    if (e == hipSuccess && !r->d_mark) e = hipMalloc((void**)&r->d_mark, 256);
+    if (e == hipSuccess) e = hipMemsetAsync(r->d_mark, 0, 256, r->copy_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(r->copy_stream);
     if (e != hipSuccess) {
         close(fd);
         sgx_if_free(c, r);
@@ -649,9 +678,28 @@ extern "C" int sgx_if_free(sgx_ctx* c, sgx_if* r) {
         hipSetDevice(c->device);
         hipStreamSynchronize(c->stream);
     }
+    if (r->copy_stream) hipStreamSynchronize(r->copy_stream);
+    if (c) {
+        // keep ONE allocation (the larger), watermark and copy stream for the next record of this context
+        std::lock_guard<std::mutex> g(c->spare_mu);
+        if (r->d && r->cap > c->spare_cap) {
+            if (c->spare_d) hipFree(c->spare_d);
+            c->spare_d = r->d;
+            c->spare_cap = r->cap;
+            r->d = nullptr;
+        }
+        if (r->d_mark && !c->spare_mark) {
+            c->spare_mark = r->d_mark;
+            r->d_mark = nullptr;
+        }
+        if (r->copy_stream && !c->spare_copy_stream && !getenv("SGX_STREAM_PRIO")) {
+            c->spare_copy_stream = r->copy_stream;
+            r->copy_stream = nullptr;
+        }
+    }
     if (r->copy_stream) hipStreamDestroy(r->copy_stream);
     if (r->d_mark) hipFree(r->d_mark);
-    hipFree(r->d);
+    if (r->d) hipFree(r->d);
     delete r;
     return SGX_OK;
 }

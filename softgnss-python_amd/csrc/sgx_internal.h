@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -57,6 +58,7 @@ struct FftPlan {
 struct sgx_if {
     int8_t* d = nullptr;   // device pointer; allocation is padded by SGX_IF_PAD zero bytes
     size_t n = 0;
+    size_t cap = 0;        // bytes of the allocation behind d (>= n + SGX_IF_PAD)
     int device = 0;
     // background file -> HBM streaming (sgx_if_open_file): samples [0, host_mark) are resident
     std::thread* loader = nullptr;
@@ -104,6 +106,14 @@ struct sgx_ctx {
     double* d_trk_out = nullptr;
     size_t trk_out_elems = 0;
     void* d_trk_aux = nullptr;   // per-call device state of sgx_track (channels, done, exchange, err, profile)
+    // One record allocation, streaming watermark and copy stream kept from the last sgx_if_free: a caller that opens a
+    // record file per step (the reference's, initialize.py:466-506) would otherwise pay hipMalloc + hipFree of 1.4 GB and
+    // a stream creation every time (milliseconds against a 50 ms step).
+    int8_t* spare_d = nullptr;
+    size_t spare_cap = 0;
+    unsigned long long* spare_mark = nullptr;
+    hipStream_t spare_copy_stream = nullptr;
+    std::mutex spare_mu;
     size_t trk_aux_cap = 0;
     // pinned staging buffers of the file streamer, kept between calls (pinning 64 MiB costs ~15 ms)
     void* stage[2] = {nullptr, nullptr};

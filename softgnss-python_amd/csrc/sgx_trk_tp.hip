@@ -236,7 +236,9 @@ __global__ __launch_bounds__(TP_THREADS, TP_OCC) void trk_kernel_tp(const int8_t
     __shared__ double s_red[6][TP_THREADS];
     __shared__ double s_tot[6];
     __shared__ TrkState s_st;
-    __shared__ double s_rec[2][16];        // the record of a block, [block parity][series]
+    __shared__ double s_rec[16][16];       // the records of the last sixteen blocks, [block & 15][series]: stored eight blocks
+                                           // at a time, 64 contiguous bytes per series row (one 8-byte store per row and
+                                           // block made 5.2 bytes of memory traffic per byte of series)
 
     const int ch = blockIdx.x;
     if (ch >= K.n_ch) return;
@@ -482,7 +484,7 @@ __global__ __launch_bounds__(TP_THREADS, TP_OCC) void trk_kernel_tp(const int8_t
                 s_st.oldCarrNco = carrNco;
                 s_st.oldCarrErr = carrError;
                 s_st.carrFreq = carrFreq;
-                double* __restrict__ r = s_rec[it & 1];   // T9 record (tracking.py:255-275): stored by wave 3, a block later
+                double* __restrict__ r = s_rec[it & 15];  // T9 record (tracking.py:255-275): stored by wave 3, up to eight blocks later
                 r[2] = carrFreq;
                 r[3] = I_P;
                 r[4] = s_tot[0];
@@ -508,7 +510,7 @@ __global__ __launch_bounds__(TP_THREADS, TP_OCC) void trk_kernel_tp(const int8_t
                 s_st.oldCodeNco = codeNco;
                 s_st.oldCodeErr = codeError;
                 s_st.codeFreq = codeFreq;
-                double* __restrict__ r = s_rec[it & 1];
+                double* __restrict__ r = s_rec[it & 15];
                 r[0] = (double)(pos_after + K.file_off);
                 r[1] = codeFreq;
                 r[9] = codeError;
@@ -516,10 +518,15 @@ __global__ __launch_bounds__(TP_THREADS, TP_OCC) void trk_kernel_tp(const int8_t
             }
             if (more) prep_code(K, codeFreq, rem_next, pos_after, s_st, s_blk, lane == 0);
         } else if (wave == TP_THREADS / 64 - 1) {
-            // the previous block's record: written to LDS by the filter waves a block ago, stored by this wave while it
-            // has nothing else to do (on the filter waves the thirteen stores and their addresses were 800 cycles of
-            // the block's critical path)
-            if (it > 0 && lane < SGX_NUM_SERIES) o[lane * m + (it - 1)] = s_rec[(it - 1) & 1][lane];
+            // the records of the eight blocks before this one: written to LDS by the filter waves, stored by this wave
+            // while it has nothing else to do - lane = 8 row + j stores block it - 8 + j of series row `row`, so the eight
+            // lanes of a row write 64 contiguous bytes (on the filter waves the thirteen stores and their addresses were
+            // 800 cycles of the block's critical path)
+            if (it > 0 && (it & 7) == 0) {
+                const int j = lane & 7, k = it - 8 + j;
+                o[(lane >> 3) * m + k] = s_rec[k & 15][lane >> 3];
+                if (lane < 8 * (SGX_NUM_SERIES - 8)) o[(8 + (lane >> 3)) * m + k] = s_rec[k & 15][8 + (lane >> 3)];
+            }
         }
         done = it + 1;
         TP_STAMP(5)
@@ -541,8 +548,11 @@ __global__ __launch_bounds__(TP_THREADS, TP_OCC) void trk_kernel_tp(const int8_t
         printf("[tp prof] ch %d wave %d cycles/block: top %lld loop %lld red-barrier %lld fold %lld filter %lld end-barrier %lld\n",
                ch, wave, tp_acc[0] / done, tp_acc[1] / done, tp_acc[2] / done, tp_acc[3] / done, tp_acc[4] / done, tp_acc[5] / done);
 #endif
-    // the last block's record (the loop's final barrier has made it visible)
-    if (done > 0 && tid < SGX_NUM_SERIES) o[tid * m + (done - 1)] = s_rec[(done - 1) & 1][tid];
+    // the records not stored yet: blocks 8 floor((done - 1) / 8) .. done - 1 (the loop's final barrier has made them visible)
+    if (done > 0 && tid < 8 * SGX_NUM_SERIES) {
+        const int k = ((done - 1) & ~7) + (tid & 7);
+        if (k < done) o[(tid >> 3) * m + k] = s_rec[k & 15][tid >> 3];
+    }
     if (tid == 0) ms_done[ch] = done;
 }
 
