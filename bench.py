@@ -497,7 +497,7 @@ def main():
     if rank == 0:
         traffic = pmc_file("_pmc_trk_kernel.json", {"channels": args.channels, "ms": args.ms})
         tk = ctx.timing()
-        trk_name = {2: "trk2_kernel", 3: "trk_kernel_tp", 4: "trk_kernel_multi", 5: "trk3_kernel"}.get(tk["track_kernel"], "trk2_kernel")
+        trk_name = {2: "trk2_kernel", 3: "trk_kernel_tp", 4: "trk_kernel_multi", 5: "trk3_kernel"}.get(tk.get("track_kernel"), "trk2_kernel")
         prof_avg = trace_avg_ms(trk_name) if (args.channels, args.ms) == (8, 37000) else None
         read_gbs, copy_gbs = ctx.stream_rates(1 << 30, 5)
         out = {
@@ -527,10 +527,10 @@ def main():
                          "kernel_avg_ms_profile_source": prof_avg[1] if prof_avg else None,
                          "measured_stream_read_gbs": read_gbs, "measured_stream_copy_gbs": copy_gbs,
                          "frac_of_measured_read": achieved / read_gbs,
-                         "workgroups_per_channel": tk["track_members"],
+                         "workgroups_per_channel": tk.get("track_members"),
                          "note": "37 000 dependent steps per channel; %d channels x %d workgroups on as many of the 256 CUs, "
                                  "each on a latency-bound chain (final pass -> exchange -> loop filter): not bandwidth-bound "
-                                 "(DESIGN.md section 4.1)" % (args.channels, tk["track_members"])},
+                                 "(DESIGN.md section 4.1)" % (args.channels, tk.get("track_members", 0))},
         }
         if cfg4 is not None:
             out["acq_config4"] = cfg4

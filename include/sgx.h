@@ -283,6 +283,24 @@ int sgx_cart2geo(double X, double Y, double Z, int32_t i, double* phi, double* l
 int sgx_find_utm_zone(double latitude, double longitude, int32_t* utmZone);                          /* :529-571 */
 int sgx_cart2utm(double X, double Y, double Z, int32_t zone, double* E, double* N, double* U);      /* :176-372 */
 
+/* The measurement-epoch loop of NavigationResult.postNavigate (postNavigation.py:150-290): for epoch m = 0 .. n_meas-1
+ * the channels in use are those of `ready` whose elevation at the previous solved epoch was >= elevationMask (all of
+ * `ready` at first); pseudoranges at millisecond subFrameStart[ch] + navSolPeriod m (sgx_pseudoranges), satellite
+ * positions at transmitTime = tow + m navSolPeriod / 1000 (sgx_satpos), and with more than three channels the
+ * least-squares fix, geodetic and UTM coordinates (sgx_least_square_pos, sgx_cart2geo, sgx_find_utm_zone,
+ * sgx_cart2utm); otherwise the epoch is flagged in not_enough[m] and its fix is NaN, as the reference leaves it.
+ * absoluteSample is [n_rows][ms] and prn_of_row [n_rows] (results row k serves channel k, as in the reference).
+ * Outputs, prefilled here as the reference prefills them: chan_PRN (zeros) and chan_el / chan_az / chan_rawP /
+ * chan_correctedP (NaN) are [numberOfChannels][64]; DOP [5][64] zeros; X Y Z dt latitude longitude height E N U
+ * [64] NaN each, in this order in `sol` ([10][64]); *utmZone the zone of the last solved epoch.  n_meas > 64 is the
+ * reference's IndexError (SGX_E_RANGE).  Host code. */
+int sgx_post_navigate(const double* absoluteSample, int32_t n_rows, int32_t ms, const int32_t* prn_of_row,
+                      const double* subFrameStart, const int32_t* ready, int32_t n_ready, int32_t numberOfChannels,
+                      const double* eph, int64_t tow, int64_t samplesPerCode, double startOffset, double c_mps,
+                      double navSolPeriod, double elevationMask, int32_t useTropCorr, int32_t n_meas,
+                      double* chan_PRN, double* chan_el, double* chan_az, double* chan_rawP, double* chan_correctedP,
+                      double* DOP, double* sol, int32_t* utmZone, int32_t* not_enough);
+
 /* ---- RCCL peak gather (multi-GPU acquisition shard) ------------------
  * (SURVEY.md section 8(b) sketched single-process sgx_group_* entry points - one host thread driving every device
  * through ncclCommInitAll.  The build runs ONE PROCESS PER GPU instead, as the bench contract launches it, so the

@@ -108,6 +108,9 @@ _PROTOS = {
     "sgx_pseudoranges": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int64, C.c_double,
                                    C.c_double, _P]),
     "sgx_nav_bits": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.POINTER(C.c_int32)]),
+    "sgx_post_navigate": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, C.c_int32, _P, C.c_int64, C.c_int64,
+                                    C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int32,
+                                    _P, _P, _P, _P, _P, _P, _P, C.POINTER(C.c_int32), _P]),
     "sgx_comm_unique_id": (C.c_int, [_P]),
     "sgx_comm_create": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.POINTER(_P)]),
     "sgx_comm_allgather": (C.c_int, [_P, _P, _P, C.c_size_t]),

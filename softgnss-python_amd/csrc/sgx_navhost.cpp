@@ -249,3 +249,106 @@ int sgx_nav_select(const double* I_P, const short* corr, int32_t n_ch, int32_t m
     }
     return SGX_OK;
 }
+
+// ---- postNavigation.py:150-290: the loop over measurement epochs ------------------------------------------------------
+extern "C" int sgx_post_navigate(const double* absoluteSample, int32_t n_rows, int32_t ms, const int32_t* prn_of_row,
+                                 const double* subFrameStart, const int32_t* ready, int32_t n_ready,
+                                 int32_t numberOfChannels, const double* eph, int64_t tow, int64_t samplesPerCode,
+                                 double startOffset, double c_mps, double navSolPeriod, double elevationMask,
+                                 int32_t useTropCorr, int32_t n_meas, double* chan_PRN, double* chan_el, double* chan_az,
+                                 double* chan_rawP, double* chan_correctedP, double* DOP, double* sol, int32_t* utmZone,
+                                 int32_t* not_enough) {
+    SGX_CHECK_ARG(absoluteSample && prn_of_row && subFrameStart && (ready || n_ready == 0) && eph && chan_PRN && chan_el &&
+                  chan_az && chan_rawP && chan_correctedP && DOP && sol && utmZone && not_enough);
+    SGX_CHECK_ARG(n_rows >= 0 && ms >= 1 && n_ready >= 0 && numberOfChannels >= 1 && numberOfChannels <= 4096 && n_meas >= 0);
+    const int nch = numberOfChannels, W = 64;
+    if (n_meas > W) {
+        sgx_set_error("IndexError: index %d is out of bounds for axis 1 with size %d (measurement epochs)", W, W);
+        return SGX_E_RANGE;
+    }
+    for (int i = 0; i < nch * W; ++i) {
+        chan_PRN[i] = 0.0;
+        chan_el[i] = chan_az[i] = chan_rawP[i] = chan_correctedP[i] = NAN;
+    }
+    for (int i = 0; i < 5 * W; ++i) DOP[i] = 0.0;
+    for (int i = 0; i < 10 * W; ++i) sol[i] = NAN;
+    for (int i = 0; i < W; ++i) not_enough[i] = 0;
+    *utmZone = 0;
+    std::vector<double> satElev((size_t)nch, INFINITY), when((size_t)nch), raw((size_t)nch);
+    std::vector<int32_t> active, prns;
+    std::vector<double> satPositions, satClk, obs, el, az;
+    double transmitTime = (double)tow;
+    for (int m = 0; m < n_meas; ++m) {
+        // intersect1d((satElev >= elevationMask).nonzero()[0], readyChnList): sorted, unique
+        active.clear();
+        for (int ch = 0; ch < nch; ++ch) {
+            if (!(satElev[(size_t)ch] >= elevationMask)) continue;
+            bool in = false;
+            for (int k = 0; k < n_ready; ++k) in = in || ready[k] == ch;
+            if (in) active.push_back(ch);
+        }
+        const int na = (int)active.size();
+        prns.resize((size_t)na);
+        for (int k = 0; k < na; ++k) {
+            if (active[(size_t)k] >= n_rows) {
+                sgx_set_error("IndexError: channel %d outside the %d tracked channels", active[(size_t)k], n_rows);
+                return SGX_E_RANGE;
+            }
+            prns[(size_t)k] = prn_of_row[active[(size_t)k]];
+            chan_PRN[(size_t)active[(size_t)k] * W + m] = (double)prns[(size_t)k];
+        }
+        for (int ch = 0; ch < nch; ++ch) when[(size_t)ch] = subFrameStart[ch] + navSolPeriod * m;
+        int rc = sgx_pseudoranges(absoluteSample, n_rows, ms, when.data(), active.data(), na, nch, samplesPerCode,
+                                  startOffset, c_mps, raw.data());
+        if (rc != SGX_OK) return rc;
+        for (int ch = 0; ch < nch; ++ch) chan_rawP[(size_t)ch * W + m] = raw[(size_t)ch];
+        satPositions.assign((size_t)3 * (size_t)(na > 0 ? na : 1), 0.0);
+        satClk.assign((size_t)(na > 0 ? na : 1), 0.0);
+        rc = sgx_satpos(transmitTime, prns.data(), na, eph, satPositions.data(), satClk.data());
+        if (rc != SGX_OK) return rc;
+        if (na > 3) {
+            obs.resize((size_t)na);
+            el.assign((size_t)na, 0.0);
+            az.assign((size_t)na, 0.0);
+            for (int k = 0; k < na; ++k) obs[(size_t)k] = raw[(size_t)active[(size_t)k]] + satClk[(size_t)k] * c_mps;
+            double pos[4] = {0, 0, 0, 0}, dop[5] = {0, 0, 0, 0, 0};
+            int32_t deficient = 0;
+            rc = sgx_least_square_pos(satPositions.data(), obs.data(), na, c_mps, useTropCorr, pos, el.data(), az.data(), dop,
+                                      &deficient);
+            if (rc != SGX_OK) return rc;
+            if (deficient) pos[0] = pos[1] = pos[2] = pos[3] = 0.0;   // (the reference's early return: a zero position)
+            for (int k = 0; k < na; ++k) {
+                chan_el[(size_t)active[(size_t)k] * W + m] = el[(size_t)k];
+                chan_az[(size_t)active[(size_t)k] * W + m] = az[(size_t)k];
+            }
+            for (int i = 0; i < 5; ++i) DOP[i * W + m] = dop[i];
+            for (int i = 0; i < 4; ++i) sol[i * W + m] = pos[i];
+            for (int ch = 0; ch < nch; ++ch) satElev[(size_t)ch] = chan_el[(size_t)ch * W + m];   // (NaN: not in use)
+            for (int k = 0; k < na; ++k)
+                chan_correctedP[(size_t)active[(size_t)k] * W + m] = (raw[(size_t)active[(size_t)k]] + satClk[(size_t)k] * c_mps) + pos[3];
+            double lat, lon, h, E, N, U;
+            rc = sgx_cart2geo(pos[0], pos[1], pos[2], 4, &lat, &lon, &h);
+            if (rc != SGX_OK) return rc;
+            sol[4 * W + m] = lat;
+            sol[5 * W + m] = lon;
+            sol[6 * W + m] = h;
+            rc = sgx_find_utm_zone(lat, lon, utmZone);
+            if (rc != SGX_OK) return rc;
+            rc = sgx_cart2utm(pos[0], pos[1], pos[2], *utmZone, &E, &N, &U);
+            if (rc != SGX_OK) return rc;
+            sol[7 * W + m] = E;
+            sol[8 * W + m] = N;
+            sol[9 * W + m] = U;
+        } else {
+            not_enough[m] = 1;
+            for (int i = 0; i < 10; ++i) sol[i * W + m] = NAN;
+            for (int i = 0; i < 5; ++i) DOP[i * W + m] = 0.0;
+            for (int k = 0; k < na; ++k) {
+                chan_az[(size_t)active[(size_t)k] * W + m] = NAN;
+                chan_el[(size_t)active[(size_t)k] * W + m] = NAN;
+            }
+        }
+        transmitTime += navSolPeriod / 1000;
+    }
+    return SGX_OK;
+}

@@ -89,9 +89,8 @@ class NavigationResult(Result):
         """Navigation solutions of reference postNavigation.py:75-305: subframe starts, ephemerides, then every
         navSolPeriod ms pseudoranges -> satellite positions -> least-squares position -> geodetic / UTM.
         Results in self.solutions (the reference's nested recarray, 64 measurement columns) and self.ephemeris.
-        The arithmetic runs in libsgx.so (sgx_find_preambles, sgx_nav_bits, sgx_ephemeris, sgx_pseudoranges,
-        sgx_satpos, sgx_least_square_pos, sgx_cart2geo, sgx_find_utm_zone, sgx_cart2utm)."""
-        from .geoFunctions import satpos, leastSquarePos, cart2geo, findUtmZone, cart2utm
+        Everything runs in libsgx.so: sgx_find_preambles, sgx_nav_bits, sgx_ephemeris, then sgx_post_navigate for the
+        loop over measurement epochs (pseudoranges, satellite positions, least-squares fix, geodetic / UTM)."""
         trackResults = self._results
         settings = self._settings
         status = trackResults.status
@@ -107,46 +106,39 @@ class NavigationResult(Result):
             self._solutions = None
             self._eph = None
             return
-        nch = settings.numberOfChannels
-        satElev = np.inf * np.ones(nch)
-        readyChnList = activeChnList.copy()
-        transmitTime = TOW
-        channel = np.rec.array([(np.zeros((nch, 64)), np.nan * np.ones((nch, 64)), np.nan * np.ones((nch, 64)),
-                                 np.nan * np.ones((nch, 64)), np.nan * np.ones((nch, 64)))],
-                               formats=['O'] * 5, names='PRN,el,az,rawP,correctedP')
-        nan64 = lambda: np.nan * np.ones(64)   # noqa: E731
-        navSolutions = np.rec.array([(channel, np.zeros((5, 64)), nan64(), nan64(), nan64(), nan64(), nan64(), nan64(),
-                                      nan64(), 0, nan64(), nan64(), nan64())], formats=['O'] * 13,
+        # the loop over measurement epochs (reference postNavigation.py:150-290) runs in libsgx (sgx_post_navigate); here
+        # its flat arrays are put into the reference's nested record arrays
+        nch = int(settings.numberOfChannels)
+        n_meas = int(np.fix(settings.msToProcess - subFrameStart.max()) / settings.navSolPeriod)
+        abs_s = np.ascontiguousarray(np.stack([np.asarray(r.absoluteSample, dtype=np.float64) for r in trackResults]))
+        prn_of_row = np.ascontiguousarray([int(r.PRN) for r in trackResults], dtype=np.int32)
+        sfs = np.ascontiguousarray(subFrameStart, dtype=np.float64)
+        ready = np.ascontiguousarray(activeChnList, dtype=np.int32)
+        from .geoFunctions import eph_table
+        tab = np.ascontiguousarray(eph_table(eph))
+        ch_PRN, ch_el, ch_az, ch_rawP, ch_corrP = (np.empty((nch, 64)) for _ in range(5))
+        DOP = np.empty((5, 64))
+        flat = np.empty((10, 64))
+        zone = C.c_int32(0)
+        short = np.zeros(64, dtype=np.int32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+        rc = _native.lib().sgx_post_navigate(
+            p(abs_s), int(abs_s.shape[0]), int(abs_s.shape[1]), p(prn_of_row), p(sfs), p(ready), int(ready.size), nch, p(tab),
+            int(TOW), int(settings.samplesPerCode), float(settings.startOffset), float(settings.c),
+            float(settings.navSolPeriod), float(settings.elevationMask), 1 if settings.useTropCorr else 0, n_meas,
+            p(ch_PRN), p(ch_el), p(ch_az), p(ch_rawP), p(ch_corrP), p(DOP), p(flat), C.byref(zone), p(short))
+        if rc == _native.SGX_E_RANGE:
+            msg = _native.last_error()
+            raise IndexError(msg) if msg.startswith('IndexError') else np.linalg.LinAlgError(msg)
+        _native.check(rc)
+        for m in np.flatnonzero(short[:max(n_meas, 0)]):
+            print('   Measurement No. %d' % m + ': Not enough information for position solution.')
+        channel = np.rec.array([(ch_PRN, ch_el, ch_az, ch_rawP, ch_corrP)], formats=['O'] * 5,
+                               names='PRN,el,az,rawP,correctedP')
+        navSolutions = np.rec.array([(channel, DOP) + tuple(flat[i] for i in range(7)) +
+                                     (float(zone.value) if np.any(short[:max(n_meas, 0)] == 0) and n_meas > 0 else 0,) +
+                                     tuple(flat[i] for i in range(7, 10))], formats=['O'] * 13,
                                     names='channel,DOP,X,Y,Z,dt,latitude,longitude,height,utmZone,E,N,U')
-        sol = navSolutions[0]
-        for currMeasNr in range(int(np.fix(settings.msToProcess - subFrameStart.max()) / settings.navSolPeriod)):
-            activeChnList = np.intersect1d((satElev >= settings.elevationMask).nonzero()[0], readyChnList)
-            channel[0].PRN[activeChnList, currMeasNr] = trackResults[activeChnList].PRN
-            channel[0].rawP[:, currMeasNr] = self.calculatePseudoranges(
-                subFrameStart + settings.navSolPeriod * currMeasNr, activeChnList)
-            satPositions, satClkCorr = satpos(transmitTime, trackResults[activeChnList].PRN, eph, settings)
-            if activeChnList.size > 3:
-                (xyzdt, channel[0].el[activeChnList, currMeasNr], channel[0].az[activeChnList, currMeasNr],
-                 sol.DOP[:, currMeasNr]) = leastSquarePos(
-                    satPositions, channel[0].rawP[activeChnList, currMeasNr] + satClkCorr * settings.c, settings)
-                xyzdt = np.asarray(xyzdt).reshape(-1)
-                sol.X[currMeasNr], sol.Y[currMeasNr], sol.Z[currMeasNr], sol.dt[currMeasNr] = xyzdt[:4]
-                satElev = channel[0].el[:, currMeasNr]
-                channel[0].correctedP[activeChnList, currMeasNr] = \
-                    channel[0].rawP[activeChnList, currMeasNr] + satClkCorr * settings.c + sol.dt[currMeasNr]
-                (sol.latitude[currMeasNr], sol.longitude[currMeasNr], sol.height[currMeasNr]) = cart2geo(
-                    sol.X[currMeasNr], sol.Y[currMeasNr], sol.Z[currMeasNr], 4)
-                sol.utmZone = findUtmZone(sol.latitude[currMeasNr], sol.longitude[currMeasNr])
-                (sol.E[currMeasNr], sol.N[currMeasNr], sol.U[currMeasNr]) = cart2utm(xyzdt[0], xyzdt[1], xyzdt[2],
-                                                                                     sol.utmZone)
-            else:
-                print('   Measurement No. %d' % currMeasNr + ': Not enough information for position solution.')
-                for name in ('X', 'Y', 'Z', 'dt', 'latitude', 'longitude', 'height', 'E', 'N', 'U'):
-                    sol[name][currMeasNr] = np.nan
-                sol.DOP[:, currMeasNr] = np.zeros(5)
-                channel[0].az[activeChnList, currMeasNr] = np.nan * np.ones(activeChnList.shape)
-                channel[0].el[activeChnList, currMeasNr] = np.nan * np.ones(activeChnList.shape)
-            transmitTime += settings.navSolPeriod / 1000
         self._solutions = navSolutions
         self._eph = eph
         return
