@@ -247,11 +247,13 @@ struct AcqSetup {
     int n_prn, n_bins;
 };
 __global__ __launch_bounds__(128) void acq_setup_kernel(AcqSetup a, int* __restrict__ d_prn, int2* __restrict__ d_bin,
-                                                        long long* __restrict__ d_sum, double* __restrict__ d_second) {
+                                                        long long* __restrict__ d_sum, double* __restrict__ d_second,
+                                                        int* __restrict__ d_arrived = nullptr) {
     const int t = threadIdx.x;
     if (t < a.n_prn) d_prn[t] = a.prn[t];
     if (t < a.n_bins) d_bin[t] = a.bin[t];
     if (t < 32) d_second[t] = 0.0;
+    if (t < 32 && d_arrived) d_arrived[t] = 0;
     if (t == 0) d_sum[0] = 0;
 }
 
@@ -351,6 +353,78 @@ __global__ __launch_bounds__(256) void acq_mixphi_kernel(SgxSig x, cplx* __restr
     double s = 0.0, c = 1.0;
     if (a.phi[j] != 0.0) sincospi((2.0 * a.phi[j]) * ((double)i / (double)n), &s, &c);
     out[(long long)blockIdx.y * n + i] = make_double2(c * xv, -(s * xv));
+}
+
+// The front of a call in ONE launch (round 4; int8 records): the first kernels of a call are a few microseconds each and
+// the host cannot queue them faster than they run, so four launches cost four launch latencies.  Workgroup roles by index:
+// [0, n_mix) acq_mixphi_kernel's tiles, [n_mix, n_mix + n_code) acq_code_kernel's (PRN list by value), then ACQ_SUM_WGS
+// of acq_sum_kernel's, then one of acq_setup_kernel's.  The record sum goes to the slot `sum_now`, which the PREVIOUS
+// call's set-up workgroup zeroed (two slots alternate; the host keeps track and clears a slot itself when it cannot know).
+#define ACQ_SUM_WGS 64
+__global__ __launch_bounds__(256) void acq_front_kernel(AcqSetup su, SgxSig x, PhiArgs pa, const int8_t* __restrict__ codes,
+                                                        cplx* __restrict__ out, long long n, int rows_fwd, double ts,
+                                                        double tc, long long n_samples, int* __restrict__ d_prn,
+                                                        int2* __restrict__ d_bin, long long* __restrict__ sum_now,
+                                                        long long* __restrict__ sum_next, double* __restrict__ d_second,
+                                                        int* __restrict__ d_arrived) {
+    const int gx = (int)((n + 255) / 256);
+    const int n_mix = rows_fwd * gx, n_code = su.n_prn * gx;
+    int blk = blockIdx.x;
+    const int t = threadIdx.x;
+    if (blk < n_mix) {
+        const int row = blk / gx;
+        const long long i = (long long)(blk - row * gx) * 256 + t;
+        if (i >= n) return;
+        const int j = row % pa.n_phi;
+        const int b = row / pa.n_phi;
+        const double xv = x.at((long long)b * n + i);
+        double s = 0.0, c = 1.0;
+        if (pa.phi[j] != 0.0) sincospi((2.0 * pa.phi[j]) * ((double)i / (double)n), &s, &c);
+        out[(long long)row * n + i] = make_double2(c * xv, -(s * xv));
+        return;
+    }
+    blk -= n_mix;
+    if (blk < n_code) {
+        const int row = blk / gx;
+        const long long i = (long long)(blk - row * gx) * 256 + t;
+        if (i >= n) return;
+        const int p = su.prn[row];
+        int idx = (int)ceil((ts * (double)(i + 1)) / tc) - 1;
+        if (i == n - 1) idx = 1022;
+        idx = idx < 0 ? 0 : (idx > 1022 ? 1022 : idx);
+        out[(long long)(rows_fwd + row) * n + i] = make_double2((double)codes[p * 1023 + idx], 0.0);
+        return;
+    }
+    blk -= n_code;
+    if (blk < ACQ_SUM_WGS) {
+        const int8_t* __restrict__ xs = x.i8;
+        const long long gid = (long long)blk * 256 + t, gsz = (long long)ACQ_SUM_WGS * 256;
+        long long head = (16 - ((unsigned long long)xs & 15)) & 15;
+        if (head > n_samples) head = n_samples;
+        const long long n16 = (n_samples - head) / 16;
+        long long acc = 0;
+        if (gid < head) acc += xs[gid];
+        const uint4* __restrict__ x16 = reinterpret_cast<const uint4*>(xs + head);
+        for (long long i = gid; i < n16; i += gsz) {
+            const uint4 v = x16[i];
+            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                acc += (int)(w[d] << 24) >> 24, acc += (int)(w[d] << 16) >> 24, acc += (int)(w[d] << 8) >> 24, acc += (int)w[d] >> 24;
+        }
+        for (long long i = head + n16 * 16 + gid; i < n_samples; i += gsz) acc += xs[i];
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+        __shared__ long long s_acc[4];
+        if ((t & 63) == 0) s_acc[t >> 6] = acc;
+        __syncthreads();
+        if (t == 0) atomicAdd((unsigned long long*)sum_now, (unsigned long long)(s_acc[0] + s_acc[1] + s_acc[2] + s_acc[3]));
+        return;
+    }
+    if (t < su.n_prn) d_prn[t] = su.prn[t];
+    if (t < su.n_bins) d_bin[t] = su.bin[t];
+    if (t < 32) d_second[t] = 0.0;
+    if (t < 32) d_arrived[t] = 0;
+    if (t == 0) sum_next[0] = 0;
 }
 
 static int ensure_buf(void** p, size_t* cap_bytes, size_t need) {
@@ -800,22 +874,26 @@ struct AcqCand {
     double v;
     int k, a, b;
 };
+// (the row maxima come from other workgroups of the SAME launch, acq_rowmax_peak_kernel: written and read past the
+// per-XCD L2s with device-scope accesses, no cache write-back or invalidation)
+#define ACQ_LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define ACQ_ST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 __device__ static inline AcqCand acq_peak_bin(const double* __restrict__ rowmax, const int* __restrict__ rowarg, int n_bins,
                                               int n_blocks, bool noncoh, int k) {
     int row = k, bsel = 0;
     if (!noncoh) {
         int best = 0;   // acquisition.py:129-133 generalised left to right, later block wins ties
         for (int b = 1; b < n_blocks; ++b) {
-            const double vb = rowmax[best * n_bins + k];
-            const double vn = rowmax[b * n_bins + k];
+            const double vb = ACQ_LD(rowmax + best * n_bins + k);
+            const double vn = ACQ_LD(rowmax + b * n_bins + k);
             if (!(vb > vn)) best = b;
         }
         row = best * n_bins + k;
         bsel = best;
     }
     AcqCand c;
-    c.v = rowmax[row];
-    c.a = rowarg[row];
+    c.v = ACQ_LD(rowmax + row);
+    c.a = ACQ_LD(rowarg + row);
     c.k = k;
     c.b = bsel;
     return c;
@@ -875,14 +953,48 @@ struct CoarseLook {
     PeakOut po;
     double second[32];
     unsigned long long seq;
+    // device-led fine search (round 4): the detections the publish kernel found (in PRN order, as the reference's loop
+    // finds them), and what the fine search made of them - the host looks ONCE, at seq2
+    int n_det;
+    int range_error;          // a detection's fine window (code phase + 10 ms) leaves the record: 1 + its slot
+    int det_slot[32];         // position in the call's PRN list
+    int det_phase[32];
+    long long fine_bi[32];    // arg-max of the 2^22-point magnitude spectrum over [4, uniq - 5)
+    unsigned long long seq2;
 };
+static_assert(sizeof(CoarseLook) <= 4096, "one pinned page");
+
+// det (device memory, read by the fine kernels): [0] n_det, [1 + d] PRN index, [33 + d] code phase
 __global__ __launch_bounds__(64) void acq_publish_kernel(const PeakOut* __restrict__ po, const double* __restrict__ second,
-                                                         int n_prn, CoarseLook* __restrict__ host, unsigned long long seq) {
+                                                         int n_prn, CoarseLook* __restrict__ host, unsigned long long seq,
+                                                         const int* __restrict__ prn_list, double threshold,
+                                                         long long fine_len, long long n_samples, int* __restrict__ det) {
     const int t = threadIdx.x;
     const int* src = reinterpret_cast<const int*>(po);
     int* dst = reinterpret_cast<int*>(&host->po);
     for (int i = t; i < (int)(sizeof(PeakOut) / sizeof(int)); i += 64) dst[i] = src[i];
     if (t < n_prn) host->second[t] = second[t];
+    if (det) {
+        // acquisition.py:164-166: detected iff peak / second peak > acqThreshold; the list in ascending PRN position
+        const bool hit = t < n_prn && po->index_error[t] == 0 && (po->peak[t] / second[t]) > threshold;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+        const int d = __builtin_popcountll(m & ((1ull << t) - 1ull));
+        const bool out = hit && (long long)po->cph[t] + fine_len > n_samples;   // (the reference would fail to broadcast)
+        const unsigned long long mo = __builtin_amdgcn_ballot_w64(out);
+        if (hit) {
+            det[1 + d] = prn_list[t];
+            det[33 + d] = po->cph[t];
+            host->det_slot[d] = t;
+            host->det_phase[d] = po->cph[t];
+        }
+        if (t == 0) {
+            det[80] = 0;                                    // fine_rows_kernel's arrival counter
+            det[0] = mo ? 0 : __builtin_popcountll(m);      // (an error: the fine kernels have nothing to do)
+            host->n_det = __builtin_popcountll(m);
+            host->range_error = mo ? 1 + __builtin_ctzll(mo) : 0;
+        }
+    }
+    if (det) return;   // device-led: the host waits for seq2 (fine_rows_kernel's last workgroup), two kernel ends later
     __threadfence_system();
     __syncthreads();
     if (t == 0) __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -890,33 +1002,32 @@ __global__ __launch_bounds__(64) void acq_publish_kernel(const PeakOut* __restri
 
 // Waits for acq_publish_kernel's `seq`.  Spins (bounded), then falls back to the stream synchronisation, after which the
 // page is complete in any case.
-static int coarse_look_wait(sgx_ctx* c, unsigned long long seq) {
-    const CoarseLook* h = (const CoarseLook*)c->h_look;
+static int coarse_look_wait(sgx_ctx* c, unsigned long long seq, bool second = false) {
+    const CoarseLook* h0 = (const CoarseLook*)c->h_look;
+    const unsigned long long* word = second ? &h0->seq2 : &h0->seq;
     const char* sp = getenv("SGX_ACQ_SPIN");
     if (!(sp && sp[0] == '0')) {
         const auto t0 = std::chrono::steady_clock::now();
         for (unsigned it = 0;; ++it) {
-            if (__atomic_load_n(&h->seq, __ATOMIC_ACQUIRE) == seq) return SGX_OK;
+            if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) return SGX_OK;
             if ((it & 1023u) == 1023u &&
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.05)
                 break;
         }
     }
     SGX_HIP(hipStreamSynchronize(c->stream));
-    if (__atomic_load_n(&h->seq, __ATOMIC_ACQUIRE) != seq) {
-        sgx_set_error("acquisition: the coarse search's result page was not written");
+    if (__atomic_load_n(word, __ATOMIC_ACQUIRE) != seq) {
+        sgx_set_error("acquisition: the search's result page was not written");
         return SGX_E_HIP;
     }
     return SGX_OK;
 }
 
 // One WAVE per PRN, a lane per Doppler bin (one lane per PRN scanning its rows was a chain of dependent loads: 12 us).
-__global__ __launch_bounds__(64) void acq_peak_kernel(const double* __restrict__ rowmax, const int* __restrict__ rowarg,
-                                                      int n_prn, int out_per_prn, int n_bins, int n_blocks, int noncoh,
-                                                      long long N, int spc, PeakOut* __restrict__ po,
-                                                      SecondArgs* __restrict__ sa, int2* __restrict__ row_map) {
-    const int pi = blockIdx.x, lane = threadIdx.x;
-    if (pi >= 32) return;
+__device__ __forceinline__ void acq_peak_one(const double* __restrict__ rowmax, const int* __restrict__ rowarg, int pi,
+                                             int lane, int n_prn, int out_per_prn, int n_bins, int n_blocks, int noncoh,
+                                             long long N, int spc, PeakOut* __restrict__ po, SecondArgs* __restrict__ sa,
+                                             int2* __restrict__ row_map) {
     if (pi >= n_prn) {
         if (lane == 0) {
             sa->row[pi] = -1;
@@ -957,6 +1068,49 @@ __global__ __launch_bounds__(64) void acq_peak_kernel(const double* __restrict__
     } else {
         row_map[pi] = make_int2(c.b * n_bins + c.k, pi);
     }
+}
+
+// acq_rowmax_finish_kernel and the peak step in one launch (round 4): a wave finishes one output row; the wave that
+// finishes the LAST row of a PRN (arrival counter per PRN, zeroed by the call's set-up) goes on to that PRN's block
+// choice, global peak and exclusion list.  The last PRN's wave also fills the unused slots of the second-peak arguments.
+__global__ __launch_bounds__(64) void acq_rowmax_peak_kernel(const double* __restrict__ pmax, const int* __restrict__ parg,
+                                                             int nblk, double* __restrict__ rowmax, int* __restrict__ rowarg,
+                                                             int* __restrict__ arrived, int n_prn, int out_per_prn,
+                                                             int n_bins, int n_blocks, int noncoh, long long N, int spc,
+                                                             PeakOut* __restrict__ po, SecondArgs* __restrict__ sa,
+                                                             int2* __restrict__ row_map) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    double best = -1.0;
+    int arg = 0;
+    for (int b = lane; b < nblk; b += 64) {
+        const double v = pmax[(long long)row * nblk + b];
+        const int i = parg[(long long)row * nblk + b];
+        if (v > best || (v == best && i < arg)) {
+            best = v;
+            arg = i;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_down(best, o);
+        const int oi = __shfl_down(arg, o);
+        if (ov > best || (ov == best && oi < arg)) {
+            best = ov;
+            arg = oi;
+        }
+    }
+    const int pi = row / out_per_prn;
+    int last = 0;
+    if (lane == 0) {
+        ACQ_ST(rowmax + row, best);
+        ACQ_ST(rowarg + row, arg);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // both written through before the arrival is counted
+        last = __hip_atomic_fetch_add(arrived + pi, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == out_per_prn;
+    }
+    last = __builtin_amdgcn_readfirstlane(last);
+    if (!last) return;
+    acq_peak_one(rowmax, rowarg, pi, lane, n_prn, out_per_prn, n_bins, n_blocks, noncoh, N, spc, po, sa, row_map);
+    if (pi == n_prn - 1 && n_prn + lane < 32)
+        acq_peak_one(rowmax, rowarg, n_prn + lane, 0, n_prn, out_per_prn, n_bins, n_blocks, noncoh, N, spc, po, sa, row_map);
 }
 
 // The acquisition on the four-step transform (sgx_fft.hip): every 38192-point transform is two kernels with register-resident
@@ -1052,28 +1206,43 @@ static int acquire_four_step(sgx_ctx* c, SgxSig x, size_t n_samples, const int32
     double* d_second = (double*)(dsm + 1024 + 12 * 4096);
     int2* d_binmap = (int2*)(dsm + 1024);              // [n_bins <= 128]
     int2* d_map = (int2*)(dsm + 200000);
+    int* d_arrived = (int*)(dsm + 51200);              // [32] rows finished per PRN (acq_rowmax_peak_kernel)
 
     hipEventRecord(c->ev[0], st);
+    cplx* const d_codefd = c->d_fwd + (size_t)rows_fwd * (size_t)N;
     {
+        // ---- set-up, record sum, mixed rows (n_blocks x n_phi, PRN independent) and code rows (n_prn): one launch for
+        //      int8 records; then the forward spectra of all of them as ONE batch, straight into d_fwd = [forward | code]
         AcqSetup su;
         memset(&su, 0, sizeof(su));
         su.n_prn = n_prn;
         su.n_bins = n_bins;
         for (int i = 0; i < n_prn; ++i) su.prn[i] = prn0[i];
         for (int k = 0; k < n_bins; ++k) su.bin[k] = bin_map[(size_t)k];
-        acq_setup_kernel<<<1, 128, 0, st>>>(su, d_prn, d_binmap, d_sum, d_second);
-    }
-    if (x.f64) acq_sum_f64_kernel<<<1, 1024, 0, st>>>(x.f64, (long long)n_samples, d_sum);
-    else acq_sum_kernel<<<64, 256, 0, st>>>(x.i8, (long long)n_samples, d_sum);
-
-    // ---- forward spectra (n_blocks x n_phi rows, PRN independent) and code spectra (n_prn rows): ONE batch, results
-    //      straight into d_fwd = [forward | code] ----------------------------------------------------------------------
-    cplx* const d_codefd = c->d_fwd + (size_t)rows_fwd * (size_t)N;
-    {
-        dim3 grid((unsigned)((N + 255) / 256), (unsigned)rows_fwd);
-        acq_mixphi_kernel<<<grid, 256, 0, st>>>(x, c->d_work[1], N, pa);
-        dim3 grid2((unsigned)((N + 255) / 256), (unsigned)n_prn);
-        acq_code_kernel<<<grid2, 256, 0, st>>>(c->d_codes, d_prn, c->d_work[1] + (size_t)rows_fwd * (size_t)N, N, ts, tc);
+        const char* fr0 = getenv("SGX_ACQ_FRONT");
+        static_assert(ACQ_MAX_BINS <= 256, "the set-up workgroup has 256 threads");
+        if (!x.f64 && !(fr0 && fr0[0] == '0')) {
+            const int ph = c->acq_sum_phase & 1;
+            long long* sum_now = (long long*)(dsm + 16) + ph;
+            long long* sum_next = (long long*)(dsm + 16) + (ph ^ 1);
+            if (!c->acq_sum_clean[ph]) SGX_HIP(hipMemsetAsync(sum_now, 0, 8, st));
+            const unsigned gx = (unsigned)((N + 255) / 256);
+            acq_front_kernel<<<(unsigned)(rows_fwd + n_prn) * gx + ACQ_SUM_WGS + 1, 256, 0, st>>>(
+                su, x, pa, c->d_codes, c->d_work[1], N, rows_fwd, ts, tc, (long long)n_samples, d_prn, d_binmap, sum_now,
+                sum_next, d_second, d_arrived);
+            c->acq_sum_clean[ph] = false;
+            c->acq_sum_clean[ph ^ 1] = true;
+            c->acq_sum_phase = ph ^ 1;
+            d_sum = sum_now;
+        } else {
+            acq_setup_kernel<<<1, 128, 0, st>>>(su, d_prn, d_binmap, d_sum, d_second, d_arrived);
+            if (x.f64) acq_sum_f64_kernel<<<1, 1024, 0, st>>>(x.f64, (long long)n_samples, d_sum);
+            else acq_sum_kernel<<<64, 256, 0, st>>>(x.i8, (long long)n_samples, d_sum);
+            dim3 grid((unsigned)((N + 255) / 256), (unsigned)rows_fwd);
+            acq_mixphi_kernel<<<grid, 256, 0, st>>>(x, c->d_work[1], N, pa);
+            dim3 grid2((unsigned)((N + 255) / 256), (unsigned)n_prn);
+            acq_code_kernel<<<grid2, 256, 0, st>>>(c->d_codes, d_prn, c->d_work[1] + (size_t)rows_fwd * (size_t)N, N, ts, tc);
+        }
         rc = sgx_fft4_forward(&c->plan_code, c->d_work[1], c->d_work[0], c->d_fwd, rows_fwd + n_prn, st, nullptr);
         if (rc != SGX_OK) return rc;
     }
@@ -1106,12 +1275,12 @@ static int acquire_four_step(sgx_ctx* c, SgxSig x, size_t n_samples, const int32
         rc = sgx_fft4_forward(&c->plan_code, nullptr, c->d_work[0], nullptr, (int64_t)np * rows_per_prn, st, &fu);
         if (rc != SGX_OK) return rc;
     }
-    acq_rowmax_finish_kernel<<<rows_out_all, 64, 0, st>>>(d_pmax, d_parg, nblk, d_rowmax, d_rowarg);
-    // ---- device: block choice, global peak, exclusion list of every PRN; the rows the second-peak search reads -------
+    // ---- device: row maxima, then per PRN block choice, global peak, exclusion list; the rows the second-peak search
+    //      reads ------------------------------------------------------------------------------------------------------
     PeakOut* d_po = (PeakOut*)(dsm + 620000);
     SecondArgs* d_sa = (SecondArgs*)(dsm + 600000);
-    acq_peak_kernel<<<32, 64, 0, st>>>(d_rowmax, d_rowarg, n_prn, out_per_prn, n_bins, n_blocks, noncoh, N, spc, d_po, d_sa,
-                                      d_map);
+    acq_rowmax_peak_kernel<<<rows_out_all, 64, 0, st>>>(d_pmax, d_parg, nblk, d_rowmax, d_rowarg, d_arrived, n_prn,
+                                                        out_per_prn, n_bins, n_blocks, noncoh, N, spc, d_po, d_sa, d_map);
     {
         const int rows2 = n_prn * (noncoh ? n_blocks : 1);
         Fft4Fuse fu;
@@ -1133,15 +1302,44 @@ static int acquire_four_step(sgx_ctx* c, SgxSig x, size_t n_samples, const int32
         rc = sgx_fft4_forward(&c->plan_code, nullptr, c->d_work[0], nullptr, rows2, st, &fu);
         if (rc != SGX_OK) return rc;
     }
-    // ---- the host's one look at the coarse search ------------------------------------------------------------------------
+    // ---- the fine search, queued right behind the coarse one: the publish kernel decides the detections on the device
+    //      (acquisition.py:164-166) and the fine kernels read its list, so the host looks ONCE, at the very end ----------
     const unsigned long long seq = ++c->look_seq;
-    acq_publish_kernel<<<1, 64, 0, st>>>(d_po, d_second, n_prn, (CoarseLook*)c->d_look, seq);
+    const long long fine_len = 10 * N;
+    const long long npts = 8ll << (long long)ceil(log2((double)fine_len));
+    const long long uniq = (long long)ceil((double)(npts + 1) / 2.0);
+    const char* fv1 = getenv("SGX_ACQ_FINE_V1");
+    const char* dl0 = getenv("SGX_ACQ_DEVICE_LED");
+    const bool device_led = sgx_fft_fine_supported(npts) && !(fv1 && fv1[0] == '1') && !(dl0 && dl0[0] == '0') && n_prn <= 32;
+    int* d_det = (int*)(dsm + 640000);
+    double* d_pv = (double*)(dsm + 65536);
+    long long* d_pi = (long long*)(dsm + 400000);
+    if (device_led) {
+        // (before the publish kernel is queued: nothing of the host's between it and the fine kernels)
+        rc = sgx_fft_plan_create(&c->plan_fine, npts);
+        if (rc != SGX_OK) return rc;
+        const int max_rows = (n_prn + 1) / 2;   // two real signals per complex row; only the detections' rows are touched
+        if ((rc = ensure_buf((void**)&c->d_fine[0], &c->cap_f0, (size_t)max_rows * sizeof(cplx) * (size_t)npts)) != SGX_OK) return rc;
+    }
+    acq_publish_kernel<<<1, 64, 0, st>>>(d_po, d_second, n_prn, (CoarseLook*)c->d_look, seq, d_prn, S.acqThreshold, fine_len,
+                                         (long long)n_samples, device_led ? d_det : nullptr);
     hipEventRecord(c->ev[1], st);
     SGX_HIP(hipGetLastError());
-    rc = coarse_look_wait(c, seq);
+    if (device_led) {
+        rc = sgx_fft_fine_search(&c->plan_fine, x, c->d_codes, nullptr, nullptr, n_prn, fine_len, d_sum, (double)n_samples, ts,
+                                 1.0 / S.codeFreqBasis, c->d_fine[0], 4, uniq - 5, d_pv, d_pi, st, d_det,
+                                 ((CoarseLook*)c->d_look)->fine_bi, &((CoarseLook*)c->d_look)->seq2, seq);
+        if (rc != SGX_OK) return rc;
+        hipEventRecord(c->ev[2], st);
+        SGX_HIP(hipGetLastError());
+        rc = coarse_look_wait(c, seq, true);
+    } else {
+        rc = coarse_look_wait(c, seq);
+    }
     if (rc != SGX_OK) return rc;
-    const PeakOut* h_po = &((const CoarseLook*)c->h_look)->po;
-    const double* h_second = ((const CoarseLook*)c->h_look)->second;
+    const CoarseLook* look = (const CoarseLook*)c->h_look;
+    const PeakOut* h_po = &look->po;
+    const double* h_second = look->second;
     const double* peak = h_po->peak;
     const int* cph = h_po->cph;
     const int* fbi = h_po->fbi;
@@ -1164,8 +1362,30 @@ static int acquire_four_step(sgx_ctx* c, SgxSig x, size_t n_samples, const int32
             det_slot.push_back(pi);
         }
     }
-    rc = acquire_fine(c, x, n_samples, det_prn, det_phase, det_slot, d_sum, carrFreq, codePhase, fineIdx);
-    if (rc != SGX_OK) return rc;
+    if (device_led) {
+        if (look->range_error) {
+            const int o = look->range_error - 1;
+            sgx_set_error("fine search needs codePhase + 10 ms = %lld samples, record window has %zu "
+                          "(reference acquisition.py:177 would fail to broadcast)", (long long)cph[o] + fine_len, n_samples);
+            return SGX_E_RANGE;
+        }
+        if (look->n_det != (int)det_prn.size()) {   // (the same comparison on the same doubles: cannot differ)
+            sgx_set_error("acquisition: device found %d detections, host %zu", look->n_det, det_prn.size());
+            return SGX_E_HIP;
+        }
+        for (int d = 0; d < look->n_det; ++d) {
+            const long long m = look->fine_bi[d] - 4;   // index inside the [4:uniq-5] slice (acquisition.py:187)
+            const int o = look->det_slot[d];
+            carrFreq[o] = ((double)m * S.samplingFreq) / (double)npts;   // acquisition.py:189-191 (Q3)
+            codePhase[o] = (double)look->det_phase[d];
+            fineIdx[o] = (int)m;
+        }
+        // (the result word is stored a moment before the last kernel retires: the device times below need its event)
+        SGX_HIP(hipEventSynchronize(c->ev[2]));
+    } else {
+        rc = acquire_fine(c, x, n_samples, det_prn, det_phase, det_slot, d_sum, carrFreq, codePhase, fineIdx);
+        if (rc != SGX_OK) return rc;
+    }
     hipEventElapsedTime(&c->timing.acq_coarse_ms, c->ev[0], c->ev[1]);
     hipEventElapsedTime(&c->timing.acq_fine_ms, c->ev[1], c->ev[2]);
     hipEventElapsedTime(&c->timing.acquire_ms, c->ev[0], c->ev[2]);

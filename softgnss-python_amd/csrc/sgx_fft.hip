@@ -1157,6 +1157,9 @@ struct FineArgs {
     int det_prn[32];          // by value: no host-to-device copy between the coarse and the fine search
     int det_phase[32];
     int n_det;
+    const int* det;           // or, device-led (round 4): the list in device memory, written by the coarse search's publish
+                              // kernel - [0] = n_det, [1 + d] = PRN index, [33 + d] = code phase - so that the fine
+                              // kernels are queued right behind the coarse ones without the host looking in between
     long long len;            // 10 N samples of signal, zeros beyond
     const long long* d_sum;   // sum of the record window (an integer for int8 samples, the bits of a double otherwise);
                               // mean = sum / n_mean (acquisition.py:59)
@@ -1173,9 +1176,23 @@ struct FineArgs {
     long long lo, hi;         // arg-max range [lo, hi)
     double* pv;               // [n_det][FF_N1 / 2] per-workgroup maxima
     long long* pi;
+    // device-led: the workgroup of fine_rows_kernel that finishes LAST folds the partial maxima into out_bi[d] and then
+    // stores `seq` into *out_seq (both in the pinned result page the host spins on); det[FINE_DONE_SLOT] counts arrivals
+    long long* out_bi;
+    unsigned long long* out_seq;
+    unsigned long long seq;
 };
 
-__global__ __launch_bounds__(FF_TPB) void fine_cols_kernel(FineArgs a, int n_tiles) {
+#define FINE_DONE_SLOT 80
+
+#define FA_NDET(a) ((a).det ? (a).det[0] : (a).n_det)
+#define FA_PRN(a, d) ((a).det ? (a).det[1 + (d)] : (a).det_prn[d])
+#define FA_PHASE(a, d) ((a).det ? (a).det[33 + (d)] : (a).det_phase[d])
+
+__global__ __launch_bounds__(FF_TPB) void fine_cols_kernel(FineArgs a, int n_tiles_host) {
+    const int n_det_k = FA_NDET(a);
+    const int n_tiles = a.det ? (FF_N2 / FF_C) * ((n_det_k + 1) / 2) : n_tiles_host;
+    if ((int)blockIdx.x >= n_tiles) return;
     extern __shared__ __attribute__((aligned(16))) char f4_smem[];
     cplx* __restrict__ buf = reinterpret_cast<cplx*>(f4_smem);   // [FF_N1][FF_C]
     cplx* __restrict__ twl = buf + FF_N1 * FF_C;                 // [FF_N1]
@@ -1214,10 +1231,10 @@ __global__ __launch_bounds__(FF_TPB) void fine_cols_kernel(FineArgs a, int n_til
     do {                                                                                                      \
         const int r_ = (t_) / TILES_PER_ROW, c0_ = ((t_) % TILES_PER_ROW) * FF_C;                              \
         const int d0_ = 2 * r_, d1_ = 2 * r_ + 1;                                                             \
-        const bool two_ = d1_ < a.n_det;                                                                      \
-        const long long pa_ = a.det_phase[d0_], pb_ = two_ ? a.det_phase[d1_] : pa_;                          \
-        const int8_t* __restrict__ ca_ = a.codes + a.det_prn[d0_] * 1023;                                    \
-        const int8_t* __restrict__ cb_ = two_ ? a.codes + a.det_prn[d1_] * 1023 : ca_;                        \
+        const bool two_ = d1_ < n_det_k;                                                                      \
+        const long long pa_ = FA_PHASE(a, d0_), pb_ = two_ ? FA_PHASE(a, d1_) : pa_;                          \
+        const int8_t* __restrict__ ca_ = a.codes + FA_PRN(a, d0_) * 1023;                                    \
+        const int8_t* __restrict__ cb_ = two_ ? a.codes + FA_PRN(a, d1_) * 1023 : ca_;                        \
         FC_ONE(tid, c0_, pa_, pb_, ca_, cb_, two_, in0, xa0, xb0, sa0, sb0);                                  \
         FC_ONE(tid + FF_TPB, c0_, pa_, pb_, ca_, cb_, two_, in1, xa1, xb1, sa1, sb1);                         \
     } while (0)
@@ -1225,7 +1242,7 @@ __global__ __launch_bounds__(FF_TPB) void fine_cols_kernel(FineArgs a, int n_til
     if (few && t < n_tiles) FC_REQUEST(t);
     for (; t < n_tiles; t += gridDim.x) {
         const int r = t / TILES_PER_ROW, c0 = (t % TILES_PER_ROW) * FF_C;
-        const bool two = 2 * r + 1 < a.n_det;
+        const bool two = 2 * r + 1 < n_det_k;
         if (few) {
             buf[tid] = in0 ? make_double2((xa0 - mean) * sa0, two ? (xb0 - mean) * sb0 : 0.0) : make_double2(0.0, 0.0);
             buf[tid + FF_TPB] = in1 ? make_double2((xa1 - mean) * sa1, two ? (xb1 - mean) * sb1 : 0.0) : make_double2(0.0, 0.0);
@@ -1245,9 +1262,9 @@ __global__ __launch_bounds__(FF_TPB) void fine_cols_kernel(FineArgs a, int n_til
             lds_sync();
         } else {
             const int d0 = 2 * r, d1 = 2 * r + 1;
-            const long long pa = a.det_phase[d0], pb = two ? a.det_phase[d1] : pa;
-            const int8_t* __restrict__ ca = a.codes + a.det_prn[d0] * 1023;
-            const int8_t* __restrict__ cb = two ? a.codes + a.det_prn[d1] * 1023 : ca;
+            const long long pa = FA_PHASE(a, d0), pb = two ? FA_PHASE(a, d1) : pa;
+            const int8_t* __restrict__ ca = a.codes + FA_PRN(a, d0) * 1023;
+            const int8_t* __restrict__ cb = two ? a.codes + FA_PRN(a, d1) * 1023 : ca;
             for (int e = tid; e < FF_N1 * FF_C; e += FF_TPB) {
                 bool in_;
                 double xa_, xb_, sa_, sb_;
@@ -1283,7 +1300,14 @@ __global__ __launch_bounds__(FF_TPB) void fine_cols_kernel(FineArgs a, int n_til
 #undef FC_ONE
 }
 
-__global__ __launch_bounds__(FF_TPB) void fine_rows_kernel(FineArgs a, int n_pairs) {
+__global__ __launch_bounds__(FF_TPB) void fine_rows_kernel(FineArgs a, int n_pairs_host) {
+    const int n_det_k = FA_NDET(a);
+    const int n_pairs = a.det ? (FF_N1 / 2) * ((n_det_k + 1) / 2) : n_pairs_host;
+    if ((int)blockIdx.x >= n_pairs) {
+        if (a.out_seq && n_pairs == 0 && blockIdx.x == 0 && threadIdx.x == 0)   // nothing detected: only the word
+            __hip_atomic_store(a.out_seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     extern __shared__ __attribute__((aligned(16))) char f4_smem[];
     constexpr int RP = FF_N2 + FF_N2 / 16;                       // a row with one spare element per 16 (lds_radix_pass)
     cplx* __restrict__ buf = reinterpret_cast<cplx*>(f4_smem);   // [2][RP]
@@ -1386,7 +1410,7 @@ __global__ __launch_bounds__(FF_TPB) void fine_rows_kernel(FineArgs a, int n_pai
         lds_sync();
         if (tid < 2) {
             const int det = 2 * r + tid;
-            if (det < a.n_det) {
+            if (det < n_det_k) {
                 double bv = s_v[tid * (FF_TPB / 64)];
                 long long bi = s_i[tid * (FF_TPB / 64)];
                 for (int w = 1; w < FF_TPB / 64; ++w) {
@@ -1397,13 +1421,66 @@ __global__ __launch_bounds__(FF_TPB) void fine_rows_kernel(FineArgs a, int n_pai
                         bi = oi;
                     }
                 }
-                a.pv[(long long)det * HALF + bx] = bv;
-                a.pi[(long long)det * HALF + bx] = bi;
+                if (a.out_seq) {   // device-led: read by the last workgroup of THIS launch - written through, no fence
+                    __hip_atomic_store(a.pv + (long long)det * HALF + bx, bv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(a.pi + (long long)det * HALF + bx, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                } else {
+                    a.pv[(long long)det * HALF + bx] = bv;
+                    a.pi[(long long)det * HALF + bx] = bi;
+                }
             }
         }
         // (the next pair's rows overwrite buf and the slots: everybody is past both by the barrier of the next turn...
         // which comes AFTER those stores; so one more here)
         lds_sync();
+    }
+    if (!a.out_seq) return;
+    // device-led: the last workgroup to arrive finishes the search (the host's loop of rounds 2-3: per detection the
+    // FIRST maximum over the workgroups' partials) and tells the host
+    __shared__ int s_last;
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned n_active = (unsigned)((int)gridDim.x < n_pairs ? (int)gridDim.x : n_pairs);
+        unsigned* ctr = reinterpret_cast<unsigned*>(const_cast<int*>(a.det)) + FINE_DONE_SLOT;
+        const unsigned ticket = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = ticket + 1u == n_active;
+        if (s_last) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    static_assert(FF_N1 / 2 == FF_TPB, "one partial per thread");
+    for (int d = 0; d < n_det_k; ++d) {
+        double bv = __hip_atomic_load(a.pv + (long long)d * (FF_N1 / 2) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        long long bi = __hip_atomic_load(a.pi + (long long)d * (FF_N1 / 2) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int o = 32; o >= 1; o >>= 1) {
+            const double ov = __shfl_xor(bv, o);
+            const long long oi = __shfl_xor(bi, o);
+            if (ov > bv || (ov == bv && oi < bi)) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        if ((tid & 63) == 0) {
+            s_v[tid >> 6] = bv;
+            s_i[tid >> 6] = bi;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < FF_TPB / 64; ++w) {
+                const double ov = s_v[w];
+                const long long oi = s_i[w];
+                if (ov > bv || (ov == bv && oi < bi)) {
+                    bv = ov;
+                    bi = oi;
+                }
+            }
+            a.out_bi[d] = bi;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        __hip_atomic_store(a.out_seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1418,7 +1495,9 @@ int sgx_fft_fine_partials(void) { return FF_N1 / 2; }
 // plan (its two-level table of W_M is used for the inter-step twiddles).  Fills pv / pi [n_det][sgx_fft_fine_partials()].
 int sgx_fft_fine_search(const FftPlan* plan, SgxSig x, const int8_t* codes, const int* det_prn,
                         const int* det_phase, int n_det, long long len, const long long* d_sum, double n_mean, double ts,
-                        double tc1, cplx* work, long long lo, long long hi, double* pv, long long* pi, hipStream_t st) {
+                        double tc1, cplx* work, long long lo, long long hi, double* pv, long long* pi, hipStream_t st,
+                        const int* d_det, long long* out_bi, unsigned long long* out_seq, unsigned long long seq) {
+    // d_det != nullptr: device-led - the detection list is in device memory (n_det here = the most it can hold)
     if (!plan->tw_hi || !sgx_fft_fine_supported(plan->n) || n_det < 1 || n_det > 32) {
         sgx_set_error("sgx_fft_fine_search: %lld points not supported", (long long)plan->n);
         return SGX_E_ARG;
@@ -1457,11 +1536,12 @@ int sgx_fft_fine_search(const FftPlan* plan, SgxSig x, const int8_t* codes, cons
     memset(&a, 0, sizeof(a));
     a.x = x;
     a.codes = codes;
-    for (int d = 0; d < n_det; ++d) {
+    for (int d = 0; d < n_det && !d_det; ++d) {
         a.det_prn[d] = det_prn[d];
         a.det_phase[d] = det_phase[d];
     }
     a.n_det = n_det;
+    a.det = d_det;
     a.len = len;
     a.d_sum = d_sum;
     a.n_mean = n_mean;
@@ -1480,6 +1560,9 @@ int sgx_fft_fine_search(const FftPlan* plan, SgxSig x, const int8_t* codes, cons
     a.hi = hi;
     a.pv = pv;
     a.pi = pi;
+    a.out_bi = d_det ? out_bi : nullptr;
+    a.out_seq = d_det ? out_seq : nullptr;
+    a.seq = seq;
     const int n_rows = (n_det + 1) / 2;
     const size_t lds_c = sizeof(cplx) * (FF_N1 * FF_C + FF_N1);
     const size_t lds_r = sizeof(cplx) * (2 * (FF_N2 + FF_N2 / 16) + 128) + (sizeof(double) + sizeof(long long)) * 2 * (FF_TPB / 64);

@@ -98,6 +98,8 @@ struct sgx_ctx {
     size_t cap_sig64 = 0;
     size_t cap_fwd = 0, cap_code = 0, cap_w0 = 0, cap_w1 = 0, cap_pow = 0, cap_f0 = 0, cap_f1 = 0;   // bytes
     void* d_small = nullptr;     // small result area
+    int acq_sum_phase = 0;       // acq_front_kernel: which of the two record-sum slots this call adds into ...
+    bool acq_sum_clean[2] = {false, false};   // ... and whether a slot is known to hold zero (the other call's set-up zeroed it)
     void* h_small = nullptr;     // pinned mirror
     void* h_look = nullptr;      // coherent pinned page a kernel publishes the coarse search's outcome to (host spins on it)
     void* d_look = nullptr;      // its device address
@@ -173,7 +175,11 @@ bool sgx_fft_fine_supported(int64_t npts);
 int sgx_fft_fine_partials(void);
 int sgx_fft_fine_search(const FftPlan* plan, SgxSig x, const int8_t* codes, const int* det_prn /* host, <= 32 */,
                         const int* d_det_phase, int n_det, long long len, const long long* d_sum, double n_mean, double ts,
-                        double tc1, cplx* work, long long lo, long long hi, double* pv, long long* pi, hipStream_t st);
+                        double tc1, cplx* work, long long lo, long long hi, double* pv, long long* pi, hipStream_t st,
+                        const int* d_det = nullptr /* device-led: [0] n_det, [1 + d] PRN index, [33 + d] code phase,
+                                                      [80] arrival counter (zero) */,
+                        long long* out_bi = nullptr /* device-led: [32] arg-max per detection (pinned page) ... */,
+                        unsigned long long* out_seq = nullptr /* ... then this word = seq */, unsigned long long seq = 0);
 bool sgx_fft4_supported(int64_t n);
 int sgx_fft4_row_blocks(void);
 int sgx_fft4_forward(const FftPlan* p, const cplx* in, cplx* work, cplx* out, int64_t rows, hipStream_t st,
