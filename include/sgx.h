@@ -199,16 +199,26 @@ int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset,
  * np.fromfile(fid, dataType, blksize) at tracking.py:154).  data_type SGX_DT_INT8 is sgx_track; otherwise the record
  * handle holds the file's BYTES as they are (little endian) and rec_file_offset, skipNumberOfBytes + codePhase and
  * absoluteSample stay BYTE positions, exactly as the reference's fid.seek / fid.tell treat them (tracking.py:107, 255) -
- * so an int16 channel whose start byte is odd reads samples that straddle the file's, as it does there.  int16 and uint8
- * need samplingFreq >= 16 x codeFreqBasis (SGX_E_ARG otherwise).
- * SGX_DT_FLOAT32: tracked EXACTLY when every sample of the window is m 2^-k for one k and 16-bit integers m (floats written
- * from ADC samples, or normalised by a power of two): the integers go through the int8 / int16 kernels and the correlator
- * series are scaled back, which no rounding of the reference's float64 arithmetic can tell from the real thing.
- * SGX_E_ARG with a message for records of arbitrary floats, non-finite samples, or a channel that starts inside a sample. */
+ * so a channel whose start byte lies inside a sample reads samples that straddle the file's, as it does there.
+ * int8, uint8 and int16 have typed kernels (int16 and uint8 at samplingFreq >= 16 x codeFreqBasis).  SGX_DT_FLOAT32 is
+ * tracked through them EXACTLY when every sample of the window is m 2^-k for one k and 16-bit integers m (floats written
+ * from ADC samples, or normalised by a power of two) and the channels start on samples: the integers go through the int8
+ * / int16 kernels and the correlator series are scaled back, which no rounding of the reference's float64 arithmetic can
+ * tell from the real thing.  Everything else - arbitrary float32, float64, float16, the wider integers, int16 / uint8 at
+ * low sampling rates - is read sample by sample where it lies and promoted to float64 as numpy promotes it (the
+ * per-sample kernel, sgx_trk_any.hip: slower, same contract).  Complex types are not tracked (the reference's
+ * discriminators fail on them). */
 #define SGX_DT_INT8  0
 #define SGX_DT_INT16 1
 #define SGX_DT_UINT8 2   /* offset-binary bytes as the reference reads them with dataType 'uint8': no offset is removed */
 #define SGX_DT_FLOAT32 3 /* IEEE binary32 */
+#define SGX_DT_FLOAT64 4
+#define SGX_DT_UINT16  5
+#define SGX_DT_INT32   6
+#define SGX_DT_UINT32  7
+#define SGX_DT_INT64   8
+#define SGX_DT_UINT64  9
+#define SGX_DT_FLOAT16 10
 int sgx_track_ex(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset,
                  const sgx_chan_init* ch, int32_t n_ch, int32_t ms,
                  double* out, int32_t* ms_done, int32_t data_type);

@@ -17,6 +17,7 @@ SGX_OK = 0
 SGX_E_ARG, SGX_E_HIP, SGX_E_NOMEM, SGX_E_INDEX, SGX_E_RCCL, SGX_E_RANGE = -1, -2, -3, -4, -5, -6
 NUM_SERIES = 13
 DT_INT8, DT_INT16, DT_UINT8, DT_FLOAT32 = 0, 1, 2, 3   # sgx_track_ex data_type (include/sgx.h)
+DT_FLOAT64, DT_UINT16, DT_INT32, DT_UINT32, DT_INT64, DT_UINT64, DT_FLOAT16 = 4, 5, 6, 7, 8, 9, 10
 MAX_SATS = 16
 SERIES = ("absoluteSample", "codeFreq", "carrFreq", "I_P", "I_E", "I_L", "Q_E", "Q_P", "Q_L",
           "dllDiscr", "dllDiscrFilt", "pllDiscr", "pllDiscrFilt")

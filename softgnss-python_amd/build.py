@@ -8,7 +8,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libsgx.so")
-SOURCES = ["sgx_host.cpp", "sgx_synth.hip", "sgx_fft.hip", "sgx_acq.hip", "sgx_trk.hip", "sgx_trk_f32.hip", "sgx_trk_tp.hip", "sgx_trk2.hip", "sgx_trk3.hip", "sgx_trk_multi.hip", "sgx_nav.hip", "sgx_navhost.cpp", "sgx_probe.hip", "sgx_geo.cpp"]
+SOURCES = ["sgx_host.cpp", "sgx_synth.hip", "sgx_fft.hip", "sgx_acq.hip", "sgx_trk.hip", "sgx_trk_f32.hip", "sgx_trk_tp.hip", "sgx_trk2.hip", "sgx_trk3.hip", "sgx_trk_multi.hip", "sgx_trk_any.hip", "sgx_nav.hip", "sgx_navhost.cpp", "sgx_probe.hip", "sgx_geo.cpp"]
 HEADERS = [os.path.join(CSRC, "sgx_trk_kernel.inc"), os.path.join(CSRC, "sgx_trk_math.h"), os.path.join(CSRC, "sgx_trk_common.h"), os.path.join(CSRC, "sgx_trk2_parts.h"), os.path.join(CSRC, "sgx_internal.h"), os.path.join(ROOT, "include", "sgx.h")]
 # -ffp-contract=off: chip-boundary index math must round exactly like the reference's numpy
 # expressions; fused multiply-adds are written explicitly where wanted.

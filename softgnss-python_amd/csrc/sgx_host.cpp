@@ -353,6 +353,10 @@ struct FilePipe {
     }
 };
 
+static const char* pipe_io_text(int err_no) {
+    return err_no ? strerror(err_no) : "the file ends there (truncated while it was read?)";
+}
+
 static void pipe_reader(FilePipe* P, int t) {
     (void)hipSetDevice(P->device);
     const long chunks = (long)P->read_ok.size();
@@ -381,7 +385,7 @@ static void pipe_reader(FilePipe* P, int t) {
             const ssize_t m = pread(P->fd, P->slot[sl] + got, len - got, (off_t)(P->file_offset + off + got));
             if (m <= 0) {
                 bad = true;
-                P->err_no.store(errno);
+                P->err_no.store(m == 0 ? 0 : errno);   // 0: the file ended here (it was truncated while streaming)
                 P->err_off.store(off + got);
                 break;
             }
@@ -401,9 +405,26 @@ static hipError_t pipe_run(FilePipe* P, bool* io_fail) {
     const long chunks = (long)P->read_ok.size();
     if (e == hipSuccess)
         for (int t = 0; t < SGX_PIPE_READERS && t < chunks; ++t) readers.emplace_back(pipe_reader, P, t);
+    // host_mark follows the copies chunk by chunk (not only when a slot is reused, 4 chunks later): the prefix an
+    // acquisition waits for is released as soon as its copy has completed.  Chunks up to issued - SLOTS are complete
+    // (their slot has been refilled, which waits for their event); the events of the later ones are still their own.
+    long completed = 0;
+    auto advance = [&](long issued) {
+        if (!P->host_mark) return;
+        if (completed < issued - SGX_PIPE_SLOTS) completed = issued - SGX_PIPE_SLOTS;
+        while (completed < issued && hipEventQuery(P->ev[completed % SGX_PIPE_SLOTS]) == hipSuccess) ++completed;
+        size_t end = (size_t)completed * SGX_SLOT_BYTES;
+        if (end > P->n) end = P->n;
+        size_t cur = P->host_mark->load();
+        while (end > cur && !P->host_mark->compare_exchange_weak(cur, end)) {
+        }
+    };
     for (long i = 0; i < chunks && e == hipSuccess; ++i) {
         int st;
-        while ((st = P->read_ok[(size_t)i].load()) == 0) std::this_thread::sleep_for(std::chrono::microseconds(10));
+        while ((st = P->read_ok[(size_t)i].load()) == 0) {
+            advance(i);
+            std::this_thread::sleep_for(std::chrono::microseconds(10));
+        }
         if (st < 0) {
             *io_fail = true;
             break;
@@ -414,10 +435,17 @@ static hipError_t pipe_run(FilePipe* P, bool* io_fail) {
         e = hipMemcpyAsync(P->dst + off, P->slot[sl], len, hipMemcpyHostToDevice, P->stream);
         if (e == hipSuccess && P->d_mark) if_mark_kernel<<<1, 1, 0, P->stream>>>(P->d_mark, (unsigned long long)(off + len));
         if (e == hipSuccess) e = hipEventRecord(P->ev[sl], P->stream);
+        if (e != hipSuccess) P->err_off.store(off);   // (the chunk whose copy could not be queued)
         P->issued.store(i + 1);
     }
     if (e != hipSuccess || *io_fail) P->stop.store(true);
     for (auto& t : readers) t.join();
+    // the tail: chunk by chunk as well (a record of a few chunks is all tail)
+    while (P->host_mark && e == hipSuccess && !*io_fail && completed < chunks) {
+        const long before = completed;
+        advance(chunks);
+        if (completed == before && hipEventSynchronize(P->ev[completed % SGX_PIPE_SLOTS]) != hipSuccess) break;
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(P->stream);
     for (int i = 0; i < SGX_PIPE_SLOTS; ++i)
         if (P->ev[i]) hipEventDestroy(P->ev[i]);
@@ -490,7 +518,7 @@ extern "C" int sgx_if_upload_file(sgx_ctx* c, const char* path, uint64_t file_of
         sgx_if_free(c, r);
         if (io_fail)
             sgx_set_error("read error on %s at byte %llu: %s", path, (unsigned long long)(file_offset + P.err_off.load()),
-                          strerror(P.err_no.load()));
+                          pipe_io_text(P.err_no.load()));
         else
             sgx_set_error("streaming upload of %s failed: %s", path, hipGetErrorString(e));
         return io_fail ? SGX_E_ARG : SGX_E_HIP;
@@ -517,7 +545,7 @@ static void if_loader_main(sgx_if* r, int fd, uint64_t file_offset, std::string 
     if (e != hipSuccess || io_fail) {
         snprintf(r->load_err, sizeof(r->load_err), io_fail ? "read error on %s at byte %llu: %s" : "streaming %s failed at byte %llu: %s",
                  path.c_str(), (unsigned long long)(file_offset + P.err_off.load()),
-                 io_fail ? strerror(P.err_no.load()) : hipGetErrorString(e));
+                 io_fail ? pipe_io_text(P.err_no.load()) : hipGetErrorString(e));
         r->load_rc.store(io_fail ? SGX_E_ARG : SGX_E_HIP);
     } else {
         r->host_mark.store(r->n);

@@ -47,6 +47,11 @@ void sgx_trk_multi_launch(int n_blocks, hipStream_t st, const int8_t* rec, const
                           double* out, int* done, const TrkConst& K, long long* prof, unsigned long long* xch,
                           int* err);
 
+// sgx_trk_any.hip: the same body with every sample fetched where it lies, for any sample type (K.kind)
+void sgx_trk_any_launch(int n_blocks, hipStream_t st, const int8_t* rec, const int8_t* codes, const TrkChan* chans,
+                        double* out, int* done, const TrkConst& K, long long* prof, unsigned long long* xch,
+                        int* err);
+
 // tracking.py:65-94: series start as zeros (absoluteSample, I/Q) or +Inf (the others)
 __global__ __launch_bounds__(256) void trk_fill_kernel(double* __restrict__ out, long long ms, long long total) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -60,9 +65,15 @@ __global__ __launch_bounds__(256) void trk_fill_kernel(double* __restrict__ out,
 // reference seeks skipNumberOfBytes + codePhase BYTES whatever the sample type and reports fid.tell(), also bytes
 // (tracking.py:107, 255); so a two-byte channel may start on an odd byte - its samples then straddle the file's - and
 // the kernel follows it there (per-channel byte shift of the record pointer, unaligned 16-byte loads).
-static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const sgx_chan_init* ch, int32_t n_ch,
-                      int32_t ms, double* out, int32_t* ms_done, int sample_bytes, bool sample_uns) {
+// kind: SGX_DT_*.  int8 / uint8 / int16 run the typed kernels (sgx_trk2 / sgx_trk3 / sgx_trk_tp); every other type - and
+// int16 / uint8 at sampling rates below 16 x the chip rate - the per-sample kernel of sgx_trk_any.hip.
+// skip_bytes: Settings.skipNumberOfBytes, or what stands in for it (sgx_trk_f32.hip tracks a narrowed copy of a window).
+int sgx_track_kind(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const sgx_chan_init* ch, int32_t n_ch,
+                   int32_t ms, double* out, int32_t* ms_done, int kind, long long skip_bytes) {
     SGX_CHECK_ARG(c && r && ch && out && ms_done);
+    const int sample_bytes = sgx_dt_bytes(kind);
+    SGX_CHECK_ARG(sample_bytes >= 1);
+    const bool sample_uns = kind == SGX_DT_UINT8;
     SGX_CHECK_ARG(n_ch >= 1 && n_ch <= 65535 && ms >= 1);
     if (!(c->s.dllCorrelatorSpacing > 0.0 && c->s.dllCorrelatorSpacing < 1.0)) {
         // beyond one chip the reference's replica index ceil(t) leaves its 1025-entry code table (or wraps)
@@ -99,6 +110,9 @@ static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
     // a group holds at most one switch per ramp, which the fast map relies on
     K.multi = (15.0 * 1.001 * S.codeFreqBasis / S.samplingFreq >= 1.0) ? 1 : 0;
     K.uns = sample_uns ? 1 : 0;
+    K.kind = kind;
+    const bool typed = kind == SGX_DT_INT8 || kind == SGX_DT_UINT8 || kind == SGX_DT_INT16;
+    const bool use_any = !typed || (K.multi && kind != SGX_DT_INT8);
     K.file_off = rec_file_offset;
     K.ms = ms;
     K.n_ch = n_ch;
@@ -119,7 +133,7 @@ static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
         // resident at once (they wait for each other), so members * channels <= CU count
         int split = cus_total / ch8;
         if (split > K.n_units) split = K.n_units;
-        if (K.multi && split > TRK_MAX_SPLIT) split = TRK_MAX_SPLIT;
+        if ((K.multi || use_any) && split > TRK_MAX_SPLIT) split = TRK_MAX_SPLIT;
         if (split < 1) split = 1;
         const char* se = getenv("SGX_TRK_SPLIT");
         if (se && atoi(se) >= 1 && atoi(se) <= split) split = atoi(se);
@@ -138,10 +152,10 @@ static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
         hc[(size_t)i].prn = ch[i].prn;
         hc[(size_t)i].pad = 0;
         SGX_CHECK_ARG(ch[i].prn >= 0 && ch[i].prn <= 32);
-        const long long p0 = (long long)S.skipNumberOfBytes + (long long)ch[i].codePhase - rec_file_offset;
+        const long long p0 = skip_bytes + (long long)ch[i].codePhase - rec_file_offset;
         if (ch[i].prn != 0 && p0 < 0) {
             sgx_set_error("channel %d starts at file byte %lld, before the record (offset %lld)", i,
-                          (long long)S.skipNumberOfBytes + (long long)ch[i].codePhase, (long long)rec_file_offset);
+                          skip_bytes + (long long)ch[i].codePhase, (long long)rec_file_offset);
             return SGX_E_RANGE;
         }
         // two-byte samples: the channel's own sample grid starts at byte (p0 & 1) of the record
@@ -207,12 +221,8 @@ static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
     // Which kernel: the low-rate variant when a group can hold several switches of a ramp; throughput mode for more
     // than 128 int8 channels (one workgroup per channel anyway); the latency-mode kernel otherwise - with one workgroup
     // per (unit, correlator arm) when three times the CUs of one-per-unit are free (SGX_TRK_ARMS=3 keeps one per unit).
-    if (K.multi && (sample_bytes != 1 || sample_uns)) {
-        sgx_set_error("int16 and uint8 samples need samplingFreq >= 16 x the chip rate (the low-rate kernel reads int8 records)");
-        return SGX_E_ARG;
-    }
-    const bool use_tp = !K.multi && sample_bytes == 1 && !sample_uns && K.split == 1 && n_ch > 128;
-    const bool use_v2 = !K.multi && !use_tp;
+    const bool use_tp = !use_any && !K.multi && sample_bytes == 1 && !sample_uns && K.split == 1 && n_ch > 128;
+    const bool use_v2 = !use_any && !K.multi && !use_tp;
     const char* ae = getenv("SGX_TRK_ARMS");
     const bool arm_split = use_v2 && K.split == K.n_units && K.n_units >= 2 && 3 * ch8 * K.n_units <= cus_total &&
                            !getenv("SGX_TRK_SPLIT") && !(ae && ae[0] == '3');
@@ -249,14 +259,18 @@ static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
             n = 0;
         }
     } reserved{c->device, 0};
-    bool used_v2 = false, retry_resident = false;
+    bool used_v2 = false;
+    // what the launches so far have established: the record's streaming has been tried (and stalled), a member of a
+    // cooperative layout timed out (the next launch runs with one workgroup per channel)
+    bool stream_tried = false, fallback_one = false;
     int used_members = 0;
     hipError_t e = hipSuccess;
     int h_err = 0;
     // The cooperating workgroups of a channel wait for each other, so all of them must be resident at once.  If
     // something else occupies the CUs a member times out (bounded spins) and flags the channel: the launch is
-    // then repeated once with one workgroup per channel, which needs no co-residency.
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    // then repeated once with one workgroup per channel, which needs no co-residency.  A streaming record whose
+    // watermark stalls is repeated on the resident record first, with the same decomposition: at most three launches.
+    for (int launches = 0; launches < 3; ++launches) {
         SGX_HIP(hipMemcpyAsync(d_ch, hc.data(), sizeof(TrkChan) * (size_t)n_ch, hipMemcpyHostToDevice, st));
         SGX_HIP(hipMemsetAsync(aux + sz_ch, 0, sz_done + sz_xch + 256, st));   // done, every polled word, err
         if (!direct) trk_fill_kernel<<<(unsigned)((elems + 255) / 256), 256, 0, st>>>(d_out, ms, (long long)elems);
@@ -264,11 +278,10 @@ static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
         // device watermark); the other kernels, and a launch repeated on the resident record, first wait for all of it
         const char* se2 = getenv("SGX_TRK_STREAM");
         const bool v2 = use_v2;
-        const bool want_stream = r->loader && !r->load_done.load() && attempt == 0 && !(se2 && se2[0] == '0') && v2;
-        if (attempt == 0 || retry_resident) K.split = split0;
-        else K.split = 1;                                        // a member timed out: no co-residency needed with one
+        const bool want_stream = r->loader && !r->load_done.load() && launches == 0 && !(se2 && se2[0] == '0') && v2;
+        K.split = fallback_one ? 1 : split0;                     // a member timed out: no co-residency needed with one
         K.n_units = n_units2;
-        bool v3 = use_v3 && (attempt == 0 || retry_resident);
+        bool v3 = use_v3 && !fallback_one;
         if (v3) {
             reserved.n = sgx_cu_reserve(c->device, cus_total, ch8 * n_units3);
             if (reserved.n == 0) v3 = false;                     // (the CUs are taken: the layouts below need fewer)
@@ -316,6 +329,12 @@ static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
             used_members = members_now;
             c->timing.track_kernel = 2.f;
         }
+        else if (use_any) {  // (any sample type, sample by sample)
+            const char* wh = getenv("SGX_TRK_TEST_WITHHOLD");
+            const int nba = (wh && wh[0] == '1' && K.split > 1) ? n_blocks - 8 : n_blocks;
+            sgx_trk_any_launch(nba, st, r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err);
+            c->timing.track_kernel = 6.f;
+        }
         else if (use_tp) {   // (one lane per prompt chip)
             sgx_trk_tp_launch(n_blocks, st, r->d, c->d_codes, d_ch, d_out, d_done, K, d_prof, d_xch, d_err);
             c->timing.track_kernel = 3.f;
@@ -334,14 +353,20 @@ static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         h_err = h_err2[0];
         reserved.drop();
-        const char* th = getenv("SGX_TRK_TEST_TIMEOUT");   // test hook: treat the first attempt as timed out
-        if (e == hipSuccess && th && th[0] == '1' && attempt == 0 && K.split > 1) h_err = 1;
-        if (e == hipSuccess && (h_err & TRK_ERR_STREAM) && attempt == 0) {
+        // test hooks: treat the first launch as timed out ('1'), or the one that follows a stalled stream ('2'); treat
+        // the first launch as a stalled stream (SGX_TRK_TEST_STALL=1)
+        const char* th = getenv("SGX_TRK_TEST_TIMEOUT");
+        const char* tst = getenv("SGX_TRK_TEST_STALL");
+        if (e == hipSuccess && th && K.split > 1 && !fallback_one &&
+            ((th[0] == '1' && launches == 0) || (th[0] == '2' && stream_tried)))
+            h_err = 1;
+        if (e == hipSuccess && tst && tst[0] == '1' && launches == 0) h_err = TRK_ERR_STREAM;
+        if (e == hipSuccess && (h_err & TRK_ERR_STREAM) && !stream_tried && !fallback_one) {
             // the streaming record's watermark stalled (the copy stream could not run beside the kernel): repeat
             // with the same decomposition once the whole record is resident
             fprintf(stderr, "[sgx] tracking: the record did not stream in beside the kernel; repeating the launch "
                             "on the resident record\n");
-            retry_resident = true;
+            stream_tried = true;
             continue;
         }
         h_err &= ~TRK_ERR_STREAM;
@@ -356,7 +381,7 @@ static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
         fprintf(stderr, "[sgx] tracking: channel %d timed out waiting for a cooperating workgroup (%d workgroups per "
                         "channel, are the CUs shared?); repeating the launch with one workgroup per channel\n", h_err - 1,
                 members_now);
-        K.split = 1;
+        fallback_one = true;
     }
     if (e == hipSuccess && !direct) e = hipMemcpyAsync(out, d_out, elems * sizeof(double), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(ms_done, d_done, sizeof(int) * (size_t)n_ch, hipMemcpyDeviceToHost, st);
@@ -406,16 +431,17 @@ static int track_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
 
 extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const sgx_chan_init* ch,
                          int32_t n_ch, int32_t ms, double* out, int32_t* ms_done) {
-    return track_impl(c, r, rec_file_offset, ch, n_ch, ms, out, ms_done, 1, false);
+    SGX_CHECK_ARG(c);
+    return sgx_track_kind(c, r, rec_file_offset, ch, n_ch, ms, out, ms_done, SGX_DT_INT8, (long long)c->s.skipNumberOfBytes);
 }
 
 extern "C" int sgx_track_ex(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const sgx_chan_init* ch,
                             int32_t n_ch, int32_t ms, double* out, int32_t* ms_done, int32_t data_type) {
+    SGX_CHECK_ARG(c);
     if (data_type == SGX_DT_FLOAT32) return sgx_track_float32(c, r, rec_file_offset, ch, n_ch, ms, out, ms_done);
-    if (data_type != SGX_DT_INT8 && data_type != SGX_DT_INT16 && data_type != SGX_DT_UINT8) {
-        sgx_set_error("sgx_track_ex: data_type %d (SGX_DT_INT8 = 0, SGX_DT_INT16 = 1, SGX_DT_UINT8 = 2 and SGX_DT_FLOAT32 = 3 are tracked)", (int)data_type);
+    if (sgx_dt_bytes(data_type) == 0) {
+        sgx_set_error("sgx_track_ex: data_type %d is not one of SGX_DT_* (include/sgx.h)", (int)data_type);
         return SGX_E_ARG;
     }
-    return track_impl(c, r, rec_file_offset, ch, n_ch, ms, out, ms_done, data_type == SGX_DT_INT16 ? 2 : 1,
-                      data_type == SGX_DT_UINT8);
+    return sgx_track_kind(c, r, rec_file_offset, ch, n_ch, ms, out, ms_done, data_type, (long long)c->s.skipNumberOfBytes);
 }

@@ -902,9 +902,14 @@ __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const
 
 // ================================ RECORD (wave 6) ================================
 // Stores block k's 13 series values once both filter waves have posted them (rflag >= k + 1): one block behind.
-__device__ __forceinline__ void t2_rec_store(T2Shared& S, int k, long long m, int lane, double* __restrict__ o) {
+__device__ __forceinline__ void t2_rec_store(T2Shared& S, int k, long long m, int lane, double* __restrict__ o,
+                                             int* __restrict__ err, int ch) {
     int budget = 1 << 16;
     while ((lds_peek(&S.rflag[0]) < k + 1 || lds_peek(&S.rflag[1]) < k + 1) && --budget) __builtin_amdgcn_s_sleep(2);
+    if (budget == 0) {   // the filter waves never posted block k: flag the channel (the host repeats or reports), no stale row
+        if (lane == 0) atomicCAS(err, 0, 1 + ch);
+        return;
+    }
     if (lane < SGX_NUM_SERIES) o[lane * m + k] = S.rec[k & 1][lane];
 }
 
@@ -924,7 +929,7 @@ __device__ __forceinline__ int t2_rec_role(T2Shared& S, const TrkConst& K, int p
     for (; it < ms; ++it) {
         const int par = it & 1;
         if (S.code[par].stop) break;
-        if (owner && it > 0) t2_rec_store(S, it - 1, m, lane, o);
+        if (owner && it > 0) t2_rec_store(S, it - 1, m, lane, o, err, ch);
         {   // (a resident record: mark_seen is all ones and this returns at once)
             const long long need = S.code[par].pos * SB + pad + 3 * span;
             wait_mark(K.mark, need < K.rec_len ? need : K.rec_len, mark_seen, err, ch);
@@ -1078,7 +1083,7 @@ __global__ __launch_bounds__(T2_THREADS) void trk2_kernel(const int8_t* __restri
 
     // a channel that was given up reports the blocks completed before the abort
     const bool aborted = S.code[done & 1].stop == 2;
-    if (wave == 6 && owner && done > 0 && !aborted) t2_rec_store(S, done - 1, (long long)K.ms, lane, o);
+    if (wave == 6 && owner && done > 0 && !aborted) t2_rec_store(S, done - 1, (long long)K.ms, lane, o, err, ch);
     if (aborted && done > 0) done -= 1;
     if (tid == 0 && owner) ms_done[ch] = done;
 }

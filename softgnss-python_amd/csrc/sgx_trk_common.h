@@ -1,6 +1,7 @@
 // Device helpers shared by the tracking kernels (sgx_trk.hip, sgx_trk2.hip, sgx_trk_tp.hip).  Everything here follows the reference's fp64 operation order where an integer
 // rounding follows; both files are built with -ffp-contract=off.
 #pragma once
+#include <hip/hip_fp16.h>
 #include <math.h>
 #include <stdlib.h>
 
@@ -54,6 +55,7 @@ struct TrkConst {
     const unsigned long long* mark;   // streaming record: bytes resident so far (device watermark), or null
     int multi;            // fewer than ~15 samples per chip: a 16-sample group can hold several chip switches
     int uns;              // one-byte samples are unsigned (Settings.dataType 'uint8')
+    int kind;             // SGX_DT_* of the record's samples (read by trk_kernel_any; the other kernels are typed)
 };
 
 struct TrkChan {
@@ -115,8 +117,9 @@ __device__ __forceinline__ void ramp_setup(double start, double step, double inv
 }
 
 // ---- filter phase, code side (wave 1): tracking.py:148-190 scalar part -------------------------------
+// (rec_len: the record's length in samples when it is not K.rec_len - trk_kernel_any's per-channel sample grid)
 __device__ __forceinline__ void prep_code(const TrkConst& K, double codeFreq, double rem, long long pos, TrkState& s,
-                                          TrkBlock& b, bool writer) {
+                                          TrkBlock& b, bool writer, long long rec_len = -1) {
     const double step = div_rn(codeFreq, K.fs, K.inv_fs);                    // T1: codeFreq / fs
     const int blk = sgx_ceil_div(K.code_len - rem, step);                    // == (int)ceil((1023 - rem) / step), always
     const double nb = (double)blk;
@@ -137,7 +140,7 @@ __device__ __forceinline__ void prep_code(const TrkConst& K, double codeFreq, do
     if (writer) {
         b.pos = pos;
         b.blk = blk;
-        b.stop = (blk <= 0 || pos + blk > K.rec_len) ? 1 : 0;
+        b.stop = (blk <= 0 || pos + blk > (rec_len >= 0 ? rec_len : K.rec_len)) ? 1 : 0;
         b.startE = startE;
         b.stepE = stepE;
         b.startL = startL;
@@ -279,6 +282,35 @@ __device__ __forceinline__ void wait_mark(const unsigned long long* mark, long l
             break;
         }
         __builtin_amdgcn_s_sleep(32);
+    }
+}
+
+// ---- trk_kernel_any (sgx_trk_any.hip): one sample of any little-endian numpy type, at any byte address -------------
+template <typename T> struct __attribute__((packed, aligned(1))) AnyAt { T v; };
+__host__ __device__ __forceinline__ int sgx_dt_bytes(int kind) {
+    switch (kind) {
+    case SGX_DT_INT8: case SGX_DT_UINT8: return 1;
+    case SGX_DT_INT16: case SGX_DT_UINT16: case SGX_DT_FLOAT16: return 2;
+    case SGX_DT_INT32: case SGX_DT_UINT32: case SGX_DT_FLOAT32: return 4;
+    case SGX_DT_INT64: case SGX_DT_UINT64: case SGX_DT_FLOAT64: return 8;
+    default: return 0;
+    }
+}
+// the value numpy's float64 arithmetic sees (tracking.py:195-196: carrier (float64) * rawSignal promotes every one of
+// these types to float64; 64-bit integers round to nearest like numpy's cast)
+__device__ __forceinline__ double any_sample(const int8_t* __restrict__ p, int kind) {
+    switch (kind) {
+    case SGX_DT_INT8: return (double)*p;
+    case SGX_DT_UINT8: return (double)*reinterpret_cast<const uint8_t*>(p);
+    case SGX_DT_INT16: return (double)reinterpret_cast<const AnyAt<short>*>(p)->v;
+    case SGX_DT_UINT16: return (double)reinterpret_cast<const AnyAt<unsigned short>*>(p)->v;
+    case SGX_DT_INT32: return (double)reinterpret_cast<const AnyAt<int>*>(p)->v;
+    case SGX_DT_UINT32: return (double)reinterpret_cast<const AnyAt<unsigned>*>(p)->v;
+    case SGX_DT_INT64: return (double)reinterpret_cast<const AnyAt<long long>*>(p)->v;
+    case SGX_DT_UINT64: return (double)reinterpret_cast<const AnyAt<unsigned long long>*>(p)->v;
+    case SGX_DT_FLOAT16: return (double)__half2float(reinterpret_cast<const AnyAt<__half>*>(p)->v);
+    case SGX_DT_FLOAT32: return (double)reinterpret_cast<const AnyAt<float>*>(p)->v;
+    default: return reinterpret_cast<const AnyAt<double>*>(p)->v;
     }
 }
 

@@ -1,19 +1,20 @@
 // Tracking of float32 records (Settings.dataType 'float32'; reference tracking.py:154 reads np.fromfile(fid, dataType,
-// blksize) and computes in float64) by EXACT NARROWING: every sample of the record is m 2^-k for one k and integers m
-// that fit 8 or 16 bits - floats written from ADC samples (k = 0) or normalised by a power of two (int16 / 32768: k = 15)
-// are - or the record is refused with a message.  The integers are tracked by the int8 / int16 kernels; a power of two
-// commutes with every rounding of the reference's arithmetic, so the correlator series are the integer record's times
-// 2^-k exactly and everything the discriminators make of them (ratios) is untouched.  A record of arbitrary floats has no
-// such k: it would need its own fixed-point scale and fp64 sample registers in the map, which this library does not have.
+// blksize) and computes in float64).  The fast way is EXACT NARROWING: when every sample of the window is m 2^-k for one k
+// (of either sign) and integers m that fit 8 or 16 bits - floats written from ADC samples (k = 0) or normalised by a power
+// of two (int16 / 32768: k = 15) are - the integers are tracked by the int8 / int16 kernels; a power of two commutes with
+// every rounding of the reference's arithmetic, so the correlator series are the integer record's times 2^-k exactly and
+// everything the discriminators make of them (ratios) is untouched.  A record of arbitrary floats has no such k, and a
+// channel may start inside a sample of the file (the reference seeks skipNumberOfBytes + codePhase BYTES, tracking.py:107):
+// both go to the per-sample kernel of sgx_trk_any.hip, which reads every float where it lies.
 #include "sgx_internal.h"
 
 #include <cmath>
 #include <cstring>
 #include <vector>
 
-// the C-ABI entry point of the integer records (sgx_trk.hip)
-extern "C" int sgx_track_ex(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const sgx_chan_init* ch, int32_t n_ch,
-                            int32_t ms, double* out, int32_t* ms_done, int32_t data_type);
+// sgx_trk.hip
+int sgx_track_kind(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const sgx_chan_init* ch, int32_t n_ch,
+                   int32_t ms, double* out, int32_t* ms_done, int kind, long long skip_bytes);
 
 // [0]: largest |x| (float bits), [1]: smallest exponent of a sample's lowest set bit + 1024 (0x7FFFFFFF: no nonzero sample),
 // [2]: a sample that is not finite was seen
@@ -58,36 +59,35 @@ int sgx_track_float32(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
     SGX_CHECK_ARG(c && r && ch && out && ms_done);
     SGX_CHECK_ARG(n_ch >= 1 && ms >= 1);
     const sgx_settings& S = c->s;
-    // the reference seeks skipNumberOfBytes + codePhase BYTES (tracking.py:107): a channel that does not start on a sample
-    // of the file reads the bit patterns of four bytes of two samples - nothing a receiver tracks
+    const long long skip = (long long)S.skipNumberOfBytes;
+    auto generic = [&]() { return sgx_track_kind(c, r, rec_file_offset, ch, n_ch, ms, out, ms_done, SGX_DT_FLOAT32, skip); };
+    {
+        const char* ne = getenv("SGX_TRK_F32_NARROW");   // '0': always the per-sample kernel
+        if (ne && ne[0] == '0') return generic();
+    }
     long long first = -1, last = -1;
     for (int i = 0; i < n_ch; ++i) {
         if (ch[i].prn == 0) continue;
-        const long long p0 = (long long)S.skipNumberOfBytes + (long long)ch[i].codePhase - rec_file_offset;
+        const long long p0 = skip + (long long)ch[i].codePhase - rec_file_offset;
         if (p0 < 0) {
             sgx_set_error("channel %d starts at file byte %lld, before the record (offset %lld)", i,
-                          (long long)S.skipNumberOfBytes + (long long)ch[i].codePhase, (long long)rec_file_offset);
+                          skip + (long long)ch[i].codePhase, (long long)rec_file_offset);
             return SGX_E_RANGE;
         }
-        if (p0 % 4 != 0) {
-            sgx_set_error("float32 record: channel %d starts at record byte %lld, inside a sample (the reference seeks "
-                          "skipNumberOfBytes + codePhase bytes, tracking.py:107)", i, p0);
-            return SGX_E_ARG;
-        }
+        // a channel that starts inside a sample of the file reads the bit patterns of bytes of two samples (the reference
+        // does): nothing to narrow
+        if (p0 % 4 != 0) return generic();
         first = (first < 0 || p0 < first) ? p0 : first;
         last = p0 > last ? p0 : last;
     }
-    if (first < 0) return sgx_track_ex(c, r, rec_file_offset, ch, n_ch, ms, out, ms_done, SGX_DT_INT8);   // nothing to track
-    // the window the channels can reach: a block is at most samplesPerCode + 1 samples long
+    if (first < 0) return generic();   // nothing to track
+    // the window the channels can reach: the same allowance per block as the kernels' units (64 samples, sgx_trk.hip)
     const long long n_code = c->n_code;
-    long long end = last + ((long long)ms * (n_code + 2) + n_code) * 4;
+    long long end = last + ((long long)ms * (n_code + 64) + n_code) * 4;
     if (end > (long long)r->n) end = (long long)r->n;
     end &= ~3ll;
     const long long n_samp = (end - first) / 4;
-    if (n_samp <= 0) {
-        sgx_set_error("float32 record: no whole sample behind record byte %lld", first);
-        return SGX_E_RANGE;
-    }
+    if (n_samp <= 0) return generic();  // (no whole sample: the kernel reports the short read)
     {
         const int rq = sgx_if_require(r, (size_t)end);   // (a streaming record: the scan needs every sample)
         if (rq != SGX_OK) return rq;
@@ -110,25 +110,17 @@ int sgx_track_float32(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
         sgx_set_error("float32 record scan: %s", hipGetErrorString(e));
         return SGX_E_HIP;
     }
-    if (h_st[2]) {
-        sgx_set_error("float32 record: a sample is NaN or infinite");
-        return SGX_E_ARG;
-    }
+    if (h_st[2]) return generic();      // NaN or infinite samples: numpy's arithmetic carries them, so does the kernel
     int k = 0;
     double peak = 0.0;
     if (h_st[1] != 0x7FFFFFFFu) {
         const int lb = (int)h_st[1] - 1024;     // every sample is a multiple of 2^lb
-        k = lb < 0 ? -lb : 0;
+        k = -lb;                                // (negative for records of multiples of 2^j, j > 0)
         float mxf;
         memcpy(&mxf, &h_st[0], sizeof(mxf));
         peak = ldexp((double)mxf, k);
     }
-    if (k > 120 || peak > 32767.0) {
-        sgx_set_error("float32 record: its samples are not m * 2^-k for one k and 16-bit integers m (largest |x| = %g needs "
-                      "%.0f at k = %d); records of arbitrary floats are not tracked - integer-valued or power-of-two "
-                      "normalised ones are, exactly", h_st[0] ? (double)ldexp(peak, -k) : 0.0, peak, k);
-        return SGX_E_ARG;
-    }
+    if (k > 120 || k < -120 || peak > 32767.0) return generic();   // arbitrary floats
     const bool narrow8 = peak <= 127.0;
     const int sb = narrow8 ? 1 : 2;
     // the integer record: the window only, its first sample at record byte 0
@@ -158,17 +150,14 @@ int sgx_track_float32(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
         // over with skipNumberOfBytes folded into codePhase... which is a double and may not be changed; instead the
         // record offset is chosen so that channel i lands on sample (p0_i - first) / 4: that needs one offset per
         // channel, so the channels are tracked with codePhase' = (p0_i - first) / 4 * sb and skip' = offset' = 0.
-        sgx_settings keep = c->s;
         std::vector<sgx_chan_init> hc((size_t)n_ch);
         for (int i = 0; i < n_ch; ++i) {
             hc[(size_t)i] = ch[i];
             if (ch[i].prn == 0) continue;
-            const long long p0 = (long long)S.skipNumberOfBytes + (long long)ch[i].codePhase - rec_file_offset;
+            const long long p0 = skip + (long long)ch[i].codePhase - rec_file_offset;
             hc[(size_t)i].codePhase = (double)((p0 - first) / 4 * sb);
         }
-        c->s.skipNumberOfBytes = 0;
-        rc = sgx_track_ex(c, &tmp, 0, hc.data(), n_ch, ms, out, ms_done, narrow8 ? SGX_DT_INT8 : SGX_DT_INT16);
-        c->s = keep;
+        rc = sgx_track_kind(c, &tmp, 0, hc.data(), n_ch, ms, out, ms_done, narrow8 ? SGX_DT_INT8 : SGX_DT_INT16, 0);
         if (rc == SGX_OK) {
             // absoluteSample is fid.tell() in BYTES of the float file (tracking.py:255): integer-record bytes * 4 / sb
             // behind the window's first byte; the six correlator series carry the 2^k

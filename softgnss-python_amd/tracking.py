@@ -37,16 +37,17 @@ class TrackingResult(Result):
         """Settings.dataType -> (sgx_track_ex data_type, bytes per sample).  The reference reads np.fromfile(fid,
         dataType, blksize) (tracking.py:154) but seeks and tells in BYTES (tracking.py:107, 255): both are kept."""
         dt = np.dtype(self._settings.dataType)
-        if dt == np.dtype(np.int8):
-            return _native.DT_INT8, 1
-        if dt == np.dtype('<i2'):
-            return _native.DT_INT16, 2
-        if dt == np.dtype(np.uint8):
-            return _native.DT_UINT8, 1
-        if dt == np.dtype('<f4'):
-            return _native.DT_FLOAT32, 4      # exact when the samples are integers times one power of two (include/sgx.h)
-        raise TypeError("the GPU path tracks int8, uint8, int16 and float32 IF samples (Settings.dataType %r)"
-                        % (self._settings.dataType,))
+        codes = {'i1': _native.DT_INT8, 'u1': _native.DT_UINT8, 'i2': _native.DT_INT16, 'u2': _native.DT_UINT16,
+                 'i4': _native.DT_INT32, 'u4': _native.DT_UINT32, 'i8': _native.DT_INT64, 'u8': _native.DT_UINT64,
+                 'f2': _native.DT_FLOAT16, 'f4': _native.DT_FLOAT32, 'f8': _native.DT_FLOAT64}
+        key = dt.kind + str(dt.itemsize)
+        # int8 / uint8 / int16 have their own kernels; float32 records of integers times one power of two are narrowed
+        # to them exactly; every other real type is read sample by sample where it lies (include/sgx.h, sgx_track_ex)
+        little = dt.byteorder in ('<', '|') or (dt.byteorder == '=' and np.little_endian)
+        if key in codes and little:
+            return codes[key], dt.itemsize
+        raise TypeError("the GPU path tracks little-endian real IF samples - int8 ... uint64, float16 / 32 / 64 - not "
+                        "Settings.dataType %r" % (self._settings.dataType,))
 
     def _window(self, fid, first, need):
         """Bytes [first, first+need) of the reference's file, as an HBM record."""
@@ -70,7 +71,7 @@ class TrackingResult(Result):
     def track(self, fid):
         """Code and carrier tracking of all channels (reference tracking.py:13-295).
 
-        fid   open binary file of Settings.dataType samples (int8 or int16; seek/read/tell/close), or a
+        fid   open binary file of Settings.dataType samples (any real little-endian type; seek/read/tell/close), or a
               DeviceFile over a record already in HBM (for int16: the file's bytes, Context.upload_bytes).  Each active channel starts at byte
               skipNumberOfBytes + codePhase (tracking.py:107).
         On a short record the reference prints a message, closes fid and returns None without
