@@ -221,7 +221,7 @@ int sgx_track_kind(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const s
     // Which kernel: the low-rate variant when a group can hold several switches of a ramp; throughput mode for more
     // than 128 int8 channels (one workgroup per channel anyway); the latency-mode kernel otherwise - with one workgroup
     // per (unit, correlator arm) when three times the CUs of one-per-unit are free (SGX_TRK_ARMS=3 keeps one per unit).
-    const bool use_tp = !use_any && !K.multi && sample_bytes == 1 && !sample_uns && K.split == 1 && n_ch > 128;
+    const bool use_tp = !use_any && !K.multi && K.split == 1 && n_ch > 128;   // (int8, uint8, int16)
     const bool use_v2 = !use_any && !K.multi && !use_tp;
     const char* ae = getenv("SGX_TRK_ARMS");
     const bool arm_split = use_v2 && K.split == K.n_units && K.n_units >= 2 && 3 * ch8 * K.n_units <= cus_total &&

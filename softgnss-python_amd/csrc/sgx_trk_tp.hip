@@ -19,6 +19,12 @@
 //   Bytes are fetched at their byte address (the hardware takes unaligned loads); bytes past a run's end are masked
 //   once per run.  A chip whose early and late switches differ (fp64 rounding exactly at a boundary) or whose runs
 //   exceed 20 samples takes an exact per-sample loop.
+//   OTHER SAMPLE TYPES (round 4; MODE 1 = uint8, 2 = little-endian int16).  The dot products take signed bytes, so a
+//   record is split into planes of signed bytes and a constant: uint8 x = x' + 128 with x' = the byte with its top bit
+//   flipped; int16 x = 256 h + (l' + 128) with h the high byte and l' the low byte with its top bit flipped (two v_perm
+//   per pair of dwords de-interleave a run into a low and a high plane, four samples per dword like an int8 run, so the
+//   same forty weight dwords serve).  sum_k x_k B_k = [256 sum h B] + sum x' B + 128 sum_{k < len} B_k; the last term from a
+//   per-block table of prefix sums of the integer weights (exact).  int16: twice the dot products of int8.
 #include "sgx_trk_common.h"
 #include "sgx_trk_math.h"
 
@@ -119,15 +125,58 @@ __device__ __forceinline__ TpChip tp_chip_bounds_inner(const TpRamps& R, int c, 
     return o;
 }
 
-// 20 bytes starting at record byte `addr` (any alignment; the hardware takes unaligned 16-byte loads): five dwords
-__device__ __forceinline__ void tp_load_raw(const int8_t* __restrict__ rec, long long addr, unsigned (&w)[5]) {
-    const U4a q = *reinterpret_cast<const U4a*>(rec + addr);
-    const unsigned q4 = reinterpret_cast<const U2a*>(rec + addr + 16)->x;
-    w[0] = q.x;
-    w[1] = q.y;
-    w[2] = q.z;
-    w[3] = q.w;
-    w[4] = q4;
+// 20 samples starting at sample `samp` of the channel's grid (any byte alignment; the hardware takes unaligned 16-byte
+// loads): five dwords of one-byte samples, ten of int16
+template <int MODE>
+__device__ __forceinline__ void tp_load_raw(const int8_t* __restrict__ rec, long long samp, unsigned (&w)[MODE == 2 ? 10 : 5]) {
+    if constexpr (MODE == 2) {
+        const long long addr = samp * 2;
+        const U4a q = *reinterpret_cast<const U4a*>(rec + addr);
+        const U4a r = *reinterpret_cast<const U4a*>(rec + addr + 16);
+        const U2a t = *reinterpret_cast<const U2a*>(rec + addr + 32);
+        w[0] = q.x, w[1] = q.y, w[2] = q.z, w[3] = q.w;
+        w[4] = r.x, w[5] = r.y, w[6] = r.z, w[7] = r.w;
+        w[8] = t.x, w[9] = t.y;
+    } else {
+        const U4a q = *reinterpret_cast<const U4a*>(rec + samp);
+        const unsigned q4 = reinterpret_cast<const U2a*>(rec + samp + 16)->x;
+        w[0] = q.x;
+        w[1] = q.y;
+        w[2] = q.z;
+        w[3] = q.w;
+        w[4] = q4;
+    }
+}
+
+// the planes of signed bytes of a run (see the header): lo for every type, hi for int16
+template <int MODE>
+__device__ __forceinline__ void tp_planes(const unsigned (&w)[MODE == 2 ? 10 : 5], unsigned (&lo)[5], unsigned (&hi)[5]) {
+#pragma unroll
+    for (int d = 0; d < 5; ++d) {
+        if constexpr (MODE == 0) {
+            lo[d] = w[d];
+            hi[d] = 0u;
+        } else if constexpr (MODE == 1) {
+            lo[d] = w[d] ^ 0x80808080u;
+            hi[d] = 0u;
+        } else {
+            lo[d] = __builtin_amdgcn_perm(w[2 * d + 1], w[2 * d], 0x06040200u) ^ 0x80808080u;
+            hi[d] = __builtin_amdgcn_perm(w[2 * d + 1], w[2 * d], 0x07050301u);
+        }
+    }
+}
+
+// one sample of the channel's grid as the reference's float64 arithmetic sees it (the exact per-sample path)
+template <int MODE>
+__device__ __forceinline__ double tp_sample(const int8_t* __restrict__ rec, long long samp, long long alloc) {
+    if constexpr (MODE == 2) {
+        long long a = samp * 2;
+        a = a > alloc - 2 ? alloc - 2 : a;
+        return (double)reinterpret_cast<const AnyAt<short>*>(rec + a)->v;
+    } else {
+        const long long a = samp > alloc - 1 ? alloc - 1 : samp;
+        return MODE == 1 ? (double)(int)(unsigned char)rec[a] : (double)(int)rec[a];
+    }
 }
 
 // bytes >= len zeroed
@@ -141,11 +190,14 @@ __device__ __forceinline__ void tp_mask_run(int len, unsigned (&w)[5]) {
 }
 
 // B_k 2^30 (k < 20) as four signed radix-256 digits, most significant first: lane = 20 comp + k
-__device__ __forceinline__ void tp_weight_digits(const TpCarr& t, signed char (&wq)[2][4][32], int lane) {
+// (returns the lane's integer weight W_k = rint(B_k 2^30), 0 for lanes >= 40)
+__device__ __forceinline__ int tp_weight_digits(const TpCarr& t, signed char (&wq)[2][4][32], int lane) {
+    int w_int = 0;
     if (lane < 40) {
         const int comp = lane / 20, k = lane - 20 * comp;
         const double v = comp ? t.B[k].y : t.B[k].x;
         int b = (int)rint(v * 1073741824.0);
+        w_int = b;
         const int d3 = (int)(signed char)(b & 0xFF);
         b = (b - d3) >> 8;
         const int d2 = (int)(signed char)(b & 0xFF);
@@ -157,6 +209,21 @@ __device__ __forceinline__ void tp_weight_digits(const TpCarr& t, signed char (&
         wq[comp][2][k] = (signed char)d2;
         wq[comp][3][k] = (signed char)d3;
     }
+    return w_int;
+}
+
+// pref[j] = sum_{k < j} (W_k cos, W_k sin), j = 0..20: the constant of a run of j unsigned bytes (integers below 2^35:
+// every addition exact).  A scan over lanes 0..19 (cos) and 20..39 (sin).
+__device__ __forceinline__ void tp_weight_prefix(int w_int, double2 (&pref)[24], int lane) {
+    const int comp = lane >= 20 ? 1 : 0, k = lane - 20 * comp;
+    double v = lane < 40 ? (double)w_int : 0.0;
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+        const double o = __shfl_up(v, off);
+        if (k >= off) v += o;
+    }
+    if (lane < 40) reinterpret_cast<double*>(&pref[k + 1])[comp] = v;
+    if (lane == 0) pref[0] = make_double2(0.0, 0.0);
 }
 
 // the four digit sums of a run -> sum_k x_k B_k 2^30 (exact in fp64: < 2^45)
@@ -173,11 +240,8 @@ __device__ __forceinline__ int tp_dot4_first(int x, int w) {
 
 // Head and tail run of a chip (bytes beyond the runs already zero): sum_k x_k B_k of each by int8 dot products against
 // the digit dwords, the runs rotated by their start phasors, the three codes applied.
-__device__ __forceinline__ void tp_runs(const int (&wr)[2][4][5], double2 gh, double2 b_tail,
-                                        const unsigned (&wh)[5], const unsigned (&wt)[5], bool e_switched, bool l_switched,
-                                        double cP, double cEh, double cEn, double cLh, double cLn, double& aIE, double& aQE,
-                                        double& aIP, double& aQP, double& aIL, double& aQL) {
-    const double2 gt = cmul2(gh, b_tail);
+__device__ __forceinline__ void tp_dots(const int (&wr)[2][4][5], const unsigned (&wh)[5], const unsigned (&wt)[5],
+                                        double& Hc, double& Hs, double& Tc, double& Ts) {
     // weight dwords [cos, sin][digit][d]: dword d holds the digits of k = 4 d .. 4 d + 3; in registers for the whole block
     int hc[4], hs[4], tc[4], ts[4];
 #pragma unroll
@@ -207,9 +271,16 @@ __device__ __forceinline__ void tp_runs(const int (&wr)[2][4][5], double2 gh, do
         tc[l] = __builtin_amdgcn_sdot4((int)wt[4], wc4, e, false);
         ts[l] = __builtin_amdgcn_sdot4((int)wt[4], ws4, f, false);
     }
-    // (the 2^-30 of the digit scale rides on gh)
-    const double Hc = tp_join(hc[0], hc[1], hc[2], hc[3]), Hs = tp_join(hs[0], hs[1], hs[2], hs[3]);
-    const double Tc = tp_join(tc[0], tc[1], tc[2], tc[3]), Ts = tp_join(ts[0], ts[1], ts[2], ts[3]);
+    Hc = tp_join(hc[0], hc[1], hc[2], hc[3]), Hs = tp_join(hs[0], hs[1], hs[2], hs[3]);
+    Tc = tp_join(tc[0], tc[1], tc[2], tc[3]), Ts = tp_join(ts[0], ts[1], ts[2], ts[3]);
+}
+
+// the runs' sums (scaled by 2^30: the 2^-30 rides on gh) rotated by their start phasors, the three codes applied
+__device__ __forceinline__ void tp_apply(double2 gh, double2 b_tail, double Hc, double Hs, double Tc, double Ts,
+                                         bool e_switched, bool l_switched, double cP, double cEh, double cEn, double cLh,
+                                         double cLn, double& aIE, double& aQE, double& aIP, double& aQP, double& aIL,
+                                         double& aQL) {
+    const double2 gt = cmul2(gh, b_tail);
     // rotate the runs by their start phasors: cos part -> Q, sin part -> I (tracking.py:205-207)
     const double hQ = __builtin_fma(gh.x, Hc, -(gh.y * Hs)), hI = __builtin_fma(gh.y, Hc, gh.x * Hs);
     const double tQ = __builtin_fma(gt.x, Tc, -(gt.y * Ts)), tI = __builtin_fma(gt.y, Tc, gt.x * Ts);
@@ -224,7 +295,8 @@ __device__ __forceinline__ void tp_runs(const int (&wr)[2][4][5], double2 gh, do
     aQL = __builtin_fma(cLt, tQ, __builtin_fma(cLh, hQ, aQL));
 }
 
-__global__ __launch_bounds__(TP_THREADS, TP_OCC) void trk_kernel_tp(const int8_t* __restrict__ rec,
+template <int MODE>
+__global__ __launch_bounds__(TP_THREADS, TP_OCC) void trk_kernel_tp(const int8_t* __restrict__ rec0,
                                                                 const int8_t* __restrict__ codes,
                                                                 const TrkChan* __restrict__ chans,
                                                                 double* __restrict__ out, int* __restrict__ ms_done,
@@ -239,6 +311,9 @@ __global__ __launch_bounds__(TP_THREADS, TP_OCC) void trk_kernel_tp(const int8_t
     __shared__ double s_rec[16][16];       // the records of the last sixteen blocks, [block & 15][series]: stored eight blocks
                                            // at a time, 64 contiguous bytes per series row (one 8-byte store per row and
                                            // block made 5.2 bytes of memory traffic per byte of series)
+    __shared__ double2 s_pref[24];         // MODE != 0: prefix sums of the integer weights (tp_weight_prefix)
+    constexpr int SB = MODE == 2 ? 2 : 1;  // bytes per sample
+    constexpr int NW = 5 * SB;             // dwords of a run as loaded
 
     const int ch = blockIdx.x;
     if (ch >= K.n_ch) return;
@@ -249,6 +324,11 @@ __global__ __launch_bounds__(TP_THREADS, TP_OCC) void trk_kernel_tp(const int8_t
         if (tid == 0) ms_done[ch] = 0;
         return;
     }
+    // the channel's sample grid starts at byte cc.pad of the record (int16 channels may start on an odd byte,
+    // tracking.py:107); K.rec_len / K.rec_alloc are bytes
+    const int8_t* __restrict__ const rec = rec0 + cc.pad;
+    const long long rec_samples = (K.rec_len - cc.pad) / SB;
+    const long long alloc_bytes = K.rec_alloc - cc.pad;
     for (int i = tid; i < 1028; i += TP_THREADS) {
         int j = i - 1;
         if (j < 0) j = 1022;
@@ -272,9 +352,10 @@ __global__ __launch_bounds__(TP_THREADS, TP_OCC) void trk_kernel_tp(const int8_t
         tp_tables(K, s_st.w, s_st.remCarr, s_car, lane, 0);
         tp_tables(K, s_st.w, s_st.remCarr, s_car, lane, 1);
         __builtin_amdgcn_s_waitcnt(0xc07f);
-        tp_weight_digits(s_car, s_wq, lane);
+        const int w_int = tp_weight_digits(s_car, s_wq, lane);
+        if constexpr (MODE != 0) tp_weight_prefix(w_int, s_pref, lane);
     }
-    if (wave == 1) prep_code(K, s_st.codeFreq, s_st.remCode, s_st.pos, s_st, s_blk, lane == 0);
+    if (wave == 1) prep_code(K, s_st.codeFreq, s_st.remCode, s_st.pos, s_st, s_blk, lane == 0, rec_samples);
     __syncthreads();
 
     double* __restrict__ o = out + (long long)ch * SGX_NUM_SERIES * K.ms;
@@ -317,9 +398,9 @@ __global__ __launch_bounds__(TP_THREADS, TP_OCC) void trk_kernel_tp(const int8_t
         int c = c_first + tid;
         bool have = c <= c_last;
         TpChip cur = bounds_of(have ? c : c_last);
-        unsigned wh[5], wt[5];
-        tp_load_raw(rec, pos + cur.s0, wh);
-        tp_load_raw(rec, pos + (cur.eE > cur.eL ? cur.eE : cur.eL), wt);
+        unsigned wh[NW], wt[NW];
+        tp_load_raw<MODE>(rec, pos + cur.s0, wh);
+        tp_load_raw<MODE>(rec, pos + (cur.eE > cur.eL ? cur.eE : cur.eL), wt);
         // the block's 40 weight dwords (two workgroups per CU leave 256 registers per lane: no LDS read per chip - with
         // them re-read for every chip the kernel measured 4 % slower)
         int wr[2][4][5];
@@ -334,8 +415,8 @@ __global__ __launch_bounds__(TP_THREADS, TP_OCC) void trk_kernel_tp(const int8_t
         }
         // one chip: `ck` with its bytes in wh / wt (the runs, unmasked), while the next chip's bounds go to `nk` and its
         // bytes are requested into yh / yt.  Called alternately with the two register sets swapped, so nothing is copied.
-        auto chip = [&](const TpChip& ck, int cc_, unsigned (&wh)[5], unsigned (&wt)[5], TpChip& nk, int cn_, unsigned (&yh)[5],
-                        unsigned (&yt)[5]) {
+        auto chip = [&](const TpChip& ck, int cc_, unsigned (&wh)[NW], unsigned (&wt)[NW], TpChip& nk, int cn_, unsigned (&yh)[NW],
+                        unsigned (&yt)[NW]) {
             const int s0 = ck.s0, s1 = ck.s1, eE = ck.eE, eL = ck.eL;
             const int e1 = eE < eL ? eE : eL, e2 = eE < eL ? eL : eE;
             const int len_h = e1 - s0, len_t = s1 - e2;
@@ -366,8 +447,8 @@ __global__ __launch_bounds__(TP_THREADS, TP_OCC) void trk_kernel_tp(const int8_t
                 asm volatile("ds_read_b128 %0, %1" : "=v"(tb) : "v"(ab));
             }
             nk = bounds_of(cn_);
-            tp_load_raw(rec, pos + nk.s0, yh);
-            tp_load_raw(rec, pos + (nk.eE > nk.eL ? nk.eE : nk.eL), yt);
+            tp_load_raw<MODE>(rec, pos + nk.s0, yh);
+            tp_load_raw<MODE>(rec, pos + (nk.eE > nk.eL ? nk.eE : nk.eL), yt);
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hP), "+v"(hE), "+v"(hL), "+v"(t3), "+v"(t2), "+v"(t1), "+v"(t0), "+v"(tb));
             const double cP = __hiloint2double((int)hP, 0);
             const double cEh = __hiloint2double((int)hE.x, 0), cEn = __hiloint2double((int)hE.y, 0);
@@ -381,9 +462,18 @@ __global__ __launch_bounds__(TP_THREADS, TP_OCC) void trk_kernel_tp(const int8_t
             // dword of a run has bytes to mask
             const bool usual = (e1 == e2) && ((unsigned)(len_h - 17) <= 3u) && ((unsigned)(len_t - 17) <= 3u);
             bool by_runs = true;
+            // planes of signed bytes: four samples per dword whatever the sample type
+            unsigned ph_lo[5], ph_hi[5], pt_lo[5], pt_hi[5];
+            tp_planes<MODE>(wh, ph_lo, ph_hi);
+            tp_planes<MODE>(wt, pt_lo, pt_hi);
+            int ln_h = len_h, ln_t = len_t;        // run lengths as the constant term counts them
             if (__builtin_expect(__all(usual), 1)) {
-                wh[4] &= 0xFFFFFFFFu >> (8 * (20 - len_h));
-                wt[4] &= 0xFFFFFFFFu >> (8 * (20 - len_t));
+                ph_lo[4] &= 0xFFFFFFFFu >> (8 * (20 - len_h));
+                pt_lo[4] &= 0xFFFFFFFFu >> (8 * (20 - len_t));
+                if constexpr (MODE == 2) {
+                    ph_hi[4] &= 0xFFFFFFFFu >> (8 * (20 - len_h));
+                    pt_hi[4] &= 0xFFFFFFFFu >> (8 * (20 - len_t));
+                }
             } else {
                 const bool odd = (s1 > s0) && (e2 != e1 || len_h > TP_RUN || len_t > TP_RUN || e2 - s0 > 31);
                 if (__any(odd)) {
@@ -393,8 +483,7 @@ __global__ __launch_bounds__(TP_THREADS, TP_OCC) void trk_kernel_tp(const int8_t
                         double2 ph = gh;
                         const double2 b1 = s_car.B[1];
                         for (int i = s0; i < s1; ++i) {
-                            long long a = pos + i;
-                            const double xd = (double)(int)rec[a > K.rec_alloc - 1 ? K.rec_alloc - 1 : a];
+                            const double xd = tp_sample<MODE>(rec, pos + i, alloc_bytes);
                             const double xs = ph.y * xd, xc = ph.x * xd;
                             const double cE = i >= eE ? cEn : cEh;
                             const double cL = i >= eL ? cLn : cLh;
@@ -410,15 +499,35 @@ __global__ __launch_bounds__(TP_THREADS, TP_OCC) void trk_kernel_tp(const int8_t
                 } else {
                     // short or empty runs (the block's first and last chip): every dword masked (a lane without samples
                     // masks everything)
-                    tp_mask_run(s1 > s0 ? len_h : 0, wh);
-                    tp_mask_run(s1 > s0 ? len_t : 0, wt);
+                    ln_h = s1 > s0 ? len_h : 0;
+                    ln_t = s1 > s0 ? len_t : 0;
+                    tp_mask_run(ln_h, ph_lo);
+                    tp_mask_run(ln_t, pt_lo);
+                    if constexpr (MODE == 2) {
+                        tp_mask_run(ln_h, ph_hi);
+                        tp_mask_run(ln_t, pt_hi);
+                    }
                 }
             }
-            if (by_runs)
-                tp_runs(wr, ghq, b_tail, wh, wt, eE <= e2, eL <= e2, cP, cEh, cEn, cLh, cLn, aIE, aQE, aIP, aQP, aIL, aQL);
+            if (by_runs) {
+                double Hc, Hs, Tc, Ts;
+                tp_dots(wr, ph_lo, pt_lo, Hc, Hs, Tc, Ts);
+                if constexpr (MODE == 2) {
+                    double Gc, Gs, Uc, Us;
+                    tp_dots(wr, ph_hi, pt_hi, Gc, Gs, Uc, Us);
+                    Hc = __builtin_fma(Gc, 256.0, Hc), Hs = __builtin_fma(Gs, 256.0, Hs);
+                    Tc = __builtin_fma(Uc, 256.0, Tc), Ts = __builtin_fma(Us, 256.0, Ts);
+                }
+                if constexpr (MODE != 0) {
+                    const double2 kh = s_pref[ln_h], kt = s_pref[ln_t];   // (all integers below 2^53: exact)
+                    Hc = __builtin_fma(kh.x, 128.0, Hc), Hs = __builtin_fma(kh.y, 128.0, Hs);
+                    Tc = __builtin_fma(kt.x, 128.0, Tc), Ts = __builtin_fma(kt.y, 128.0, Ts);
+                }
+                tp_apply(ghq, b_tail, Hc, Hs, Tc, Ts, eE <= e2, eL <= e2, cP, cEh, cEn, cLh, cLn, aIE, aQE, aIP, aQP, aIL, aQL);
+            }
         };
         TpChip nxt;
-        unsigned nh[5], nt[5];
+        unsigned nh[NW], nt[NW];
         TP_STAMP(1)
 #pragma unroll 1
         while (have) {
@@ -476,7 +585,8 @@ __global__ __launch_bounds__(TP_THREADS, TP_OCC) void trk_kernel_tp(const int8_t
                 tp_tables(K, w_new, rc, s_car, lane, 0);
                 tp_tables(K, w_new, rc, s_car, lane, 1);
                 __builtin_amdgcn_s_waitcnt(0xc07f);
-                tp_weight_digits(s_car, s_wq, lane);
+                const int w_int = tp_weight_digits(s_car, s_wq, lane);
+                if constexpr (MODE != 0) tp_weight_prefix(w_int, s_pref, lane);
             }
             if (lane == 0) {
                 s_st.w = w_new;
@@ -511,12 +621,12 @@ __global__ __launch_bounds__(TP_THREADS, TP_OCC) void trk_kernel_tp(const int8_t
                 s_st.oldCodeErr = codeError;
                 s_st.codeFreq = codeFreq;
                 double* __restrict__ r = s_rec[it & 15];
-                r[0] = (double)(pos_after + K.file_off);
+                r[0] = (double)(pos_after * SB + cc.pad + K.file_off);   // fid.tell(): bytes (tracking.py:255)
                 r[1] = codeFreq;
                 r[9] = codeError;
                 r[10] = codeNco;
             }
-            if (more) prep_code(K, codeFreq, rem_next, pos_after, s_st, s_blk, lane == 0);
+            if (more) prep_code(K, codeFreq, rem_next, pos_after, s_st, s_blk, lane == 0, rec_samples);
         } else if (wave == TP_THREADS / 64 - 1) {
             // the records of the eight blocks before this one: written to LDS by the filter waves, stored by this wave
             // while it has nothing else to do - lane = 8 row + j stores block it - 8 + j of series row `row`, so the eight
@@ -562,6 +672,8 @@ void sgx_trk_tp_launch(int n_blocks, hipStream_t st, const int8_t* rec, const in
     (void)prof;
     (void)xch;
     (void)err;
-    trk_kernel_tp<<<K.n_ch, TP_THREADS, 0, st>>>(rec, codes, (const TrkChan*)chans, out, done, K);
+    if (K.kind == SGX_DT_INT16) trk_kernel_tp<2><<<K.n_ch, TP_THREADS, 0, st>>>(rec, codes, (const TrkChan*)chans, out, done, K);
+    else if (K.kind == SGX_DT_UINT8) trk_kernel_tp<1><<<K.n_ch, TP_THREADS, 0, st>>>(rec, codes, (const TrkChan*)chans, out, done, K);
+    else trk_kernel_tp<0><<<K.n_ch, TP_THREADS, 0, st>>>(rec, codes, (const TrkChan*)chans, out, done, K);
     (void)n_blocks;
 }

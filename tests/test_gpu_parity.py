@@ -1357,7 +1357,7 @@ def test_track_int16_every_member_layout_and_a_known_type():
         assert np.array_equal(s2[:, 0], ser[:, 0]) and _trk_err(s2, ser) < 1e-9
     many, dm = ctx.track(rec, chans * 130, 5, data_type=m._native.DT_INT16)
     tm = ctx.timing()
-    assert tm["track_kernel"] == 2 and tm["track_members"] == 1 and np.all(dm == 5)
+    assert tm["track_kernel"] == 3 and tm["track_members"] == 1 and np.all(dm == 5)
     assert all(np.array_equal(many[i], many[0]) for i in range(1, 130))
     assert np.array_equal(many[0, 0], ser[0, 0]) and _trk_err(many[:1], ser) < 1e-9
 
@@ -1392,6 +1392,16 @@ def test_track_int16_odd_start_byte_and_short_record():
         assert (t3.series is not None) == ok
         o = orc.track(so, dict(PRN=prn, acquiredFreq=freq, codePhase=phase, status=['T'] * 3), raw)
         assert (o is not None) == ok
+        # the same in throughput mode (150 channels: one workgroup each, byte planes of the int16 samples)
+        ctx3 = m.engine.get_context(s3, 0)
+        chans = [(int(prn[i]), float(freq[i]), float(phase[i])) for i in range(3)] * 50
+        many, dm = ctx3.track(dev.record, chans, ms, data_type=m._native.DT_INT16)
+        assert ctx3.timing()["track_kernel"] == 3
+        if ok:
+            assert np.all(dm == ms) and np.array_equal(many[:3, 0], want[:, 0]) and _trk_err(many[:3], want) < TRK_TOL
+            assert all(np.array_equal(many[i], many[i % 3]) for i in range(3, 150))
+        else:
+            assert np.any(dm < ms)
 
 
 def test_track_uint8_record_against_the_oracle(tmp_path):
@@ -1437,7 +1447,7 @@ def test_track_uint8_record_against_the_oracle(tmp_path):
         assert np.array_equal(s2[:, 0], want[:, 0]) and _trk_err(s2, want) < TRK_TOL
     many, dm = ctx.track(rec, chans * 50, 20, data_type=m._native.DT_UINT8)
     tm = ctx.timing()
-    assert tm["track_kernel"] == 2 and tm["track_members"] == 1 and np.all(dm == 20)
+    assert tm["track_kernel"] == 3 and tm["track_members"] == 1 and np.all(dm == 20)
     assert np.array_equal(many[:3, 0], want[:, 0, :20]) and _trk_err(many[:3], want[:, :, :20]) < TRK_TOL
     s.dataType = 'complex64'
     with pytest.raises(TypeError, match="little-endian real IF samples"):
