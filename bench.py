@@ -538,6 +538,9 @@ def main():
         if world == 1 and args.many_channels > 0:
             out["roofline_many_channels"] = leg("roofline_many_channels", many_channels_leg, pkg, ctx, rec, acq, args,
                                                 read_gbs, n_code)
+        if world == 1 and args.many_channels > 0:
+            out["many_channels_other_types"] = leg("many_channels_other_types", many_typed_leg, pkg, ctx, rec, acq, n_code,
+                                                   1024, min(300, max(20, args.ms - 20)))
         if world == 1 and not args.no_from_file:
             out["from_file"] = leg("from_file", from_file_leg, pkg, ctx, s, rec, rec_len, n_code, local, args, series,
                                    elapsed / args.steps * 1e3)
@@ -655,6 +658,29 @@ def many_channels_leg(pkg, ctx, rec, acq, args, read_gbs, n_code):
         out["bound"] = d.get("bound", "valu")
     else:
         out["bound"] = "valu"
+    return out
+
+
+def many_typed_leg(pkg, ctx, rec, acq, n_code, nch=1024, ms=300):
+    """The throughput-mode kernel on the other sample types it reads (Settings.dataType 'uint8' and 'int16',
+    tracking.py:154): 1 024 channels x 300 ms of the first 310 ms of the record re-typed on the host, channel-seconds
+    tracked per second of kernel time (best of three launches).  A side figure; never part of `value`."""
+    chans = [(int(c.PRN), float(c.acquiredFreq), float(c.codePhase)) for c in acq.channels if c.PRN != 0]
+    x8 = rec.download(0, (ms + 10) * n_code)
+    out = {"channels": nch, "ms": ms, "unit": "channel-s/s"}
+    for name, arr, code in (("uint8", (x8.astype(np.int16) + 128).astype(np.uint8), pkg._native.DT_UINT8),
+                            ("int16", x8.astype("<i2") * 129 - 5, pkg._native.DT_INT16)):
+        isz = arr.dtype.itemsize
+        dev = ctx.upload_bytes(np.ascontiguousarray(arr).view(np.int8))
+        many = [(chans[j % len(chans)][0], chans[j % len(chans)][1],
+                 (chans[j % len(chans)][2] + ((j // len(chans)) % 8) * n_code) * isz) for j in range(nch)]
+        ts = []
+        for _ in range(3):
+            ser, dn = ctx.track(dev, many, ms, data_type=code)
+            ts.append(ctx.timing()["track_ms"])
+        dev.free()
+        out[name] = {"kernel_ms": float(np.min(ts)), "channel_s_per_s": nch * ms / float(np.min(ts)),
+                     "locked_channels": int(np.sum(dn == ms)), "track_kernel": int(ctx.timing()["track_kernel"])}
     return out
 
 

@@ -276,11 +276,10 @@ __device__ __forceinline__ void tp_dots(const int (&wr)[2][4][5], const unsigned
 }
 
 // the runs' sums (scaled by 2^30: the 2^-30 rides on gh) rotated by their start phasors, the three codes applied
-__device__ __forceinline__ void tp_apply(double2 gh, double2 b_tail, double Hc, double Hs, double Tc, double Ts,
+__device__ __forceinline__ void tp_apply(double2 gh, double2 gt, double Hc, double Hs, double Tc, double Ts,
                                          bool e_switched, bool l_switched, double cP, double cEh, double cEn, double cLh,
                                          double cLn, double& aIE, double& aQE, double& aIP, double& aQP, double& aIL,
                                          double& aQL) {
-    const double2 gt = cmul2(gh, b_tail);
     // rotate the runs by their start phasors: cos part -> Q, sin part -> I (tracking.py:205-207)
     const double hQ = __builtin_fma(gh.x, Hc, -(gh.y * Hs)), hI = __builtin_fma(gh.y, Hc, gh.x * Hs);
     const double tQ = __builtin_fma(gt.x, Tc, -(gt.y * Ts)), tI = __builtin_fma(gt.y, Tc, gt.x * Ts);
@@ -462,68 +461,93 @@ __global__ __launch_bounds__(TP_THREADS, TP_OCC) void trk_kernel_tp(const int8_t
             // dword of a run has bytes to mask
             const bool usual = (e1 == e2) && ((unsigned)(len_h - 17) <= 3u) && ((unsigned)(len_t - 17) <= 3u);
             bool by_runs = true;
-            // planes of signed bytes: four samples per dword whatever the sample type
-            unsigned ph_lo[5], ph_hi[5], pt_lo[5], pt_hi[5];
-            tp_planes<MODE>(wh, ph_lo, ph_hi);
-            tp_planes<MODE>(wt, pt_lo, pt_hi);
-            int ln_h = len_h, ln_t = len_t;        // run lengths as the constant term counts them
-            if (__builtin_expect(__all(usual), 1)) {
-                ph_lo[4] &= 0xFFFFFFFFu >> (8 * (20 - len_h));
-                pt_lo[4] &= 0xFFFFFFFFu >> (8 * (20 - len_t));
-                if constexpr (MODE == 2) {
-                    ph_hi[4] &= 0xFFFFFFFFu >> (8 * (20 - len_h));
-                    pt_hi[4] &= 0xFFFFFFFFu >> (8 * (20 - len_t));
+            // the exact per-sample loop over a chip (rare)
+            auto per_sample = [&]() {
+                if (s1 > s0) {
+                    double2 ph = gh;
+                    const double2 b1 = s_car.B[1];
+                    for (int i = s0; i < s1; ++i) {
+                        const double xd = tp_sample<MODE>(rec, pos + i, alloc_bytes);
+                        const double xs = ph.y * xd, xc = ph.x * xd;
+                        const double cE = i >= eE ? cEn : cEh;
+                        const double cL = i >= eL ? cLn : cLh;
+                        aIE = __builtin_fma(cE, xs, aIE);
+                        aQE = __builtin_fma(cE, xc, aQE);
+                        aIP = __builtin_fma(cP, xs, aIP);
+                        aQP = __builtin_fma(cP, xc, aQP);
+                        aIL = __builtin_fma(cL, xs, aIL);
+                        aQL = __builtin_fma(cL, xc, aQL);
+                        ph = cmul2(ph, b1);
+                    }
+                }
+            };
+            if constexpr (MODE == 0) {
+                // int8: the record's dwords ARE the plane (masked in place)
+                if (__builtin_expect(__all(usual), 1)) {
+                    wh[4] &= 0xFFFFFFFFu >> (8 * (20 - len_h));
+                    wt[4] &= 0xFFFFFFFFu >> (8 * (20 - len_t));
+                } else {
+                    const bool odd = (s1 > s0) && (e2 != e1 || len_h > TP_RUN || len_t > TP_RUN || e2 - s0 > 31);
+                    if (__any(odd)) {
+                        by_runs = false;
+                        per_sample();
+                    } else {
+                        // short or empty runs (the block's first and last chip): every dword masked (a lane without
+                        // samples masks everything)
+                        tp_mask_run(s1 > s0 ? len_h : 0, wh);
+                        tp_mask_run(s1 > s0 ? len_t : 0, wt);
+                    }
+                }
+                if (by_runs) {
+                    const double2 gt = cmul2(ghq, b_tail);
+                    double Hc, Hs, Tc, Ts;
+                    tp_dots(wr, wh, wt, Hc, Hs, Tc, Ts);
+                    tp_apply(ghq, gt, Hc, Hs, Tc, Ts, eE <= e2, eL <= e2, cP, cEh, cEn, cLh, cLn, aIE, aQE, aIP, aQP, aIL, aQL);
                 }
             } else {
-                const bool odd = (s1 > s0) && (e2 != e1 || len_h > TP_RUN || len_t > TP_RUN || e2 - s0 > 31);
-                if (__any(odd)) {
-                    // exact per-sample loop over the chip (rare)
-                    by_runs = false;
-                    if (s1 > s0) {
-                        double2 ph = gh;
-                        const double2 b1 = s_car.B[1];
-                        for (int i = s0; i < s1; ++i) {
-                            const double xd = tp_sample<MODE>(rec, pos + i, alloc_bytes);
-                            const double xs = ph.y * xd, xc = ph.x * xd;
-                            const double cE = i >= eE ? cEn : cEh;
-                            const double cL = i >= eL ? cLn : cLh;
-                            aIE = __builtin_fma(cE, xs, aIE);
-                            aQE = __builtin_fma(cE, xc, aQE);
-                            aIP = __builtin_fma(cP, xs, aIP);
-                            aQP = __builtin_fma(cP, xc, aQP);
-                            aIL = __builtin_fma(cL, xs, aIL);
-                            aQL = __builtin_fma(cL, xc, aQL);
-                            ph = cmul2(ph, b1);
-                        }
+                // planes of signed bytes: four samples per dword whatever the sample type
+                unsigned ph_lo[5], ph_hi[5], pt_lo[5], pt_hi[5];
+                tp_planes<MODE>(wh, ph_lo, ph_hi);
+                tp_planes<MODE>(wt, pt_lo, pt_hi);
+                int ln_h = len_h, ln_t = len_t;        // run lengths as the constant term counts them
+                if (__builtin_expect(__all(usual), 1)) {
+                    ph_lo[4] &= 0xFFFFFFFFu >> (8 * (20 - len_h));
+                    pt_lo[4] &= 0xFFFFFFFFu >> (8 * (20 - len_t));
+                    if constexpr (MODE == 2) {
+                        ph_hi[4] &= 0xFFFFFFFFu >> (8 * (20 - len_h));
+                        pt_hi[4] &= 0xFFFFFFFFu >> (8 * (20 - len_t));
                     }
                 } else {
-                    // short or empty runs (the block's first and last chip): every dword masked (a lane without samples
-                    // masks everything)
-                    ln_h = s1 > s0 ? len_h : 0;
-                    ln_t = s1 > s0 ? len_t : 0;
-                    tp_mask_run(ln_h, ph_lo);
-                    tp_mask_run(ln_t, pt_lo);
-                    if constexpr (MODE == 2) {
-                        tp_mask_run(ln_h, ph_hi);
-                        tp_mask_run(ln_t, pt_hi);
+                    const bool odd = (s1 > s0) && (e2 != e1 || len_h > TP_RUN || len_t > TP_RUN || e2 - s0 > 31);
+                    if (__any(odd)) {
+                        by_runs = false;
+                        per_sample();
+                    } else {
+                        ln_h = s1 > s0 ? len_h : 0;
+                        ln_t = s1 > s0 ? len_t : 0;
+                        tp_mask_run(ln_h, ph_lo);
+                        tp_mask_run(ln_t, pt_lo);
+                        if constexpr (MODE == 2) {
+                            tp_mask_run(ln_h, ph_hi);
+                            tp_mask_run(ln_t, pt_hi);
+                        }
                     }
                 }
-            }
-            if (by_runs) {
-                double Hc, Hs, Tc, Ts;
-                tp_dots(wr, ph_lo, pt_lo, Hc, Hs, Tc, Ts);
-                if constexpr (MODE == 2) {
-                    double Gc, Gs, Uc, Us;
-                    tp_dots(wr, ph_hi, pt_hi, Gc, Gs, Uc, Us);
-                    Hc = __builtin_fma(Gc, 256.0, Hc), Hs = __builtin_fma(Gs, 256.0, Hs);
-                    Tc = __builtin_fma(Uc, 256.0, Tc), Ts = __builtin_fma(Us, 256.0, Ts);
-                }
-                if constexpr (MODE != 0) {
+                if (by_runs) {
+                    double Hc, Hs, Tc, Ts;
+                    tp_dots(wr, ph_lo, pt_lo, Hc, Hs, Tc, Ts);
+                    if constexpr (MODE == 2) {
+                        double Gc, Gs, Uc, Us;
+                        tp_dots(wr, ph_hi, pt_hi, Gc, Gs, Uc, Us);
+                        Hc = __builtin_fma(Gc, 256.0, Hc), Hs = __builtin_fma(Gs, 256.0, Hs);
+                        Tc = __builtin_fma(Uc, 256.0, Tc), Ts = __builtin_fma(Us, 256.0, Ts);
+                    }
                     const double2 kh = s_pref[ln_h], kt = s_pref[ln_t];   // (all integers below 2^53: exact)
                     Hc = __builtin_fma(kh.x, 128.0, Hc), Hs = __builtin_fma(kh.y, 128.0, Hs);
                     Tc = __builtin_fma(kt.x, 128.0, Tc), Ts = __builtin_fma(kt.y, 128.0, Ts);
+                    tp_apply(ghq, cmul2(ghq, b_tail), Hc, Hs, Tc, Ts, eE <= e2, eL <= e2, cP, cEh, cEn, cLh, cLn, aIE, aQE, aIP,
+                             aQP, aIL, aQL);
                 }
-                tp_apply(ghq, b_tail, Hc, Hs, Tc, Ts, eE <= e2, eL <= e2, cP, cEh, cEn, cLh, cLn, aIE, aQE, aIP, aQP, aIL, aQL);
             }
         };
         TpChip nxt;
