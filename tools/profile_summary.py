@@ -90,17 +90,17 @@ def main():
         with open(os.path.join(dst, "%s_pmc_trk_kernel.json" % tag), "w") as f:
             json.dump(rec, f, indent=1)
     # ---- many-channel (throughput-mode) kernel: traffic + VALU ----
-    f_tp, w_tp = big(fetch, "trk_kernel_tp"), big(write, "trk_kernel_tp")
+    f_tp, w_tp = big(fetch, "trk_kernel_tp<0>"), big(write, "trk_kernel_tp<0>")   # (the int8 instance)
     valu_db = db_of(os.path.join(out, "valu"))
     grbm_db = db_of(os.path.join(out, "grbm"))
     if f_tp is not None and valu_db and grbm_db:
         def biggest(db, counter, prefix):
             d = by_kernel(per_dispatch(db, counter))
-            ks = [k for k in d if k.startswith(prefix)]
+            ks = [k for k in d if prefix in k]
             return max(max(d[k]) for k in ks)
-        act = biggest(valu_db, "SQ_ACTIVE_INST_VALU", "trk_kernel_tp")
-        insts = biggest(valu_db, "SQ_INSTS_VALU", "trk_kernel_tp")
-        gui = biggest(grbm_db, "GRBM_GUI_ACTIVE", "trk_kernel_tp")
+        act = biggest(valu_db, "SQ_ACTIVE_INST_VALU", "trk_kernel_tp<0>")
+        insts = biggest(valu_db, "SQ_INSTS_VALU", "trk_kernel_tp<0>")
+        gui = biggest(grbm_db, "GRBM_GUI_ACTIVE", "trk_kernel_tp<0>")
         hbm = 2.0 * f_tp + w_tp
         n_many = int(os.environ.get("SGX_MANY_CHANNELS", "3072"))      # bench.py's --many-channels default
         samples = n_many * 500 * 38192.0
