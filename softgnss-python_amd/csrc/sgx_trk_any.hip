@@ -3,7 +3,7 @@
 // ... records, and int16 / uint8 records at sampling rates the typed kernels exclude.  The per-sample body of
 // sgx_trk_kernel.inc with every sample fetched where it lies, at any byte address (the reference seeks BYTES,
 // tracking.py:107, so a channel may start inside a sample of the file - it does there, too), converted the way numpy's
-// float64 arithmetic promotes it.  Compatibility before speed: ~3 us per code period and channel.
+// float64 arithmetic promotes it.  Compatibility before speed: ~5 us per code period for 8 channels (tools/any_type_probe.py).
 #include "sgx_trk_common.h"
 
 #define TRK_MULTI 1

@@ -314,6 +314,37 @@ __device__ __forceinline__ double any_sample(const int8_t* __restrict__ p, int k
     }
 }
 
+// the 16 samples of a group (sample i0 + b of the block at p + b * sizeof(T)); samples outside [0, blk) are zero and not read
+template <typename T>
+__device__ __forceinline__ void any_group_t(const int8_t* __restrict__ p, int i0, int blk, double (&xd)[16]) {
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+        T v = T(0);
+        if ((unsigned)(i0 + b) < (unsigned)blk) v = reinterpret_cast<const AnyAt<T>*>(p + (long long)b * (long long)sizeof(T))->v;
+        xd[b] = (double)v;
+    }
+}
+__device__ __forceinline__ void any_group(const int8_t* __restrict__ p, int kind, int i0, int blk, double (&xd)[16]) {
+    switch (kind) {                      // (wave-uniform: one branch per group, not per sample)
+    case SGX_DT_INT8: any_group_t<signed char>(p, i0, blk, xd); break;
+    case SGX_DT_UINT8: any_group_t<unsigned char>(p, i0, blk, xd); break;
+    case SGX_DT_INT16: any_group_t<short>(p, i0, blk, xd); break;
+    case SGX_DT_UINT16: any_group_t<unsigned short>(p, i0, blk, xd); break;
+    case SGX_DT_INT32: any_group_t<int>(p, i0, blk, xd); break;
+    case SGX_DT_UINT32: any_group_t<unsigned>(p, i0, blk, xd); break;
+    case SGX_DT_INT64: any_group_t<long long>(p, i0, blk, xd); break;
+    case SGX_DT_UINT64: any_group_t<unsigned long long>(p, i0, blk, xd); break;
+    case SGX_DT_FLOAT32: any_group_t<float>(p, i0, blk, xd); break;
+    case SGX_DT_FLOAT16: {
+#pragma unroll
+        for (int b = 0; b < 16; ++b)
+            xd[b] = ((unsigned)(i0 + b) < (unsigned)blk) ? (double)__half2float(reinterpret_cast<const AnyAt<__half>*>(p + 2 * b)->v) : 0.0;
+        break;
+    }
+    default: any_group_t<double>(p, i0, blk, xd); break;
+    }
+}
+
 __device__ __forceinline__ uint4 load_group(const int8_t* __restrict__ rec, long long addr, long long limit) {
     if (addr > limit) addr = limit;   // never read past the allocation (data of a stopped block is unused)
     return *reinterpret_cast<const uint4*>(rec + addr);

@@ -1599,6 +1599,33 @@ def test_track_any_sample_type_against_the_oracle(tmp_path):
                 assert t2.track(fid) is None and t2.series is None
 
 
+def test_track_float32_where_a_group_meets_two_switches():
+    """26 Msps: 12.7 samples per half chip, so a 16-sample group often holds the prompt ramp's switch AND the early / late
+    one - the per-sample kernel's group path then takes the samples one by one with the switches as compares; 61.38 Msps:
+    the group sums.  Arbitrary float32 values against the oracle."""
+    m = pkg()
+    for fs, IF in ((26000000.0, 6500000.0), (61380000.0, 15345000.0)):
+        ms = 30
+        s = m.Settings()
+        os_ = orc.OracleSettings()
+        for o in (s, os_):
+            o.samplingFreq, o.IF, o.numberOfChannels, o.msToProcess, o.dataType = fs, IF, 2, float(ms), 'float32'
+        n = s.samplesPerCode
+        sc = m.synth.Scene.make(0xFE200 + n, fs, IF, [2, 5], [1750.0, -3300.0], [n // 3, n - 5], [9, 8])
+        rec8 = m.synth.generate(sc, m.synth.record_length(n, ms))
+        arr = (rec8.astype(np.float64) * 0.173 - 0.02).astype("<f4")
+        prn = np.array([2, 5])
+        freq = np.array([IF + 1750.0, IF - 3300.0])
+        phase = (np.array([n // 3, n - 5], dtype=np.int64)) * 4
+        want = orc.stack_series(orc.track(os_, dict(PRN=prn, acquiredFreq=freq, codePhase=phase.astype(np.float64),
+                                                    status=['T'] * 2), arr))
+        ctx = m.engine.get_context(s, 0)
+        chans = [(int(prn[i]), float(freq[i]), float(phase[i])) for i in range(2)]
+        got, done = ctx.track(ctx.upload_bytes(arr.view(np.int8)), chans, ms, data_type=m._native.DT_FLOAT32)
+        assert ctx.timing()["track_kernel"] == 6 and np.all(done == ms)
+        assert np.array_equal(got[:, 0], want[:, 0]) and _trk_err(got, want) < TRK_TOL, fs
+
+
 def test_track_low_rate_int16_and_uint8_against_the_oracle():
     """int16 and uint8 records at a sampling rate below 16 x the chip rate (5.456 MHz: 5.3 samples per chip) - which the
     typed kernels exclude and round 3 refused - on the per-sample kernel, against the oracle."""
