@@ -204,9 +204,11 @@ int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset,
  * tracked through them EXACTLY when every sample of the window is m 2^-k for one k and 16-bit integers m (floats written
  * from ADC samples, or normalised by a power of two) and the channels start on samples: the integers go through the int8
  * / int16 kernels and the correlator series are scaled back, which no rounding of the reference's float64 arithmetic can
- * tell from the real thing.  Everything else - arbitrary float32, float64, float16, the wider integers, int16 / uint8 at
- * low sampling rates - is read sample by sample where it lies and promoted to float64 as numpy promotes it (the
- * per-sample kernel, sgx_trk_any.hip: slower, same contract).  Complex types are not tracked (the reference's
+ * tell from the real thing.  Other float32 records, and SGX_DT_FLOAT64, run the latency-mode kernel on samples scaled by a
+ * power of two (the window is scanned once for its largest |x|; exact both ways).  Everything else - float16, the wider
+ * integers, int16 / uint8 at low sampling rates, float records with NaN / infinite samples or channels that start inside
+ * a sample - is read sample by sample where it lies and promoted to float64 as numpy promotes it (the per-sample kernel,
+ * sgx_trk_any.hip: slower, same contract).  Complex types are not tracked (the reference's
  * discriminators fail on them). */
 #define SGX_DT_INT8  0
 #define SGX_DT_INT16 1

@@ -74,6 +74,8 @@ int sgx_if_require(const sgx_if* r, size_t end);
 // float32 records by exact narrowing to int8 / int16 (sgx_trk_f32.hip)
 int sgx_track_float32(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const sgx_chan_init* ch, int32_t n_ch, int32_t ms,
                       double* out, int32_t* ms_done);
+int sgx_track_float64(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const sgx_chan_init* ch, int32_t n_ch, int32_t ms,
+                      double* out, int32_t* ms_done);
 #define SGX_IF_PAD 256
 
 struct sgx_ctx {

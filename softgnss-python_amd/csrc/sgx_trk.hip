@@ -68,8 +68,11 @@ __global__ __launch_bounds__(256) void trk_fill_kernel(double* __restrict__ out,
 // kind: SGX_DT_*.  int8 / uint8 / int16 run the typed kernels (sgx_trk2 / sgx_trk3 / sgx_trk_tp); every other type - and
 // int16 / uint8 at sampling rates below 16 x the chip rate - the per-sample kernel of sgx_trk_any.hip.
 // skip_bytes: Settings.skipNumberOfBytes, or what stands in for it (sgx_trk_f32.hip tracks a narrowed copy of a window).
+// fscale > 0 (float32 / float64 only): every sample the channels can reach is finite and at most 128 / fscale in magnitude
+// (sgx_trk_f32.hip has scanned the window; fscale is a power of two) - the record then runs the latency-mode kernel, which
+// scales the samples by it on conversion; the correlator series are scaled back here.  0: the per-sample kernel.
 int sgx_track_kind(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const sgx_chan_init* ch, int32_t n_ch,
-                   int32_t ms, double* out, int32_t* ms_done, int kind, long long skip_bytes) {
+                   int32_t ms, double* out, int32_t* ms_done, int kind, long long skip_bytes, double fscale) {
     SGX_CHECK_ARG(c && r && ch && out && ms_done);
     const int sample_bytes = sgx_dt_bytes(kind);
     SGX_CHECK_ARG(sample_bytes >= 1);
@@ -111,7 +114,18 @@ int sgx_track_kind(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const s
     K.multi = (15.0 * 1.001 * S.codeFreqBasis / S.samplingFreq >= 1.0) ? 1 : 0;
     K.uns = sample_uns ? 1 : 0;
     K.kind = kind;
-    const bool typed = kind == SGX_DT_INT8 || kind == SGX_DT_UINT8 || kind == SGX_DT_INT16;
+    bool floaty = (kind == SGX_DT_FLOAT32 || kind == SGX_DT_FLOAT64) && fscale > 0.0 && !K.multi;
+    for (int i = 0; i < n_ch && floaty; ++i) {
+        // (a channel that starts inside a sample reads other values than the ones that were scanned)
+        const long long p0 = skip_bytes + (long long)ch[i].codePhase - rec_file_offset;
+        if (ch[i].prn != 0 && p0 >= 0 && p0 % sample_bytes != 0) floaty = false;
+    }
+    {
+        const char* fe = getenv("SGX_TRK_FLOAT_TYPED");   // '0': float records always on the per-sample kernel
+        if (fe && fe[0] == '0') floaty = false;
+    }
+    K.fscale = floaty ? fscale : 1.0;
+    const bool typed = kind == SGX_DT_INT8 || kind == SGX_DT_UINT8 || kind == SGX_DT_INT16 || floaty;
     const bool use_any = !typed || (K.multi && kind != SGX_DT_INT8);
     K.file_off = rec_file_offset;
     K.ms = ms;
@@ -221,10 +235,10 @@ int sgx_track_kind(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const s
     // Which kernel: the low-rate variant when a group can hold several switches of a ramp; throughput mode for more
     // than 128 int8 channels (one workgroup per channel anyway); the latency-mode kernel otherwise - with one workgroup
     // per (unit, correlator arm) when three times the CUs of one-per-unit are free (SGX_TRK_ARMS=3 keeps one per unit).
-    const bool use_tp = !use_any && !K.multi && K.split == 1 && n_ch > 128;   // (int8, uint8, int16)
+    const bool use_tp = !use_any && !floaty && !K.multi && K.split == 1 && n_ch > 128;   // (int8, uint8, int16)
     const bool use_v2 = !use_any && !K.multi && !use_tp;
     const char* ae = getenv("SGX_TRK_ARMS");
-    const bool arm_split = use_v2 && K.split == K.n_units && K.n_units >= 2 && 3 * ch8 * K.n_units <= cus_total &&
+    const bool arm_split = use_v2 && !floaty && K.split == K.n_units && K.n_units >= 2 && 3 * ch8 * K.n_units <= cus_total &&
                            !getenv("SGX_TRK_SPLIT") && !(ae && ae[0] == '3');
     // The speculative kernel (sgx_trk3.hip) serves all three arms from one lane, which rests on a 16-sample group (and one
     // sample on either side of it) meeting at most ONE chip boundary of ANY arm: the arms' boundaries lie at code phases
@@ -426,22 +440,35 @@ int sgx_track_kind(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const s
         if (rq != SGX_OK) return sgx_if_require(r, r->n);
     }
     hipEventElapsedTime(&c->timing.track_ms, c->ev[3], c->ev[4]);
+    if (floaty && K.fscale != 1.0) {
+        // the kernel tracked fscale x the record: the six correlator series carry the factor (a power of two: exact),
+        // everything the discriminators made of them (ratios) does not
+        const double un = 1.0 / K.fscale;
+        for (int i = 0; i < n_ch; ++i) {
+            if (ch[i].prn == 0) continue;
+            double* o = out + (size_t)i * SGX_NUM_SERIES * (size_t)ms;
+            const int dn = ms_done[i] < ms ? ms_done[i] : ms;
+            for (int sidx = 3; sidx <= 8; ++sidx)
+                for (int t = 0; t < dn; ++t) o[(size_t)sidx * ms + t] *= un;
+        }
+    }
     return SGX_OK;
 }
 
 extern "C" int sgx_track(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const sgx_chan_init* ch,
                          int32_t n_ch, int32_t ms, double* out, int32_t* ms_done) {
     SGX_CHECK_ARG(c);
-    return sgx_track_kind(c, r, rec_file_offset, ch, n_ch, ms, out, ms_done, SGX_DT_INT8, (long long)c->s.skipNumberOfBytes);
+    return sgx_track_kind(c, r, rec_file_offset, ch, n_ch, ms, out, ms_done, SGX_DT_INT8, (long long)c->s.skipNumberOfBytes, 0.0);
 }
 
 extern "C" int sgx_track_ex(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const sgx_chan_init* ch,
                             int32_t n_ch, int32_t ms, double* out, int32_t* ms_done, int32_t data_type) {
     SGX_CHECK_ARG(c);
     if (data_type == SGX_DT_FLOAT32) return sgx_track_float32(c, r, rec_file_offset, ch, n_ch, ms, out, ms_done);
+    if (data_type == SGX_DT_FLOAT64) return sgx_track_float64(c, r, rec_file_offset, ch, n_ch, ms, out, ms_done);
     if (sgx_dt_bytes(data_type) == 0) {
         sgx_set_error("sgx_track_ex: data_type %d is not one of SGX_DT_* (include/sgx.h)", (int)data_type);
         return SGX_E_ARG;
     }
-    return sgx_track_kind(c, r, rec_file_offset, ch, n_ch, ms, out, ms_done, data_type, (long long)c->s.skipNumberOfBytes);
+    return sgx_track_kind(c, r, rec_file_offset, ch, n_ch, ms, out, ms_done, data_type, (long long)c->s.skipNumberOfBytes, 0.0);
 }

@@ -58,7 +58,8 @@
 template <int SB>
 __device__ __forceinline__ int t2_map3_role(T2Shared& S, const int8_t* __restrict__ rec, long long rec_alloc, int ms,
                                             long long pos0, int member, int P, int n_units, bool uns, int tid,
-                                            unsigned long long* __restrict__ xbase, bool fast, bool prof_on, bool prof_any) {
+                                            unsigned long long* __restrict__ xbase, bool fast, bool prof_on, bool prof_any,
+                                            double fscale) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const long long limit = rec_alloc - 16;                  // bytes: the last 16-byte word that may be loaded
@@ -74,12 +75,14 @@ __device__ __forceinline__ int t2_map3_role(T2Shared& S, const int8_t* __restric
     int blk_pred;                    // block length the prepared samples are cut for
 
     // samples from block sample index END on belong to the next block: zeroed by an integer mask on the high dword
+    // (integer samples: the low dword of their fp64 value is zero anyway; float samples: both dwords)
 #define T2_CUT(XD, I0, END)                                                                                    \
     do {                                                                                                       \
         if ((I0) < (END) && (I0) + 16 > (END)) {                                                               \
             const int e_ = (END) - (I0);                                                                       \
             _Pragma("unroll") for (int b_ = 0; b_ < 16; ++b_)                                                  \
-                (XD)[b_] = __hiloint2double(__double2hiint((XD)[b_]) & ((b_ - e_) >> 31), 0);                  \
+                (XD)[b_] = __hiloint2double(__double2hiint((XD)[b_]) & ((b_ - e_) >> 31),                      \
+                                            SB >= 4 ? (__double2loint((XD)[b_]) & ((b_ - e_) >> 31)) : 0);    \
         }                                                                                                      \
     } while (0)
     // The block's last, partial group is cut in the shadow too, for the length the block will most likely have (the
@@ -91,7 +94,7 @@ __device__ __forceinline__ int t2_map3_role(T2Shared& S, const int8_t* __restric
         i0 = g * 16 - head_;                                                                                   \
         ilo = i0 < 0 ? 0 : i0;                                                                                 \
         ilod = (double)ilo;                                                                                    \
-        t2_convert<SB>(raw, i0, uns, xd);                                                                           \
+        t2_convert<SB>(raw, i0, uns, xd, fscale);                                                                   \
         blk_pred = (BLK_PRED);                                                                                 \
         T2_CUT(xd, i0, blk_pred);                                                                              \
     } while (0)
@@ -136,7 +139,7 @@ __device__ __forceinline__ int t2_map3_role(T2Shared& S, const int8_t* __restric
             // end convert their bytes again and cut them at the real length
             const int lo_ = blk < blk_pred ? blk : blk_pred, hi_ = blk < blk_pred ? blk_pred : blk;
             if (__any(i0 < hi_ && i0 + 16 > lo_)) {
-                t2_convert<SB>(raw, i0, uns, xd);
+                t2_convert<SB>(raw, i0, uns, xd, fscale);
                 T2_CUT(xd, i0, blk);
             }
         }
@@ -215,7 +218,7 @@ __device__ __forceinline__ int t2_map3_role(T2Shared& S, const int8_t* __restric
                     Ac = __builtin_fma(x[b], Bb.x, Ac);
                     As = __builtin_fma(x[b], Bb.y, As);
                     const int keep = ~((b - bsw) >> 31);                  // all ones iff b >= bsw
-                    const double xt = __hiloint2double(__double2hiint(x[b]) & keep, 0);
+                    const double xt = __hiloint2double(__double2hiint(x[b]) & keep, SB >= 4 ? (__double2loint(x[b]) & keep) : 0);
                     Tc = __builtin_fma(xt, Bb.x, Tc);
                     Ts = __builtin_fma(xt, Bb.y, Ts);
                 }
@@ -245,7 +248,7 @@ __device__ __forceinline__ int t2_map3_role(T2Shared& S, const int8_t* __restric
             if (j0 >= blk) break;                              // (uniform: the whole unit lies beyond the block)
             const T2Raw<SB> rj = t2_load<SB>(rec, (pos & ~15ll) + (long long)gj * 16, limit);
             double xj[16];
-            t2_convert<SB>(rj, j0, uns, xj);
+            t2_convert<SB>(rj, j0, uns, xj, fscale);
             T2_CUT(xj, j0, blk);
             group(xj, j0, j0, (double)j0, CR.T[T2_W3 + j]);   // (j0 > 0: only the block's very first group starts before it)
         }
@@ -1073,7 +1076,7 @@ __global__ __launch_bounds__(T2_THREADS) void trk2_kernel(const int8_t* __restri
             done = t2_map1_role<SB>(S, rec + cc.pad, K.rec_alloc, K.ms, cc.pos0, unit, arm, tid, xbase, fast,
                                     K.code_basis / K.fs, K.spacing, K.uns != 0, prof_on, prof != nullptr);
         else
-            done = t2_map3_role<SB>(S, rec + cc.pad, K.rec_alloc, K.ms, cc.pos0, unit, P, K.n_units, K.uns != 0, tid, xbase, fast, prof_on, prof != nullptr);
+            done = t2_map3_role<SB>(S, rec + cc.pad, K.rec_alloc, K.ms, cc.pos0, unit, P, K.n_units, K.uns != 0, tid, xbase, fast, prof_on, prof != nullptr, K.fscale);
     } else if (wave == 4)
         done = t2_pll_role<SB>(S, K, cc, unit, member, owner, lane, P, ch, xbase, err, prof_on, prof);
     else if (wave == 5)
@@ -1101,7 +1104,11 @@ void sgx_trk2_launch(int n_blocks, hipStream_t st, const int8_t* rec, const int8
                                       lds_pad);                                                                        \
         trk2_kernel<SBV, ARMSV><<<n_blocks, T2_THREADS, (size_t)(lds_pad > 0 ? lds_pad : 0), st>>>(rec, codes, chans, out, done, K, prof, xch, err); \
     } while (0)
-    if (sample_bytes == 2) {
+    if (sample_bytes == 4) {          // float32 / float64: one workgroup per unit, all three arms (arms == 3)
+        T2_LAUNCH(4, 3);
+    } else if (sample_bytes == 8) {
+        T2_LAUNCH(8, 3);
+    } else if (sample_bytes == 2) {
         if (arms == 1) T2_LAUNCH(2, 1);
         else T2_LAUNCH(2, 3);
     } else {

@@ -21,10 +21,13 @@
 #define T2_PROF_STRIDE 192         // profile words per channel: [3 phases][64 members]
 #define T2_FIX 268435456.0         // 2^28: fixed-point scale of a granule's 48-bit payload (member sums are < 2^19)
 #define T2_FIX16 524288.0          // 2^19: the same for two-byte samples (member sums are < 2^28)
-// SB = bytes per IF sample (1: int8, 2: int16).  Positions are counted in samples everywhere; only the loads, the
-// fixed-point scale and the reported file position (bytes, tracking.py:107 / fid.tell(), tracking.py:255) depend on it.
+// SB = bytes per IF sample (1: int8 / uint8, 2: int16, 4: float32, 8: float64).  Positions are counted in samples
+// everywhere; only the loads, the fixed-point scale and the reported file position (bytes, tracking.py:107 / fid.tell(),
+// tracking.py:255) depend on it.  Float samples are scaled on conversion by a power of two of the record's (TrkConst::fscale,
+// exact) so that none exceeds 128: they then share the int8 scale of the granules, and the host scales the correlator
+// series back (exact again).
 template <int SB>
-__device__ __forceinline__ constexpr double t2_fix() { return SB == 1 ? T2_FIX : T2_FIX16; }
+__device__ __forceinline__ constexpr double t2_fix() { return SB == 2 ? T2_FIX16 : T2_FIX; }
 // ... when a member owns ceil(n_units / P) units its sum can be that many times larger: the scale drops by the next
 // power of two (exact), so the 48-bit payload still holds it
 template <int SB>
@@ -246,6 +249,8 @@ typedef double t2_v2d __attribute__((ext_vector_type(2)));
 template <int SB> struct T2Raw;
 template <> struct T2Raw<1> { uint4 a; };
 template <> struct T2Raw<2> { uint4 a, b; };
+template <> struct T2Raw<4> { uint4 q[4]; };
+template <> struct T2Raw<8> { uint4 q[8]; };
 
 // the (clamped) addresses of a lane's 16 samples, and the load from them: the arm-split map prepares the addresses in the
 // shadow of the previous block, so that the chain only holds the load itself
@@ -276,9 +281,12 @@ __device__ __forceinline__ T2Raw<SB> t2_load(const int8_t* __restrict__ rec, lon
     T2Raw<SB> r;
     if constexpr (SB == 1) {
         r.a = load_group(rec, first_sample, limit);
-    } else {
+    } else if constexpr (SB == 2) {
         r.a = load_group(rec, first_sample * 2, limit);
         r.b = load_group(rec, first_sample * 2 + 16, limit);
+    } else {
+#pragma unroll
+        for (int k = 0; k < SB; ++k) r.q[k] = load_group(rec, first_sample * SB + 16 * k, limit);
     }
     return r;
 }
@@ -299,11 +307,28 @@ __device__ __forceinline__ int t2_sample(const T2Raw<SB>& raw, int b, bool uns) 
     }
 }
 
-// 16 samples -> fp64, samples before the block's first one (i0 + b < 0) zeroed
+// 16 samples -> fp64, samples before the block's first one (i0 + b < 0) zeroed; float samples times fscale (a power of two)
 template <int SB>
-__device__ __forceinline__ void t2_convert(const T2Raw<SB>& raw, int i0, bool uns, double (&xd)[16]) {
+__device__ __forceinline__ void t2_convert(const T2Raw<SB>& raw, int i0, bool uns, double (&xd)[16], double fscale = 1.0) {
+    if constexpr (SB == 4) {
 #pragma unroll
-    for (int b = 0; b < 16; ++b) xd[b] = (i0 + b >= 0) ? (double)t2_sample<SB>(raw, b, uns) : 0.0;
+        for (int b = 0; b < 16; ++b) {
+            const uint4& q = raw.q[b >> 2];
+            const unsigned w = ((b & 3) == 0) ? q.x : ((b & 3) == 1) ? q.y : ((b & 3) == 2) ? q.z : q.w;
+            xd[b] = (i0 + b >= 0) ? (double)__uint_as_float(w) * fscale : 0.0;
+        }
+    } else if constexpr (SB == 8) {
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            const uint4& q = raw.q[b >> 1];
+            const double v = (b & 1) ? __hiloint2double((int)q.w, (int)q.z) : __hiloint2double((int)q.y, (int)q.x);
+            xd[b] = (i0 + b >= 0) ? v * fscale : 0.0;
+        }
+    } else {
+        (void)fscale;
+#pragma unroll
+        for (int b = 0; b < 16; ++b) xd[b] = (i0 + b >= 0) ? (double)t2_sample<SB>(raw, b, uns) : 0.0;
+    }
 }
 
 // 16 samples -> the HIGH dwords of their fp64 values (small integers: the low dword is zero); samples outside the

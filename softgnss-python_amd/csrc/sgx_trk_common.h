@@ -56,6 +56,7 @@ struct TrkConst {
     int multi;            // fewer than ~15 samples per chip: a 16-sample group can hold several chip switches
     int uns;              // one-byte samples are unsigned (Settings.dataType 'uint8')
     int kind;             // SGX_DT_* of the record's samples (read by trk_kernel_any; the other kernels are typed)
+    double fscale;        // float records on the typed kernel (sgx_trk2.hip): the power of two the samples are scaled by
 };
 
 struct TrkChan {

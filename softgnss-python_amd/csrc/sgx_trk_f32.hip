@@ -14,7 +14,16 @@
 
 // sgx_trk.hip
 int sgx_track_kind(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const sgx_chan_init* ch, int32_t n_ch,
-                   int32_t ms, double* out, int32_t* ms_done, int kind, long long skip_bytes);
+                   int32_t ms, double* out, int32_t* ms_done, int kind, long long skip_bytes, double fscale);
+
+// the power of two that brings a record whose largest |sample| is mx to at most 128 (what the typed kernels' fixed point
+// is cut for); 1 for an all-zero record
+static double scale_for(double mx) {
+    if (!(mx > 0.0)) return 1.0;
+    int ex = 0;
+    (void)frexp(mx, &ex);          // mx = m 2^ex, 1/2 <= m < 1
+    return ldexp(1.0, 7 - ex);
+}
 
 // [0]: largest |x| (float bits), [1]: smallest exponent of a sample's lowest set bit + 1024 (0x7FFFFFFF: no nonzero sample),
 // [2]: a sample that is not finite was seen
@@ -60,7 +69,10 @@ int sgx_track_float32(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
     SGX_CHECK_ARG(n_ch >= 1 && ms >= 1);
     const sgx_settings& S = c->s;
     const long long skip = (long long)S.skipNumberOfBytes;
-    auto generic = [&]() { return sgx_track_kind(c, r, rec_file_offset, ch, n_ch, ms, out, ms_done, SGX_DT_FLOAT32, skip); };
+    // the per-sample kernel (fs = 0), or the latency-mode kernel on samples scaled by the power of two fs
+    auto generic = [&](double fs = 0.0) {
+        return sgx_track_kind(c, r, rec_file_offset, ch, n_ch, ms, out, ms_done, SGX_DT_FLOAT32, skip, fs);
+    };
     {
         const char* ne = getenv("SGX_TRK_F32_NARROW");   // '0': always the per-sample kernel
         if (ne && ne[0] == '0') return generic();
@@ -120,7 +132,13 @@ int sgx_track_float32(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
         memcpy(&mxf, &h_st[0], sizeof(mxf));
         peak = ldexp((double)mxf, k);
     }
-    if (k > 120 || k < -120 || peak > 32767.0) return generic();   // arbitrary floats
+    {
+        const char* ne = getenv("SGX_TRK_F32_NARROW");   // '1': narrowing or the per-sample kernel (round-4 first cut)
+        float mxf;
+        memcpy(&mxf, &h_st[0], sizeof(mxf));
+        if (k > 120 || k < -120 || peak > 32767.0)       // arbitrary floats: the latency-mode kernel reads them as they are
+            return generic((ne && ne[0] == '1') ? 0.0 : scale_for((double)mxf));
+    }
     const bool narrow8 = peak <= 127.0;
     const int sb = narrow8 ? 1 : 2;
     // the integer record: the window only, its first sample at record byte 0
@@ -157,7 +175,7 @@ int sgx_track_float32(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
             const long long p0 = skip + (long long)ch[i].codePhase - rec_file_offset;
             hc[(size_t)i].codePhase = (double)((p0 - first) / 4 * sb);
         }
-        rc = sgx_track_kind(c, &tmp, 0, hc.data(), n_ch, ms, out, ms_done, narrow8 ? SGX_DT_INT8 : SGX_DT_INT16, 0);
+        rc = sgx_track_kind(c, &tmp, 0, hc.data(), n_ch, ms, out, ms_done, narrow8 ? SGX_DT_INT8 : SGX_DT_INT16, 0, 0.0);
         if (rc == SGX_OK) {
             // absoluteSample is fid.tell() in BYTES of the float file (tracking.py:255): integer-record bytes * 4 / sb
             // behind the window's first byte; the six correlator series carry the 2^k
@@ -176,4 +194,73 @@ int sgx_track_float32(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
     hipFree(tmp.d);
     tmp.d = nullptr;
     return rc;
+}
+
+// ---- float64 records: the same latency-mode kernel on samples scaled by a power of two, after one scan of the window -------
+// [0]: largest |x| (the bits of a non-negative double order like integers), [1]: a sample that is not finite was seen
+__global__ __launch_bounds__(256) void f64_scan_kernel(const double* __restrict__ x, long long n, unsigned long long* __restrict__ st) {
+    unsigned long long mx = 0ull, bad = 0ull;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const unsigned long long u = (unsigned long long)__double_as_longlong(x[i]) & 0x7FFFFFFFFFFFFFFFull;
+        if ((u >> 52) == 0x7FFull) bad = 1ull;
+        else mx = u > mx ? u : mx;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long omx = __shfl_down(mx, off), ob = __shfl_down(bad, off);
+        mx = omx > mx ? omx : mx;
+        bad |= ob;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&st[0], mx);
+        if (bad) atomicOr(&st[1], 1ull);
+    }
+}
+
+int sgx_track_float64(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const sgx_chan_init* ch, int32_t n_ch,
+                      int32_t ms, double* out, int32_t* ms_done) {
+    SGX_CHECK_ARG(c && r && ch && out && ms_done);
+    SGX_CHECK_ARG(n_ch >= 1 && ms >= 1);
+    const long long skip = (long long)c->s.skipNumberOfBytes;
+    auto generic = [&](double fs) {
+        return sgx_track_kind(c, r, rec_file_offset, ch, n_ch, ms, out, ms_done, SGX_DT_FLOAT64, skip, fs);
+    };
+    long long first = -1, last = -1;
+    for (int i = 0; i < n_ch; ++i) {
+        if (ch[i].prn == 0) continue;
+        const long long p0 = skip + (long long)ch[i].codePhase - rec_file_offset;
+        if (p0 < 0 || p0 % 8 != 0) return generic(0.0);   // (before the record: reported there; inside a sample: per-sample kernel)
+        first = (first < 0 || p0 < first) ? p0 : first;
+        last = p0 > last ? p0 : last;
+    }
+    if (first < 0) return generic(0.0);
+    const long long n_code = c->n_code;
+    long long end = last + ((long long)ms * (n_code + 64) + n_code) * 8;
+    if (end > (long long)r->n) end = (long long)r->n;
+    end &= ~7ll;
+    const long long n_samp = (end - first) / 8;
+    if (n_samp <= 0) return generic(0.0);
+    {
+        const int rq = sgx_if_require(r, (size_t)end);
+        if (rq != SGX_OK) return rq;
+    }
+    SGX_HIP(hipSetDevice(c->device));
+    unsigned long long* d_st = nullptr;
+    SGX_HIP(hipMalloc((void**)&d_st, 2 * sizeof(unsigned long long)));
+    unsigned long long h_st[2] = {0ull, 0ull};
+    hipError_t e = hipMemsetAsync(d_st, 0, sizeof(h_st), c->stream);
+    if (e == hipSuccess) {
+        const int grid = (int)((n_samp + 255) / 256 < 4096 ? (n_samp + 255) / 256 : 4096);
+        f64_scan_kernel<<<grid, 256, 0, c->stream>>>(reinterpret_cast<const double*>(r->d + first), n_samp, d_st);
+        e = hipMemcpyAsync(h_st, d_st, sizeof(h_st), hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d_st);
+    if (e != hipSuccess) {
+        sgx_set_error("float64 record scan: %s", hipGetErrorString(e));
+        return SGX_E_HIP;
+    }
+    if (h_st[1]) return generic(0.0);        // NaN or infinite samples: numpy's arithmetic carries them, so does the per-sample kernel
+    double mx;
+    memcpy(&mx, &h_st[0], sizeof(mx));
+    return generic(scale_for(mx));
 }

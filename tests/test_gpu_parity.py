@@ -1539,8 +1539,9 @@ def test_track_float32_record_by_exact_narrowing(tmp_path):
 
 def test_track_any_sample_type_against_the_oracle(tmp_path):
     """Settings.dataType is whatever numpy dtype the settings name (tracking.py:154): records of arbitrary float32 and
-    float64 values, float16, the wider integers - read sample by sample where they lie (sgx_trk_any.hip) and promoted
-    to float64 as numpy promotes them - against the oracle on the same bytes: block boundaries (byte positions of the
+    float64 values on the latency-mode kernel (scaled by a power of two on conversion, sgx_trk2.hip) and - float16, the
+    wider integers, or SGX_TRK_FLOAT_TYPED=0 - read sample by sample where they lie (sgx_trk_any.hip), promoted to
+    float64 as numpy promotes them - against the oracle on the same bytes: block boundaries (byte positions of the
     file, tracking.py:107, 255) exactly, the series to rounding.  A channel that starts INSIDE a sample of the file
     reads the bytes of two samples, as the reference does (int32: every bit pattern is a finite value).  Cooperating
     workgroups and one workgroup per channel agree; a short record ends the run like the reference's short read."""
@@ -1579,18 +1580,33 @@ def test_track_any_sample_type_against_the_oracle(tmp_path):
             t.track(fid)
             assert fid.tell() == int(want[-1, 0, ms - 1])
         ctx = m.engine.get_context(s, 0)
-        assert ctx.timing()["track_kernel"] == 6, dtype
+        floaty = dtype in ("float32", "float64")
+        assert ctx.timing()["track_kernel"] == (2 if floaty else 6), dtype
         scale = np.abs(want[:, 3:9]).max()
         assert np.array_equal(t.series[:, 0], want[:, 0]), (dtype, shift)
         assert _trk_err(t.series, want) < TRK_TOL, (dtype, shift, _trk_err(t.series, want), scale)
+        if floaty:
+            # the same record on the per-sample kernel, and with one workgroup per channel on the typed one
+            for env, kern in (({"SGX_TRK_FLOAT_TYPED": "0"}, 6), ({"SGX_TRK_SPLIT": "1"}, 2)):
+                os.environ.update(env)
+                try:
+                    tq = m.TrackingResult(a, device=0)
+                    tq.track(m.DeviceFile(ctx.upload_bytes(raw.view(np.int8)), 0))
+                finally:
+                    for k in env:
+                        os.environ.pop(k)
+                assert ctx.timing()["track_kernel"] == kern, (dtype, env)
+                assert np.array_equal(tq.series[:, 0], want[:, 0]) and _trk_err(tq.series, want) < TRK_TOL, (dtype, env)
         if dtype == "float32":
+            os.environ["SGX_TRK_FLOAT_TYPED"] = "0"      # (the checks below: the per-sample kernel's layouts)
             os.environ["SGX_TRK_SPLIT"] = "1"
             try:
                 t1 = m.TrackingResult(a, device=0)
                 t1.track(m.DeviceFile(ctx.upload_bytes(raw.view(np.int8)), 0))
             finally:
                 os.environ.pop("SGX_TRK_SPLIT")
-            assert ctx.timing()["track_members"] == 1
+                os.environ.pop("SGX_TRK_FLOAT_TYPED")
+            assert ctx.timing()["track_members"] == 1 and ctx.timing()["track_kernel"] == 6
             assert np.array_equal(t1.series[:, 0], want[:, 0]) and _trk_err(t1.series, want) < TRK_TOL
             # the record ends inside the run: nothing is set, like the reference's short read (tracking.py:159-163)
             raw[:16 + 20 * n].tofile(path)
@@ -1621,9 +1637,15 @@ def test_track_float32_where_a_group_meets_two_switches():
                                                     status=['T'] * 2), arr))
         ctx = m.engine.get_context(s, 0)
         chans = [(int(prn[i]), float(freq[i]), float(phase[i])) for i in range(2)]
-        got, done = ctx.track(ctx.upload_bytes(arr.view(np.int8)), chans, ms, data_type=m._native.DT_FLOAT32)
-        assert ctx.timing()["track_kernel"] == 6 and np.all(done == ms)
-        assert np.array_equal(got[:, 0], want[:, 0]) and _trk_err(got, want) < TRK_TOL, fs
+        for env, kern in (({"SGX_TRK_FLOAT_TYPED": "0"}, 6), ({}, 2)):
+            os.environ.update(env)
+            try:
+                got, done = ctx.track(ctx.upload_bytes(arr.view(np.int8)), chans, ms, data_type=m._native.DT_FLOAT32)
+            finally:
+                for k in env:
+                    os.environ.pop(k)
+            assert ctx.timing()["track_kernel"] == kern and np.all(done == ms)
+            assert np.array_equal(got[:, 0], want[:, 0]) and _trk_err(got, want) < TRK_TOL, (fs, kern)
 
 
 def test_track_low_rate_int16_and_uint8_against_the_oracle():
