@@ -99,7 +99,8 @@ typedef struct sgx_timing {
     float track_ms;          /* the tracking kernel */
     float synth_ms;          /* the generator kernel */
     float track_kernel;      /* which tracking kernel the last sgx_track ran: 2 latency-mode (sgx_trk2.hip), 3 throughput-mode
-                                (sgx_trk_tp.hip), 4 low-rate (sgx_trk_multi.hip), 5 speculative latency-mode (sgx_trk3.hip) */
+                                (sgx_trk_tp.hip), 4 low-rate (sgx_trk_multi.hip), 5 speculative latency-mode (sgx_trk3.hip),
+                                6 per-sample, any sample type (sgx_trk_any.hip) */
     float track_members;     /* workgroups per channel of that launch */
     float track_streamed;    /* 1: the kernel followed the watermark of a record that was still streaming in */
 } sgx_timing;
