@@ -1115,8 +1115,9 @@ __global__ __launch_bounds__(64) void acq_rowmax_peak_kernel(const double* __res
 
 // The acquisition on the four-step transform (sgx_fft.hip): every 38192-point transform is two kernels with register-resident
 // sub-transforms, the mixed-signal spectra are computed once per (block, phi) and read with a circular shift, results
-// land where they are needed (no device-to-device copies) and the host looks at the device twice before the fine search
-// (row maxima of ALL PRNs, then the second peaks) whatever the number of PRN chunks.
+// land where they are needed (no device-to-device copies) and the host looks at the device ONCE, at the very end of the
+// call (round 4: peaks, second peaks, the detections and their fine-search results arrive in one pinned page), whatever the
+// number of PRN chunks.
 static int acquire_four_step(sgx_ctx* c, SgxSig x, size_t n_samples, const int32_t* prn0,
                              int32_t n_prn, int32_t n_blocks, int32_t noncoh, double* carrFreq, double* codePhase,
                              double* peakMetric, int32_t* freqBin, int32_t* fineIdx, bool* handled) {
