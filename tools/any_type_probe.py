@@ -1,4 +1,4 @@
-"""(diagnosis) The per-sample kernel (trk_kernel_any) on float32 / float64 records of arbitrary values: kernel time per
+"""(diagnosis) float32 / float64 records of arbitrary values (trk2_kernel<4|8,3>; SGX_TRK_FLOAT_TYPED=0: trk_kernel_any): time per
 code period for 8 channels (cooperating workgroups) and for 256 (one workgroup each).
 GPU box:  python3 tools/any_type_probe.py [ms=2000]"""
 import importlib
