@@ -994,7 +994,10 @@ __global__ __launch_bounds__(64) void acq_publish_kernel(const PeakOut* __restri
             host->range_error = mo ? 1 + __builtin_ctzll(mo) : 0;
         }
     }
-    if (det) return;   // device-led: the host waits for seq2 (fine_rows_kernel's last workgroup), two kernel ends later
+    if (det) {         // device-led: `host` is a device-side copy of the page; fine_rows_kernel's last workgroup copies it
+        if (t == 0) host->seq = 0ull;   // to the real one and the host waits for seq2
+        return;
+    }
     __threadfence_system();
     __syncthreads();
     if (t == 0) __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1322,14 +1325,19 @@ static int acquire_four_step(sgx_ctx* c, SgxSig x, size_t n_samples, const int32
         const int max_rows = (n_prn + 1) / 2;   // two real signals per complex row; only the detections' rows are touched
         if ((rc = ensure_buf((void**)&c->d_fine[0], &c->cap_f0, (size_t)max_rows * sizeof(cplx) * (size_t)npts)) != SGX_OK) return rc;
     }
-    acq_publish_kernel<<<1, 64, 0, st>>>(d_po, d_second, n_prn, (CoarseLook*)c->d_look, seq, d_prn, S.acqThreshold, fine_len,
-                                         (long long)n_samples, device_led ? d_det : nullptr);
+    // (device-led: into a device-side copy of the page - a kernel that writes host memory ends with a flush the next one
+    // waits for, 5 us in front of the fine search)
+    CoarseLook* const d_stage = (CoarseLook*)(dsm + 700000);
+    acq_publish_kernel<<<1, 64, 0, st>>>(d_po, d_second, n_prn, device_led ? d_stage : (CoarseLook*)c->d_look, seq, d_prn,
+                                         S.acqThreshold, fine_len, (long long)n_samples, device_led ? d_det : nullptr);
     hipEventRecord(c->ev[1], st);
     SGX_HIP(hipGetLastError());
     if (device_led) {
         rc = sgx_fft_fine_search(&c->plan_fine, x, c->d_codes, nullptr, nullptr, n_prn, fine_len, d_sum, (double)n_samples, ts,
                                  1.0 / S.codeFreqBasis, c->d_fine[0], 4, uniq - 5, d_pv, d_pi, st, d_det,
-                                 ((CoarseLook*)c->d_look)->fine_bi, &((CoarseLook*)c->d_look)->seq2, seq);
+                                 ((CoarseLook*)c->d_look)->fine_bi, &((CoarseLook*)c->d_look)->seq2, seq,
+                                 reinterpret_cast<const int*>(d_stage), reinterpret_cast<int*>(c->d_look),
+                                 (int)(offsetof(CoarseLook, fine_bi) / sizeof(int)));
         if (rc != SGX_OK) return rc;
         hipEventRecord(c->ev[2], st);
         SGX_HIP(hipGetLastError());

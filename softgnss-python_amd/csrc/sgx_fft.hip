@@ -1181,6 +1181,11 @@ struct FineArgs {
     long long* out_bi;
     unsigned long long* out_seq;
     unsigned long long seq;
+    // ... after copying stage_words dwords of the coarse search's outcome from device memory (stage_src, filled by the
+    // publish kernel) to the same page (stage_dst): no kernel in front of the fine search writes host memory
+    const int* stage_src;
+    int* stage_dst;
+    int stage_words;
 };
 
 #define FINE_DONE_SLOT 80
@@ -1304,8 +1309,11 @@ __global__ __launch_bounds__(FF_TPB) void fine_rows_kernel(FineArgs a, int n_pai
     const int n_det_k = FA_NDET(a);
     const int n_pairs = a.det ? (FF_N1 / 2) * ((n_det_k + 1) / 2) : n_pairs_host;
     if ((int)blockIdx.x >= n_pairs) {
-        if (a.out_seq && n_pairs == 0 && blockIdx.x == 0 && threadIdx.x == 0)   // nothing detected: only the word
-            __hip_atomic_store(a.out_seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (a.out_seq && n_pairs == 0 && blockIdx.x == 0) {   // nothing detected: the coarse outcome and the word
+            for (int i = threadIdx.x; i < a.stage_words; i += FF_TPB) a.stage_dst[i] = a.stage_src[i];
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_store(a.out_seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         return;
     }
     extern __shared__ __attribute__((aligned(16))) char f4_smem[];
@@ -1449,6 +1457,7 @@ __global__ __launch_bounds__(FF_TPB) void fine_rows_kernel(FineArgs a, int n_pai
     }
     __syncthreads();
     if (!s_last) return;
+    for (int i = tid; i < a.stage_words; i += FF_TPB) a.stage_dst[i] = a.stage_src[i];   // (stored long before the word below)
     static_assert(FF_N1 / 2 == FF_TPB, "one partial per thread");
     for (int d = 0; d < n_det_k; ++d) {
         double bv = __hip_atomic_load(a.pv + (long long)d * (FF_N1 / 2) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1496,7 +1505,8 @@ int sgx_fft_fine_partials(void) { return FF_N1 / 2; }
 int sgx_fft_fine_search(const FftPlan* plan, SgxSig x, const int8_t* codes, const int* det_prn,
                         const int* det_phase, int n_det, long long len, const long long* d_sum, double n_mean, double ts,
                         double tc1, cplx* work, long long lo, long long hi, double* pv, long long* pi, hipStream_t st,
-                        const int* d_det, long long* out_bi, unsigned long long* out_seq, unsigned long long seq) {
+                        const int* d_det, long long* out_bi, unsigned long long* out_seq, unsigned long long seq,
+                        const int* stage_src, int* stage_dst, int stage_words) {
     // d_det != nullptr: device-led - the detection list is in device memory (n_det here = the most it can hold)
     if (!plan->tw_hi || !sgx_fft_fine_supported(plan->n) || n_det < 1 || n_det > 32) {
         sgx_set_error("sgx_fft_fine_search: %lld points not supported", (long long)plan->n);
@@ -1562,6 +1572,9 @@ int sgx_fft_fine_search(const FftPlan* plan, SgxSig x, const int8_t* codes, cons
     a.pi = pi;
     a.out_bi = d_det ? out_bi : nullptr;
     a.out_seq = d_det ? out_seq : nullptr;
+    a.stage_src = stage_src;
+    a.stage_dst = stage_dst;
+    a.stage_words = (d_det && stage_src && stage_dst) ? stage_words : 0;
     a.seq = seq;
     const int n_rows = (n_det + 1) / 2;
     const size_t lds_c = sizeof(cplx) * (FF_N1 * FF_C + FF_N1);

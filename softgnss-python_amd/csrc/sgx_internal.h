@@ -181,7 +181,9 @@ int sgx_fft_fine_search(const FftPlan* plan, SgxSig x, const int8_t* codes, cons
                         const int* d_det = nullptr /* device-led: [0] n_det, [1 + d] PRN index, [33 + d] code phase,
                                                       [80] arrival counter (zero) */,
                         long long* out_bi = nullptr /* device-led: [32] arg-max per detection (pinned page) ... */,
-                        unsigned long long* out_seq = nullptr /* ... then this word = seq */, unsigned long long seq = 0);
+                        unsigned long long* out_seq = nullptr /* ... then this word = seq */, unsigned long long seq = 0,
+                        const int* stage_src = nullptr /* device-led: dwords copied to stage_dst (the page) before the word */,
+                        int* stage_dst = nullptr, int stage_words = 0);
 bool sgx_fft4_supported(int64_t n);
 int sgx_fft4_row_blocks(void);
 int sgx_fft4_forward(const FftPlan* p, const cplx* in, cplx* work, cplx* out, int64_t rows, hipStream_t st,
