@@ -541,6 +541,9 @@ def main():
         if world == 1 and args.many_channels > 0:
             out["many_channels_other_types"] = leg("many_channels_other_types", many_typed_leg, pkg, ctx, rec, acq, n_code,
                                                    1024, min(300, max(20, args.ms - 20)))
+        if world == 1 and args.many_channels > 0:
+            out["float_records"] = leg("float_records", float_records_leg, pkg, ctx, rec, acq, n_code,
+                                       min(2000, max(20, args.ms - 20)))
         if world == 1 and not args.no_from_file:
             out["from_file"] = leg("from_file", from_file_leg, pkg, ctx, s, rec, rec_len, n_code, local, args, series,
                                    elapsed / args.steps * 1e3)
@@ -681,6 +684,30 @@ def many_typed_leg(pkg, ctx, rec, acq, n_code, nch=1024, ms=300):
         dev.free()
         out[name] = {"kernel_ms": float(np.min(ts)), "channel_s_per_s": nch * ms / float(np.min(ts)),
                      "locked_channels": int(np.sum(dn == ms)), "track_kernel": int(ctx.timing()["track_kernel"])}
+    return out
+
+
+def float_records_leg(pkg, ctx, rec, acq, n_code, ms=2000):
+    """Settings.dataType 'float32' / 'float64' records of ARBITRARY values (tracking.py:154 reads whatever numpy dtype the
+    settings name): the acquired channels x `ms` code periods of the record's start re-typed on the host and scaled by
+    a non-power of two, on the latency-mode kernel (sgx_trk2.hip <4,3> / <8,3>).  A side figure; never part of `value`."""
+    chans = [(int(c.PRN), float(c.acquiredFreq), float(c.codePhase)) for c in acq.channels if c.PRN != 0]
+    x8 = rec.download(0, (ms + 4) * n_code)
+    out = {"channels": len(chans), "ms": ms}
+    for name, arr, code in (("float32", (x8.astype(np.float64) * 0.37 + 0.011).astype("<f4"), pkg._native.DT_FLOAT32),
+                            ("float64", x8.astype(np.float64) * 1.2345e-3, pkg._native.DT_FLOAT64)):
+        isz = arr.dtype.itemsize
+        dev = ctx.upload_bytes(np.ascontiguousarray(arr).view(np.int8))
+        many = [(p, f, cp * isz) for p, f, cp in chans]
+        ts = []
+        for _ in range(3):
+            ser, dn = ctx.track(dev, many, ms, data_type=code)
+            ts.append(ctx.timing()["track_ms"])
+        dev.free()
+        t = float(np.min(ts))
+        out[name] = {"kernel_ms": t, "us_per_code_period": t * 1e3 / ms, "x_realtime": ms / t,
+                     "locked_channels": int(np.sum(dn == ms)), "track_kernel": int(ctx.timing()["track_kernel"]),
+                     "workgroups_per_channel": int(ctx.timing()["track_members"])}
     return out
 
 
