@@ -18,17 +18,24 @@ int sgx_track_kind(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const s
 
 // the power of two that brings a record whose largest |sample| is mx to at most 128 (what the typed kernels' fixed point
 // is cut for); 1 for an all-zero record
-static double scale_for(double mx) {
+// The typed kernel's granules are a fixed point cut for samples of comparable size (2^-28 of the largest): a record whose
+// largest sample towers 2^12 times above the mean |x| (an outlier, a burst) would lose the small ones' last digits against
+// the reference's float64 sums - such a record takes the per-sample kernel (0 is returned).
+static double scale_for(double mx, double sum_abs, long long n) {
     if (!(mx > 0.0)) return 1.0;
+    if (n > 0 && mx > 4096.0 * (sum_abs / (double)n)) return 0.0;
     int ex = 0;
     (void)frexp(mx, &ex);          // mx = m 2^ex, 1/2 <= m < 1
     return ldexp(1.0, 7 - ex);
 }
 
 // [0]: largest |x| (float bits), [1]: smallest exponent of a sample's lowest set bit + 1024 (0x7FFFFFFF: no nonzero sample),
-// [2]: a sample that is not finite was seen
-__global__ __launch_bounds__(256) void f32_scan_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ st) {
+// [2]: a sample that is not finite was seen; sum_abs: the sum of |x| over the finite samples (for a threshold only: the
+// order of its additions is not fixed)
+__global__ __launch_bounds__(256) void f32_scan_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ st,
+                                                       double* __restrict__ sum_abs) {
     unsigned mx = 0u, lo = 0x7FFFFFFFu, bad = 0u;
+    double sa = 0.0;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const unsigned u = __float_as_uint(x[i]) & 0x7FFFFFFFu;
         const unsigned e = u >> 23, m = u & 0x7FFFFFu;
@@ -40,6 +47,7 @@ __global__ __launch_bounds__(256) void f32_scan_kernel(const float* __restrict__
             const unsigned key = (unsigned)(lb + 1024);
             lo = key < lo ? key : lo;
             mx = u > mx ? u : mx;
+            sa += (double)__uint_as_float(u);
         }
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -47,11 +55,13 @@ __global__ __launch_bounds__(256) void f32_scan_kernel(const float* __restrict__
         mx = omx > mx ? omx : mx;
         lo = olo < lo ? olo : lo;
         bad |= ob;
+        sa += __shfl_down(sa, off);
     }
     if ((threadIdx.x & 63) == 0) {
         atomicMax(&st[0], mx);
         atomicMin(&st[1], lo);
         if (bad) atomicOr(&st[2], 1u);
+        if (sum_abs) atomicAdd(sum_abs, sa);
     }
 }
 
@@ -106,14 +116,14 @@ int sgx_track_float32(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
     }
     SGX_HIP(hipSetDevice(c->device));
     unsigned* d_st = nullptr;
-    SGX_HIP(hipMalloc((void**)&d_st, 3 * sizeof(unsigned)));
-    const unsigned h_init[3] = {0u, 0x7FFFFFFFu, 0u};
-    unsigned h_st[3] = {0u, 0u, 0u};
+    SGX_HIP(hipMalloc((void**)&d_st, 4 * sizeof(unsigned) + sizeof(double)));   // [3 words | pad | sum of |x|]
+    const unsigned h_init[6] = {0u, 0x7FFFFFFFu, 0u, 0u, 0u, 0u};
+    unsigned h_st[6] = {0u, 0u, 0u, 0u, 0u, 0u};
     const float* x = reinterpret_cast<const float*>(r->d + first);
     hipError_t e = hipMemcpyAsync(d_st, h_init, sizeof(h_init), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
         const int grid = (int)((n_samp + 255) / 256 < 4096 ? (n_samp + 255) / 256 : 4096);
-        f32_scan_kernel<<<grid, 256, 0, c->stream>>>(x, n_samp, d_st);
+        f32_scan_kernel<<<grid, 256, 0, c->stream>>>(x, n_samp, d_st, reinterpret_cast<double*>(d_st + 4));
         e = hipMemcpyAsync(h_st, d_st, sizeof(h_st), hipMemcpyDeviceToHost, c->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -137,7 +147,11 @@ int sgx_track_float32(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
         float mxf;
         memcpy(&mxf, &h_st[0], sizeof(mxf));
         if (k > 120 || k < -120 || peak > 32767.0)       // arbitrary floats: the latency-mode kernel reads them as they are
-            return generic((ne && ne[0] == '1') ? 0.0 : scale_for((double)mxf));
+        {
+            double sum_abs;
+            memcpy(&sum_abs, &h_st[4], sizeof(sum_abs));
+            return generic((ne && ne[0] == '1') ? 0.0 : scale_for((double)mxf, sum_abs, n_samp));
+        }
     }
     const bool narrow8 = peak <= 127.0;
     const int sb = narrow8 ? 1 : 2;
@@ -197,22 +211,29 @@ int sgx_track_float32(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
 }
 
 // ---- float64 records: the same latency-mode kernel on samples scaled by a power of two, after one scan of the window -------
-// [0]: largest |x| (the bits of a non-negative double order like integers), [1]: a sample that is not finite was seen
+// [0]: largest |x| (the bits of a non-negative double order like integers), [1]: a sample that is not finite was seen,
+// [2]: the sum of |x| over the finite samples (a double; for a threshold only)
 __global__ __launch_bounds__(256) void f64_scan_kernel(const double* __restrict__ x, long long n, unsigned long long* __restrict__ st) {
     unsigned long long mx = 0ull, bad = 0ull;
+    double sa = 0.0;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const unsigned long long u = (unsigned long long)__double_as_longlong(x[i]) & 0x7FFFFFFFFFFFFFFFull;
         if ((u >> 52) == 0x7FFull) bad = 1ull;
-        else mx = u > mx ? u : mx;
+        else {
+            mx = u > mx ? u : mx;
+            sa += __longlong_as_double((long long)u);
+        }
     }
     for (int off = 32; off > 0; off >>= 1) {
         const unsigned long long omx = __shfl_down(mx, off), ob = __shfl_down(bad, off);
         mx = omx > mx ? omx : mx;
         bad |= ob;
+        sa += __shfl_down(sa, off);
     }
     if ((threadIdx.x & 63) == 0) {
         atomicMax(&st[0], mx);
         if (bad) atomicOr(&st[1], 1ull);
+        atomicAdd(reinterpret_cast<double*>(&st[2]), sa);
     }
 }
 
@@ -245,8 +266,8 @@ int sgx_track_float64(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
     }
     SGX_HIP(hipSetDevice(c->device));
     unsigned long long* d_st = nullptr;
-    SGX_HIP(hipMalloc((void**)&d_st, 2 * sizeof(unsigned long long)));
-    unsigned long long h_st[2] = {0ull, 0ull};
+    SGX_HIP(hipMalloc((void**)&d_st, 3 * sizeof(unsigned long long)));
+    unsigned long long h_st[3] = {0ull, 0ull, 0ull};
     hipError_t e = hipMemsetAsync(d_st, 0, sizeof(h_st), c->stream);
     if (e == hipSuccess) {
         const int grid = (int)((n_samp + 255) / 256 < 4096 ? (n_samp + 255) / 256 : 4096);
@@ -260,7 +281,8 @@ int sgx_track_float64(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
         return SGX_E_HIP;
     }
     if (h_st[1]) return generic(0.0);        // NaN or infinite samples: numpy's arithmetic carries them, so does the per-sample kernel
-    double mx;
+    double mx, sum_abs;
     memcpy(&mx, &h_st[0], sizeof(mx));
-    return generic(scale_for(mx));
+    memcpy(&sum_abs, &h_st[2], sizeof(sum_abs));
+    return generic(scale_for(mx, sum_abs, n_samp));
 }

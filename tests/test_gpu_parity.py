@@ -1615,6 +1615,31 @@ def test_track_any_sample_type_against_the_oracle(tmp_path):
                 assert t2.track(fid) is None and t2.series is None
 
 
+def test_track_float32_record_with_an_outlier_takes_the_per_sample_kernel():
+    """The typed kernel's fixed point is cut for samples of comparable size; a float record whose largest sample towers
+    2^12 times above the mean |x| goes to the per-sample kernel (plain float64 sums, like the reference's) - and still
+    agrees with the oracle."""
+    m = pkg()
+    ms = 20
+    s = m.Settings()
+    s.dataType, s.numberOfChannels, s.msToProcess = 'float32', 3, float(ms)
+    n = s.samplesPerCode
+    rec8 = m.synth.generate(m.synth.Scene.default(), m.synth.record_length(n, ms))
+    a8 = orc.acquire(orc.OracleSettings(), rec8[:11 * n])
+    ch = orc.pre_run(orc.OracleSettings(numberOfChannels=3), a8)
+    arr = (rec8.astype(np.float64) * 0.37 + 0.011).astype("<f4")
+    arr[5 * n + 123] = np.float32(3.0e6)
+    phase = (np.asarray(ch["codePhase"], dtype=np.int64) - 1) * 4
+    so = orc.OracleSettings(numberOfChannels=3, msToProcess=float(ms), dataType='float32')
+    want = orc.stack_series(orc.track(so, dict(PRN=ch["PRN"], acquiredFreq=ch["acquiredFreq"],
+                                               codePhase=phase.astype(np.float64), status=['T'] * 3), arr))
+    ctx = m.engine.get_context(s, 0)
+    chans = [(int(ch["PRN"][i]), float(ch["acquiredFreq"][i]), float(phase[i])) for i in range(3)]
+    got, done = ctx.track(ctx.upload_bytes(arr.view(np.int8)), chans, ms, data_type=m._native.DT_FLOAT32)
+    assert ctx.timing()["track_kernel"] == 6 and np.all(done == ms)
+    assert np.array_equal(got[:, 0], want[:, 0]) and _trk_err(got, want) < TRK_TOL
+
+
 def test_track_float32_where_a_group_meets_two_switches():
     """26 Msps: 12.7 samples per half chip, so a 16-sample group often holds the prompt ramp's switch AND the early / late
     one - the per-sample kernel's group path then takes the samples one by one with the switches as compares; 61.38 Msps:
