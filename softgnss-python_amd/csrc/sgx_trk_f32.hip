@@ -83,10 +83,8 @@ int sgx_track_float32(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
     auto generic = [&](double fs = 0.0) {
         return sgx_track_kind(c, r, rec_file_offset, ch, n_ch, ms, out, ms_done, SGX_DT_FLOAT32, skip, fs);
     };
-    {
-        const char* ne = getenv("SGX_TRK_F32_NARROW");   // '0': always the per-sample kernel
-        if (ne && ne[0] == '0') return generic();
-    }
+    const char* ne = getenv("SGX_TRK_F32_NARROW");       // '0': no narrowing - every float32 record as floats
+    const bool no_narrow = ne && ne[0] == '0';
     long long first = -1, last = -1;
     for (int i = 0; i < n_ch; ++i) {
         if (ch[i].prn == 0) continue;
@@ -143,14 +141,13 @@ int sgx_track_float32(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
         peak = ldexp((double)mxf, k);
     }
     {
-        const char* ne = getenv("SGX_TRK_F32_NARROW");   // '1': narrowing or the per-sample kernel (round-4 first cut)
         float mxf;
         memcpy(&mxf, &h_st[0], sizeof(mxf));
-        if (k > 120 || k < -120 || peak > 32767.0)       // arbitrary floats: the latency-mode kernel reads them as they are
+        if (no_narrow || k > 120 || k < -120 || peak > 32767.0)   // arbitrary floats: the latency-mode kernel reads them as they are
         {
             double sum_abs;
             memcpy(&sum_abs, &h_st[4], sizeof(sum_abs));
-            return generic((ne && ne[0] == '1') ? 0.0 : scale_for((double)mxf, sum_abs, n_samp));
+            return generic(scale_for((double)mxf, sum_abs, n_samp));
         }
     }
     const bool narrow8 = peak <= 127.0;

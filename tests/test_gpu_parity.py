@@ -1517,6 +1517,15 @@ def test_track_float32_record_by_exact_narrowing(tmp_path):
         t2 = m.TrackingResult(a, device=0)
         t2.track(m.DeviceFile(ctx.upload_bytes(raw.view(np.int8)), 0))
         assert np.array_equal(t2.series, t.series)
+        # the same floats without narrowing: the latency-mode kernel's float instance
+        os.environ["SGX_TRK_F32_NARROW"] = "0"
+        try:
+            t3 = m.TrackingResult(a, device=0)
+            t3.track(m.DeviceFile(ctx.upload_bytes(raw.view(np.int8)), 0))
+        finally:
+            os.environ.pop("SGX_TRK_F32_NARROW")
+        assert m.engine.get_context(s, 0).timing()["track_members"] == 10
+        assert np.array_equal(t3.series[:, 0], want[:, 0]) and _trk_err(t3.series, want) < TRK_TOL, name
     # the integers themselves through the int8 kernel: the float run is that run, positions in float bytes
     s8 = m.Settings()
     s8.numberOfChannels, s8.msToProcess, s8.skipNumberOfBytes = 3, float(ms), 0
