@@ -1311,6 +1311,7 @@ __global__ __launch_bounds__(FF_TPB) void fine_rows_kernel(FineArgs a, int n_pai
     if ((int)blockIdx.x >= n_pairs) {
         if (a.out_seq && n_pairs == 0 && blockIdx.x == 0) {   // nothing detected: the coarse outcome and the word
             for (int i = threadIdx.x; i < a.stage_words; i += FF_TPB) a.stage_dst[i] = a.stage_src[i];
+            __threadfence_system();   // every wave's page stores are out before the barrier: the word's release covers thread 0's only
             __syncthreads();
             if (threadIdx.x == 0) __hip_atomic_store(a.out_seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -1457,7 +1458,9 @@ __global__ __launch_bounds__(FF_TPB) void fine_rows_kernel(FineArgs a, int n_pai
     }
     __syncthreads();
     if (!s_last) return;
-    for (int i = tid; i < a.stage_words; i += FF_TPB) a.stage_dst[i] = a.stage_src[i];   // (stored long before the word below)
+    for (int i = tid; i < a.stage_words; i += FF_TPB) a.stage_dst[i] = a.stage_src[i];
+    __threadfence_system();   // (each wave drains its own page stores; the barriers below then order them before the word)
+    __syncthreads();
     static_assert(FF_N1 / 2 == FF_TPB, "one partial per thread");
     for (int d = 0; d < n_det_k; ++d) {
         double bv = __hip_atomic_load(a.pv + (long long)d * (FF_N1 / 2) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -273,6 +273,17 @@ static int if_alloc(sgx_ctx* c, size_t n, sgx_if** out) {
     }
     if (!r->d) {
         e = hipMalloc((void**)&r->d, n + SGX_IF_PAD);
+        if (e != hipSuccess) {
+            // the parked allocation of an earlier record may be what is in the way: give it back and try once more
+            (void)hipGetLastError();
+            std::lock_guard<std::mutex> g(c->spare_mu);
+            if (c->spare_d) {
+                hipFree(c->spare_d);
+                c->spare_d = nullptr;
+                c->spare_cap = 0;
+                e = hipMalloc((void**)&r->d, n + SGX_IF_PAD);
+            }
+        }
         r->cap = n + SGX_IF_PAD;
     }
     if (e != hipSuccess) {
@@ -710,7 +721,8 @@ extern "C" int sgx_if_free(sgx_ctx* c, sgx_if* r) {
     if (c) {
         // keep ONE allocation (the larger), watermark and copy stream for the next record of this context
         std::lock_guard<std::mutex> g(c->spare_mu);
-        if (r->d && r->cap > c->spare_cap) {
+        const char* sp = getenv("SGX_IF_SPARE");   // '0': nothing is parked, a freed record's memory goes back at once
+        if (r->d && r->cap > c->spare_cap && !(sp && sp[0] == '0')) {
             if (c->spare_d) hipFree(c->spare_d);
             c->spare_d = r->d;
             c->spare_cap = r->cap;

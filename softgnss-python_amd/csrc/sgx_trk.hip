@@ -258,8 +258,11 @@ int sgx_track_kind(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const s
         }
         const double stepn = S.codeFreqBasis / S.samplingFreq;
         const char* v3e = getenv("SGX_TRK_V3");
+        // (the kernel's fused half-chip ramp puts the early / late boundaries on the ODD half chips: spacing 1/2 exactly;
+        // any other spacing whose gaps happen to pass at a higher sampling rate runs sgx_trk2.hip)
         use_v3 = use_v2 && sample_bytes == 1 && n_units3 >= 2 && n_units3 <= T3_MAXP && ch8 * n_units3 <= cus_total &&
-                 18.0 * stepn * 1.01 <= gap && !getenv("SGX_TRK_SPLIT") && !ae && !(v3e && v3e[0] == '0');
+                 fabs(d - 0.5) < 1e-12 && 18.0 * stepn * 1.01 <= gap && !getenv("SGX_TRK_SPLIT") && !ae &&
+                 !(v3e && v3e[0] == '0');
     }
     const char* le = getenv("SGX_TRK_LDSPAD");   // dynamic LDS per workgroup (bytes); default: one workgroup per CU
     const int lds_pad_coop = le ? atoi(le) : 90112;

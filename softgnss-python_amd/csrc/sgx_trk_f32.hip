@@ -26,6 +26,9 @@ static double scale_for(double mx, double sum_abs, long long n) {
     if (n > 0 && mx > 4096.0 * (sum_abs / (double)n)) return 0.0;
     int ex = 0;
     (void)frexp(mx, &ex);          // mx = m 2^ex, 1/2 <= m < 1
+    // (records near the ends of the float64 range: the scale, its reciprocal or the reference's own I^2 + Q^2 would
+    // leave the range - the per-sample kernel follows the reference there, overflow and all)
+    if (7 - ex > 900 || 7 - ex < -900) return 0.0;
     return ldexp(1.0, 7 - ex);
 }
 

@@ -1256,6 +1256,34 @@ def test_other_front_ends_against_oracle(fs, IF):
         assert np.array_equal(many[i], many[i % 2])
 
 
+def test_speculative_kernel_is_for_half_chip_spacing_only():
+    """60 Msps with dllCorrelatorSpacing 0.32: the gaps between the arms' chip boundaries (0.32 chips = 18.8 samples) pass
+    the 18-sample test of the speculative kernel, whose fused ramp is cut for a spacing of exactly half a chip - the host
+    must send this to the round-3 kernel (track_kernel 2), and the result must be the oracle's."""
+    m = pkg()
+    s = m.Settings()
+    os_ = orc.OracleSettings()
+    fs, IF = 60000000.0, 15000000.0
+    for o in (s, os_):
+        o.samplingFreq, o.IF = fs, IF
+        o.dllCorrelatorSpacing = 0.32
+        o.acqSatelliteList = range(1, 7)
+        o.numberOfChannels = 2
+        o.msToProcess = 60.0
+    n = s.samplesPerCode
+    sc = m.synth.Scene.make(0xFE000 + n, fs, IF, [2, 5], [1750.0, -3300.0], [n // 3, n - 5], [9, 8])
+    rec = m.synth.generate(sc, m.synth.record_length(n, 60))
+    a, t = _oracle_vs_gpu(m, s, os_, rec, 60)
+    assert t is not None
+    assert int(m.engine.get_context(s, 0).timing()["track_kernel"]) == 2
+    # the same front end at half a chip does take the speculative kernel, against the oracle as well
+    for o in (s, os_):
+        o.dllCorrelatorSpacing = 0.5
+    a, t = _oracle_vs_gpu(m, s, os_, rec, 60)
+    assert t is not None
+    assert int(m.engine.get_context(s, 0).timing()["track_kernel"]) == 5
+
+
 def test_tiny_runs_and_unsupported_sample_type(default_record):
     """msToProcess of 1, 2 and 3 code periods (first block, first filter update) and a non-int8 dataType."""
     g = load_golden("trk_default.npz")
