@@ -38,11 +38,18 @@
 // redundant filters in every member).
 #include "sgx_trk2_parts.h"
 
+#ifdef T3_TSEC
+#define T3_TS(n) do { if (T3_TSEC == (n) && prof_any && (tid & 127) == 0) S.tsec[par] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define T3_TS(n) do { } while (0)
+#endif
 #define T3_LANES 128               // map lanes = groups per unit (two waves)
 #define T3_UNIT (T3_LANES * 16)    // samples per unit
 #define T3_THREADS 448             // 2 x 2 map waves (two SETS, alternating blocks) + PLL wave (4) + DLL wave (5) + record wave (6)
 #define T3_MAXP 32                 // units per channel
+#ifndef T3_XLINE
 #define T3_XLINE 32                // granules per line: [2 parities][6 sums] lines of 32 units
+#endif
 #define T3_XABORT (12 * T3_XLINE)
 #define T3_XPLACE (12 * T3_XLINE + 8)
 #define T3_XCH_STRIDE 512          // words per channel (sgx_trk.hip sizes the allocation with the same figure)
@@ -75,12 +82,49 @@ struct T3Shared {
     T3Code code[2];
     T3Carr carr[2];
     unsigned long long acc[2][8];   // {arrival count << 56 | 48-bit fixed-point sum} of the six sums, by block parity
-    uint4 scratch[256];             // a map lane's 16 bytes, for reading single samples back by a dynamic index
+    uint4 scratch[256];             // a map lane's 16 bytes (outside the block: zeros), for reading single samples back by a dynamic index
+    uint4 raw[256];                 // the same bytes as loaded: a block that starts or ends a sample or two from where the pass put it
+    double2 btab[2][16];            // the sample phasors a set's pass ran with (the carr[] slot is another block's by the final pass)
     double rec[2][16];              // a block's 13 series values (member 0), stored one block later
     int flag[4];                    // [0] same-XCD placement, [1] abort seen by this workgroup
     int rflag[4];                   // [0] PLL wave, [1] DLL wave: number of blocks whose record values are in rec[]
     long long tpub[2];              // (profiling) time stamp of the member's publish, by block parity
+    long long tsec[2];              // (diagnosis, -DT3_TSEC=n) time stamp of point n of the final pass
 };
+
+// Two 64-bit values per lane -> sums over lanes 0..31 (rows 1) and 32..63 (rows 3) of either, the two chains interleaved
+// so that no DPP source was written by either of the two instructions before it (no wait states, no s_nop)
+__device__ __forceinline__ void t3_reduce2_half(unsigned long long& a, unsigned long long& b) {
+    unsigned a0 = (unsigned)a, a1 = (unsigned)(a >> 32), b0 = (unsigned)b, b1 = (unsigned)(b >> 32);
+    unsigned c0, c1, d0, d1;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_co_u32_dpp %4, vcc, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_addc_co_u32_dpp %5, vcc, %1, %1, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_co_u32_dpp %6, vcc, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_addc_co_u32_dpp %7, vcc, %3, %3, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_co_u32_dpp %0, vcc, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_addc_co_u32_dpp %1, vcc, %5, %5, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_co_u32_dpp %2, vcc, %6, %6 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_addc_co_u32_dpp %3, vcc, %7, %7, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_co_u32_dpp %4, vcc, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_addc_co_u32_dpp %5, vcc, %1, %1, vcc row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_co_u32_dpp %6, vcc, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_addc_co_u32_dpp %7, vcc, %3, %3, vcc row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_co_u32_dpp %0, vcc, %4, %4 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_addc_co_u32_dpp %1, vcc, %5, %5, vcc row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_co_u32_dpp %2, vcc, %6, %6 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_addc_co_u32_dpp %3, vcc, %7, %7, vcc row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_co_u32_dpp %4, vcc, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_addc_co_u32_dpp %5, vcc, %1, %1, vcc row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_co_u32_dpp %6, vcc, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_addc_co_u32_dpp %7, vcc, %3, %3, vcc row_bcast:15 row_mask:0xa bank_mask:0xf"
+        : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "=&v"(c0), "=&v"(c1), "=&v"(d0), "=&v"(d1)
+        :
+        : "vcc");
+    a = ((unsigned long long)c1 << 32) | c0;
+    b = ((unsigned long long)d1 << 32) | d0;
+}
 
 // rows 1 and 3 of the wave: v + (lane 15 of the row before) - joins two 16-lane row sums into a 32-lane sum
 __device__ __forceinline__ unsigned long long t3_addl_bc15(unsigned long long v) {
@@ -101,10 +145,10 @@ __device__ __forceinline__ unsigned long long t3_addl_bc15(unsigned long long v)
 #define T3_WB_UNIT 0
 #endif
 #define T3_WB_ON(unit, ch) ((unit) == T3_WB_UNIT && (ch) == 0)
-#define T3_WB_DECL long long wb_acc = 0, wb_t = (long long)__builtin_amdgcn_s_memtime();
+#define T3_WB_DECL long long wb_acc[2] = {0, 0}, wb_t = (long long)__builtin_amdgcn_s_memtime();
 #define T3_WB(on)                                                                \
     do {                                                                         \
-        if (on) wb_acc += (long long)__builtin_amdgcn_s_memtime() - wb_t;        \
+        if (on) wb_acc[it & 1] += (long long)__builtin_amdgcn_s_memtime() - wb_t; \
         wg_barrier();                                                            \
         if (on) wb_t = (long long)__builtin_amdgcn_s_memtime();                  \
     } while (0)
@@ -112,7 +156,7 @@ __device__ __forceinline__ unsigned long long t3_addl_bc15(unsigned long long v)
     if ((on) && (threadIdx.x & 63) == 0) {                                       \
         unsigned hw_;                                                            \
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));        \
-        printf("[waveprof] %s wave %d (simd %u cu %u): %.1f cycles from release to arrival\n", name, (int)(threadIdx.x >> 6), (hw_ >> 4) & 3u, (hw_ >> 8) & 15u, (double)wb_acc / (n)); \
+        printf("[waveprof] %s wave %d (simd %u cu %u): release -> arrival %.1f cycles on even blocks, %.1f on odd blocks\n", name, (int)(threadIdx.x >> 6), (hw_ >> 4) & 3u, (hw_ >> 8) & 15u, 2.0 * (double)wb_acc[0] / (n), 2.0 * (double)wb_acc[1] / (n)); \
     }
 #else
 #define T3_WB_ON(unit, ch) false
@@ -216,6 +260,7 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
         win = (unsigned)((((unsigned long long)hi << 32) | lo) >> (bi & 31)) & 0xFFu;
     }
     signed char* const scr = reinterpret_cast<signed char*>(S.scratch) + (tid & 255) * 16;   // the lane's 16 bytes in LDS
+    signed char* const rawb = reinterpret_cast<signed char*>(S.raw) + (tid & 255) * 16;      // ... as loaded
     const unsigned long long odd1 = 0xAAAAAAAAAAAAAAAAull, odd2 = 0xCCCCCCCCCCCCCCCCull;       // lanes with bit 0 / bit 1 set
     double magic = T2_MAGIC;
     T2_PIN(magic);
@@ -228,38 +273,53 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
     double alE = 0.0, alP = 0.0, alL = 0.0;                  // arm a's sum = al_a (all) + be_a (front)
     double beE = 0.0, beP = 0.0, beL = 0.0;
     double khd = 0.0;                // the half-chip boundary the lane follows
-    double mid = 0.0;                // floor(u) + 0.5 of the pass; NaN: nothing of this lane can change sides
+    double mid = 0.0;                // floor(u) + 0.5 of the pass
     double im1d = 0.0;               // (double)(ilo - 1): the anchor sample of the boundary position
-    int i0 = 0;                      // block index of the lane's first sample
+    int i0 = 0;                      // block index of the lane's first sample (for the block start the pass assumed)
     int cut = 0;                     // block length the pass was cut for
-    T2Raw<SB> nraw;                  // the lane's 16 samples of this set's NEXT block (requested two blocks ahead)
+    int bsw_s = 0;                   // the pass's switch sample: the lane's sample b lay in front of the boundary iff b < bsw_s
+    long long spos = pos0;           // the block start the pass assumed
+    unsigned r0 = 0, r1 = 0, r2 = 0, r3 = 0;   // the lane's bytes, zeroed outside the block: part A of a pass -> its part B
+    T2Raw<SB> nraw;                  // the lane's 16 samples of this set's NEXT block (requested one pass ahead)
+    uint4 held = make_uint4(0u, 0u, 0u, 0u);   // ... taken out of nraw at the end of part B: part A then starts without a wait for
+                                     // the loads in flight (the vector memory counter also counts the granule store just made)
     long long pos = pos0;            // first sample of the block the loop is at
+#ifdef T3_COUNT   // (diagnosis) how often this wave leaves the fast path: [0] start / length mispredicted, [1] patched, [2] accumulated again, [3] direct
+    int n_ev[4] = {0, 0, 0, 0};
+#endif
     long long npos_pred = 0;         // first sample the bytes in nraw were requested for
 
-    // The speculative pass over the lane's 16 samples `rw` of a block that starts at record sample POS with prompt code
-    // phase REM, slope STEP (1 / STEP ~ INV) and length CUT, with the sample phasors of table CARR.  NEXT >= 0: once the
-    // samples are converted, the bytes of this set's next block are requested INTO `nraw` for a block start NEXT (rw may
-    // be nraw itself: its registers are free by then, so nothing is copied at the loop's end - a copy there would wait
-    // for the request that was just made).
-    auto spec = [&](const T2Raw<SB>& rw, long long POS, double REM, double STEP, double INV, int CUT, const T3Carr& CARR,
-                    long long NEXT) {
+    // The block that follows a block (POS, REM, BLK) when the code rate stays what it is: its first sample is exact, its
+    // code phase exact up to the roundings of the reference's linspace (1e-12 chips), its length the one this phase gives
+    // at this rate.
+    auto advance = [&](long long& POS, double& REM, int& BLK, double STEP, double INV) {
+        POS += BLK;
+        REM = __builtin_fma((double)BLK, STEP, REM) - 1023.0;
+        int nb = (int)ceil((1023.0 - REM) * INV);
+        BLK = nb < 1 ? 1 : nb;
+    };
+
+    // THE SPECULATIVE PASS over the lane's 16 samples `rw` of a block that is taken to start at record sample POS with
+    // prompt code phase REM, slope STEP (1 / STEP ~ INV) and length CUT, with the sample phasors of table CARR.  In two
+    // parts, so that the block barrier can lie between them (the pass of block k + 2 starts right behind the final pass
+    // of block k and ends in the first half of block k + 1's period):
+    //   part A  the block's edges, the boundary, the chips, the two candidates; NEXT >= 0: the bytes of this set's next
+    //           block are requested INTO `nraw` for a block start NEXT (rw may be nraw itself: its registers are free by
+    //           then, so nothing is copied at the loop's end - a copy there would wait for the request just made);
+    //   part B  the sixteen samples' moments.
+    auto spec_a = [&](const uint4 rw, long long POS, double REM, double STEP, double INV, int CUT, const T3Carr& CARR,
+                      long long NEXT) {
         const int head = (int)(POS & 15);
         i0 = g * 16 - head;
         const int ilo = i0 < 0 ? 0 : i0;
         const int dlo = ilo - i0;
-        cut = CUT;
+        // (wave-uniform values as scalars: the final pass's test of them is then a scalar compare, not an exec mask)
+        cut = __builtin_amdgcn_readfirstlane(CUT);
+        spos = ((long long)__builtin_amdgcn_readfirstlane((int)(POS >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)POS);
         im1d = (double)(ilo - 1);
-        // the block's 16 sample phasors (one batch of reads, one wait)
-        t2_v2d Bt[16];
-        {
-            const unsigned ba = (unsigned)(unsigned long long)&CARR.T[T2_B];
-#define T3_BLD(i) asm volatile("ds_read_b128 %0, %1 offset:" #i "*16" : "=v"(Bt[i]) : "v"(ba))
-            T3_BLD(0); T3_BLD(1); T3_BLD(2); T3_BLD(3); T3_BLD(4); T3_BLD(5); T3_BLD(6); T3_BLD(7);
-            T3_BLD(8); T3_BLD(9); T3_BLD(10); T3_BLD(11); T3_BLD(12); T3_BLD(13); T3_BLD(14); T3_BLD(15);
-#undef T3_BLD
-        }
         // the lane's bytes with everything outside the block zeroed (only the block's first and last groups are cut)
-        unsigned r0 = rw.a.x, r1 = rw.a.y, r2 = rw.a.z, r3 = rw.a.w;
+        r0 = rw.x; r1 = rw.y; r2 = rw.z; r3 = rw.w;
+        *reinterpret_cast<uint4*>(rawb) = make_uint4(r0, r1, r2, r3);
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(i0 < 0 || i0 + 16 > CUT) != 0, 0)) {
             const int lo = i0 < 0 ? -i0 : 0;                 // first byte inside the block
             int hi = CUT - i0;                               // one past the last byte inside it
@@ -280,6 +340,7 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
         const int kb = khi >> 1;
         int bsw = dlo + (int)fu;                              // the lane's sample b lies behind the boundary iff b >= bsw
         bsw = bsw > 17 ? 17 : bsw;
+        bsw_s = bsw;
         const int sh = kb - ws;
         unsigned bits;
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(i0 < CUT && (unsigned)sh > 5u) != 0, 0)) {
@@ -300,12 +361,12 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
         beE = __hiloint2double((int)(odd & d01h), 0);
         beP = __hiloint2double((int)(~odd & d01h), 0);
         beL = __hiloint2double((int)(odd & d12h), 0);
-        // this lane can change only if the boundary is in reach of the group and the group has samples inside the block
+        // this lane's sums can change only if the boundary is in reach of the group and the group has samples inside the
+        // block (its candidates are zero otherwise); EVERY lane watches how far its boundary moves - a boundary that was
+        // out of reach and comes two samples nearer has crossed one (code rate steps of a kHz-wide DLL on a channel without
+        // signal: the wave then takes the direct path)
         const unsigned lv = (unsigned)(((bsw - 17) & (i0 - CUT)) >> 31);          // all ones: live
-        {
-            const double m_ = fu + 0.5;
-            mid = __hiloint2double((int)((lv & (unsigned)__double2hiint(m_)) | (~lv & 0x7FF80000u)), __double2loint(m_));
-        }
+        mid = fu + 0.5;
         // the two candidates: sample bsw - 1 (leaves the front when the boundary comes one sample earlier) and sample
         // bsw (joins it when the boundary comes one later); bytes outside the block are zero already
         const int bm = bsw - 1;
@@ -320,7 +381,28 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
             xmi = (int)scr[bmc];
             xpi = (int)scr[bpc];
         }
-        // samples -> high dwords of their fp64 values
+        const double xm = -(double)(int)((unsigned)xmi & vm);
+        const double xp = (double)(int)((unsigned)xpi & vp);
+        if (NEXT >= 0) {
+            // (everything that reads rw is above; the asm statement keeps it there)
+            asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+            npos_pred = NEXT;
+            nraw = t2_load<SB>(rec, (NEXT & ~15ll) + lane_off, limit);
+        }
+        pmc = xm * Bm.x;
+        pms = xm * Bm.y;
+        ppc = xp * Bp.x;
+        pps = xp * Bp.y;
+        const double dbm = (double)bmc - 7.5, dbp = (double)bpc - 7.5;
+        pm1c = pmc * dbm;
+        pm1s = pms * dbm;
+        pp1c = ppc * dbp;
+        pp1s = pps * dbp;
+        T2STAMP(prof_on && NEXT >= 0, 1);   // edges, boundary, chips, candidates (waits for the bytes), next request made
+    };
+    auto spec_b = [&](const T3Carr& CARR, bool shadow) {
+        // samples -> high dwords of their fp64 values (first: the final pass of the other set reads its parameters from LDS
+        // right now, the sixteen reads below would queue in front of them)
         unsigned xh[16];
         {
             const unsigned rr[4] = {r0, r1, r2, r3};
@@ -332,17 +414,20 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
                 for (int b = 0; b < 16; ++b) xh[b] = (unsigned)__double2hiint((double)(int)__builtin_amdgcn_sbfe((int)rr[b >> 2], 8 * (b & 3), 8));
             }
         }
-        double xm = -(double)(int)((unsigned)xmi & vm);
-        double xp = (double)(int)((unsigned)xpi & vp);
-        if (NEXT >= 0) {
-            // (everything that reads rw is above; the asm statements keep it there)
 #pragma unroll
-            for (int b = 0; b < 16; ++b) asm volatile("" : "+v"(xh[b]));
-            npos_pred = NEXT;
-            nraw = t2_load<SB>(rec, (NEXT & ~15ll) + lane_off, limit);
+        for (int b = 0; b < 16; ++b) asm volatile("" : "+v"(xh[b]));
+        // the block's 16 sample phasors (one batch of reads, one wait); lanes 0 .. 15 of the set keep a copy for the
+        // final pass's patches (CARR is another block's table by then)
+        t2_v2d Bt[16];
+        {
+            const unsigned ba = (unsigned)(unsigned long long)&CARR.T[T2_B];
+#define T3_BLD(i) asm volatile("ds_read_b128 %0, %1 offset:" #i "*16" : "=v"(Bt[i]) : "v"(ba))
+            T3_BLD(0); T3_BLD(1); T3_BLD(2); T3_BLD(3); T3_BLD(4); T3_BLD(5); T3_BLD(6); T3_BLD(7);
+            T3_BLD(8); T3_BLD(9); T3_BLD(10); T3_BLD(11); T3_BLD(12); T3_BLD(13); T3_BLD(14); T3_BLD(15);
+#undef T3_BLD
         }
-        T2STAMP(prof_on && NEXT >= 0, 1);   // boundary, chips, samples converted (waits for the bytes), next request made
-        const int fmask = (1 << bsw) - 1;                     // bit b set: sample b lies in front of the boundary
+        if ((tid & (T3_LANES - 1)) < 16) S.btab[set][tid & 15] = CARR.T[T2_B + (tid & 15)];
+        const int fmask = (1 << bsw_s) - 1;                   // bit b set: sample b lies in front of the boundary
         double a0c = 0.0, a0s = 0.0, a1c = 0.0, a1s = 0.0, g0c = 0.0, g0s = 0.0, g1c = 0.0, g1s = 0.0;
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Bt[0]), "+v"(Bt[1]), "+v"(Bt[2]), "+v"(Bt[3]), "+v"(Bt[4]), "+v"(Bt[5]), "+v"(Bt[6]),
                      "+v"(Bt[7]), "+v"(Bt[8]), "+v"(Bt[9]), "+v"(Bt[10]), "+v"(Bt[11]), "+v"(Bt[12]), "+v"(Bt[13]), "+v"(Bt[14]),
@@ -364,32 +449,32 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
             g1c = __builtin_fma(xf1, Bt[b].x, g1c);
             g1s = __builtin_fma(xf1, Bt[b].y, g1s);
         }
-        T2STAMP(prof_on && NEXT >= 0, 3);   // accumulation
         tc = a0c; ts = a0s; t1c = a1c; t1s = a1s;
         fc = g0c; fs_ = g0s; f1c = g1c; f1s = g1s;
-        pmc = xm * Bm.x;
-        pms = xm * Bm.y;
-        ppc = xp * Bp.x;
-        pps = xp * Bp.y;
-        const double dbm = (double)bmc - 7.5, dbp = (double)bpc - 7.5;
-        pm1c = pmc * dbm;
-        pm1s = pms * dbm;
-        pp1c = ppc * dbp;
-        pp1s = pps * dbp;
+        T2STAMP(prof_on && shadow, 3);   // accumulation
     };
 
     {
-        // set 0 owns the even blocks: block 0's pass runs here; set 1 requests the bytes of block 1
+        // set 0 owns the even blocks: block 0's pass runs here.  Set 1 owns the odd ones: block 1's pass runs here as well,
+        // with block 0's rates.  Either requests the bytes of its next block (2 / 3) where block 0's rates put it.
         const T3Code& C0 = S.code[0];
         T2_FP_TOP
-        if (set == 0) {
-            nraw = t2_load<SB>(rec, (pos0 & ~15ll) + lane_off, limit);
-            spec(nraw, pos0, C0.start[1], C0.step, C0.inv_step, C0.blk, S.carr[0], pos0 + 2ll * C0.blk);
-        } else {
-            npos_pred = pos0 + C0.blk;
-            nraw = t2_load<SB>(rec, (npos_pred & ~15ll) + lane_off, limit);
-        }
+        long long p = pos0;
+        double rm = C0.start[1];
+        int bl = C0.blk;
+        const double st0 = C0.step, iv0 = C0.inv_step;
+        if (set == 1) advance(p, rm, bl, st0, iv0);
+        long long p2 = p;
+        double rm2 = rm;
+        int bl2 = bl;
+        advance(p2, rm2, bl2, st0, iv0);
+        advance(p2, rm2, bl2, st0, iv0);
+        nraw = t2_load<SB>(rec, (p & ~15ll) + lane_off, limit);
+        spec_a(nraw.a, p, rm, st0, iv0, bl, S.carr[0], p2);
+        spec_b(S.carr[0], false);
+        held = nraw.a;
     }
+    bool pend_b = false;             // part B of this set's next pass is still to run
     int it = 0;
     for (; it < ms; ++it) {
         const int par = it & 1;
@@ -409,7 +494,8 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
         if ((it & 1) == set) {
         // ======== this set's block: the final pass (on the chain) ========
         __builtin_amdgcn_s_setprio(2);
-        const double eps = ep.x;
+        T3_TS(1);
+        double eps = ep.x;
         // group phasor G' = W1'[tid & 15] * W2'[(tid >> 4) & 7] * W3' (rotated tables)
         double gc, gs;
         {
@@ -418,27 +504,123 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
             gc = __builtin_fma(lc, w3.x, -(ls * w3.y));
             gs = __builtin_fma(lc, w3.y, ls * w3.x);
         }
+        bool direct = false;
+        double aI0, aQ0, aI1, aQ1, aI2, aQ2;                  // the lane's six sums: arm 0 early, 1 prompt, 2 late
+        // (either path below defines them; the statement costs nothing and spares the plain path six initialisations)
+        asm volatile("" : "=v"(aI0), "=v"(aQ0), "=v"(aI1), "=v"(aQ1), "=v"(aI2), "=v"(aQ2));
         // ---- where the boundary is now: u' = (kh - h'(ilo - 1)) / (2 step'); r = u' - (floor(u) + 1/2) ----
         double r = (khd - __builtin_fma(im1d, step + step, rem + rem)) * (0.5 * inv_step) - mid;
-        double aI0, aQ0, aI1, aQ1, aI2, aQ2;                  // the lane's six sums: arm 0 early, 1 prompt, 2 late
-        bool direct = false;
+        // ONE test for everything that is not the plain case (each term of it uniform or rare): the boundary within 1e-7
+        // samples of a sample or moved by two; a block that does not lie where the pass put it; a code rate at which 18
+        // samples span half a chip; tables the PLL wave evaluated in full
+        bool plain;
         {
-            const double a = fabs(r) - 0.5;                   // > 0: the boundary crossed a sample; NaN: this lane cannot change
+            const double a = fabs(r) - 0.5;                   // > 0: the boundary crossed a sample
+            plain = !((fabs(a) < 1e-7) | (a > 1.0) | (blk != cut) | ((int)pos != (int)spos) | (step > step_max) | (ep.y != 0.0));
+        }
+#ifdef T3_CHECK
+        bool chk_moved = false;
+        int chk_dpos = 0;
+        const double chk_gc = gc, chk_gs = gs;
+#endif
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!plain) != 0, 0)) {
+            unsigned long long me = 0, mb = 0;
+            // The pass ran two blocks back: the block starts `dpos` samples from where it was put and is `blk - cut` samples
+            // longer than it was cut (either in a few per cent of the blocks, a sample or two).  The samples' ABSOLUTE
+            // positions, code phases and carrier phases do not depend on where the block was taken to start, so the lanes
+            // keep what they have with their block indices moved - except the lanes that hold the block's first and last
+            // samples, where [lo_s, hi_s) of the lane's bytes were inside the block for the pass and [lo_f, hi_f) are now:
+            // a sample or two that cannot change sides of the lane's boundary are PATCHED in or out - raw byte, the pass's
+            // sample phasor, the side the pass put it on; anything else accumulates again.
+            const int dpos = (int)(pos - spos);
+            if (__builtin_expect(blk != cut || dpos != 0, 0)) {   // (wave-uniform)
+                const bool same_win = ((pos ^ spos) & ~15ll) == 0;
+#ifdef T3_CHECK
+                chk_moved = true;
+                chk_dpos = dpos;
+#endif
+                const int i0n = i0 - dpos;
+                int lo_s = -i0, hi_s = cut - i0, lo_f = -i0n, hi_f = blk - i0n;
+                lo_s = lo_s < 0 ? 0 : (lo_s > 16 ? 16 : lo_s);
+                hi_s = hi_s < 0 ? 0 : (hi_s > 16 ? 16 : hi_s);
+                lo_f = lo_f < 0 ? 0 : (lo_f > 16 ? 16 : lo_f);
+                hi_f = hi_f < 0 ? 0 : (hi_f > 16 ? 16 : hi_f);
+                if (hi_s < lo_s) hi_s = lo_s;                 // (a lane beyond the block's end: an empty range)
+                if (hi_f < lo_f) hi_f = lo_f;
+                // runs of changed bytes: [a1, b1) at the block's start, [a2, b2) at its end
+                const int a1 = lo_s < lo_f ? lo_s : lo_f, b1 = lo_s < lo_f ? lo_f : lo_s;
+                const int a2 = hi_s < hi_f ? hi_s : hi_f, b2 = hi_s < hi_f ? hi_f : hi_s;
+                const int cnt = (b1 - a1) + (b2 - a2);
+                // Which side of the lane's boundary a changed sample lies on: a lane that follows the boundary AT the block's
+                // start (half chip 0: the code phase wraps where the block starts, so every sample inside the block lies
+                // behind it) or AT its end (half chip 2046: every sample inside lies in front) knows by construction, and
+                // its boundary moved WITH the block - nothing of it crosses.  Any other lane keeps the side the pass saw
+                // unless the sample is one of the two next to the boundary, which the rate step may move across.
+                const bool edge0 = khd < 0.5, edge_e = khd > 2045.5 && khd < 2046.5;
+                const bool st = b1 > a1, en = b2 > a2;
+                const int ca = st ? a1 : a2, cb = st ? b1 : b2;
+                // (edge0: ... unless the code phase the block starts with is not positive - the reference's own roundings
+                // leave it at -1e-13 while the code NCO rests at its basis - and its first sample lies IN FRONT)
+                const bool hard = cnt > 2 || (st && en) ||
+                                  (cnt > 0 && (khd > 2046.5 || (edge0 && (bsw_s != lo_s || !(rem > 0.0))) ||
+                                               (edge_e && bsw_s < hi_s) ||
+                                               (!edge0 && !edge_e && bsw_s >= ca && bsw_s <= cb)));
+                me = same_win ? __builtin_amdgcn_ballot_w64(hard) : ~0ull;
+#ifdef T3_COUNT
+                n_ev[0] += 1;
+                if (me == 0 && __builtin_amdgcn_ballot_w64(cnt > 0) != 0) n_ev[1] += 1;
+#endif
+                if (me == 0) {
+                    if (ep.y == 0.0 && __builtin_amdgcn_ballot_w64(cnt > 0) != 0) {
+                        const double sgn = st ? (lo_f < lo_s ? 1.0 : -1.0) : (hi_f > hi_s ? 1.0 : -1.0);
+#pragma unroll 1
+                        for (int k = 0; k < 2; ++k) {
+                            const bool act = k < cnt;
+                            const int bb = act ? ca + k : 0;
+                            const int xi = uns ? (int)reinterpret_cast<const unsigned char*>(rawb)[bb] : (int)rawb[bb];
+                            const double x = act ? sgn * (double)xi : 0.0;
+                            const double2 Bb = S.btab[set][bb];   // the table the pass ran with
+                            const double wgt = (double)bb - 7.5;
+                            const double c0 = x * Bb.x, s0 = x * Bb.y;
+                            tc += c0;
+                            ts += s0;
+                            t1c = __builtin_fma(c0, wgt, t1c);
+                            t1s = __builtin_fma(s0, wgt, t1s);
+                            if (edge0 ? false : (edge_e ? true : bb < bsw_s)) {
+                                fc += c0;
+                                fs_ += s0;
+                                f1c = __builtin_fma(c0, wgt, f1c);
+                                f1s = __builtin_fma(s0, wgt, f1s);
+                            }
+                        }
+                        if (cnt > 0 && (edge0 || edge_e)) {    // (nothing of this lane crosses: no candidates; the guard stays)
+                            pmc = pms = pm1c = pm1s = 0.0;
+                            ppc = pps = pp1c = pp1s = 0.0;
+                        }
+                    }
+                    cut = blk;
+                }
+                // the lanes' block indices where the block really starts
+                i0 = i0n;
+                im1d -= (double)dpos;
+                spos = pos;
+            }
+            r = (khd - __builtin_fma(im1d, step + step, rem + rem)) * (0.5 * inv_step) - mid;   // (the lanes' indices may have moved)
+            const double a = fabs(r) - 0.5;
             const bool bad = (fabs(a) < 1e-7) || (a > 1.0);   // within 1e-7 samples of a sample / moved by two
             // (a code rate at which 18 samples span half a chip or more - a code NCO driven percents off by a kHz-wide DLL
             // on a channel without signal -: a group can meet two boundaries, every wave takes the direct path)
-            const unsigned long long mb = __builtin_amdgcn_ballot_w64(bad) | (step > step_max ? ~0ull : 0ull);
-            unsigned long long me = 0;
-            if (__builtin_expect(blk != cut, 0))              // (wave-uniform: all lanes were cut for the same length)
-                me = __builtin_amdgcn_ballot_w64((i0 < (blk > cut ? blk : cut)) && (i0 + 16 > (blk < cut ? blk : cut)));
+            mb = __builtin_amdgcn_ballot_w64(bad) | (step > step_max ? ~0ull : 0ull);
             if (__builtin_expect((mb | me) != 0 || ep.y != 0.0, 0)) {
-                const T2Raw<SB> again = t2_load<SB>(rec, (pos & ~15ll) + lane_off, limit);   // (an L2 hit: read a block ago)
-                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) HERE: left to the compiler, a path that does not read every
-                                                      // register of `again` costs every block a full wait at the loop's top
+#ifdef T3_COUNT
+                n_ev[mb != 0 ? 3 : 2] += 1;
+#endif
                 if (mb != 0) {
+                    direct = true;
                     // DIRECT: per-sample chips from the exact linspace ramps (tracking.py:166-188), this block's own
                     // sample phasors; the group phasor less the 7.5 samples of rate step the PLL wave turned W3 by
-                    direct = true;
+                    const T2Raw<SB> again = t2_load<SB>(rec, (pos & ~15ll) + lane_off, limit);
+                    __builtin_amdgcn_s_waitcnt(0x0F70);
                     int budget = 1 << 20;
                     while (lds_peek(&C.xflag) != it + 1 && --budget) __builtin_amdgcn_s_sleep(1);
                     const double stE = C.stp[0], stP = C.stp[1], stL = C.stp[2];
@@ -448,7 +630,7 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
                     double dI0 = 0.0, dQ0 = 0.0, dI1 = 0.0, dQ1 = 0.0, dI2 = 0.0, dQ2 = 0.0;
                     const int head = (int)(pos & 15);
                     const int j0 = g * 16 - head;
-#pragma unroll 1
+        #pragma unroll 1
                     for (int b = 0; b < 16; ++b) {
                         const int i = j0 + b;
                         if ((unsigned)i < (unsigned)blk) {
@@ -471,16 +653,61 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
                         }
                     }
                     aI0 = dI0; aQ0 = dQ0; aI1 = dI1; aQ1 = dQ1; aI2 = dI2; aQ2 = dQ2;
+        #ifdef T3_CHECK_AT
+                    if (it == T3_CHECK_AT && (blockIdx.x & 7) == 7) {
+                        // (diagnosis) what the fused evaluation would have given this lane
+                        const double dm = __hiloint2double((__double2hiint(r + 0.5) >> 31) & 0x3FF00000, 0);
+                        const double dp = __hiloint2double((__double2hiint(0.5 - r) >> 31) & 0x3FF00000, 0);
+                        const double z0c = __builtin_fma(dp, ppc, __builtin_fma(dm, pmc, fc));
+                        const double z0s = __builtin_fma(dp, pps, __builtin_fma(dm, pms, fs_));
+                        const double z1c = __builtin_fma(dp, pp1c, __builtin_fma(dm, pm1c, f1c));
+                        const double z1s = __builtin_fma(dp, pp1s, __builtin_fma(dm, pm1s, f1s));
+                        const double Fc = __builtin_fma(-eps, z1s, z0c), Fs = __builtin_fma(eps, z1c, z0s);
+                        const double Tc = __builtin_fma(-eps, t1s, tc), Ts = __builtin_fma(eps, t1c, ts);
+                        const double tI = __builtin_fma(gs, Tc, gc * Ts), fI = __builtin_fma(gs, Fc, gc * Fs);
+                        const double fI0 = __builtin_fma(beE, fI, alE * tI), fI1 = __builtin_fma(beP, fI, alP * tI), fI2 = __builtin_fma(beL, fI, alL * tI);
+                        if (fabs(fI0 - dI0) + fabs(fI1 - dI1) + fabs(fI2 - dI2) > 1e-3 || fabs(fabs(r) - 0.5) < 1e-3)
+                            printf("[t3 at] unit %d tid %d i0 %d blk %d khd %.1f mid %.3f r %.9f bsw %d dm %.0f dp %.0f | fused E %.4f P %.4f L %.4f | direct E %.4f P %.4f L %.4f | al %.0f %.0f %.0f be %.0f %.0f %.0f | pm %.3f pp %.3f rem %.6e step %.12e\n",
+                                   unit, tid, i0, blk, khd, mid, r, bsw_s, dm, dp, fI0, fI1, fI2, dI0, dI1, dI2, alE, alP, alL, beE, beP, beL, pmc, ppc, rem, step);
+                    }
+        #endif
                 } else {
-                    // accumulate again with the true code phase, rate and length.  The sample phasors stay those of the
-                    // speculative pass - the table of the previous block, which the PLL wave overwrites only after
-                    // this member has published - so that eps and the rotated W3 still apply; only when the PLL wave
-                    // says so (respec: it evaluated this block's tables in full, eps = 0) are they this block's own.
-                    spec(again, pos, rem, step, inv_step, blk, (it == 0 || ep.y != 0.0) ? CR : S.carr[par ^ 1], -1ll);
+                    const T2Raw<SB> again = t2_load<SB>(rec, (pos & ~15ll) + lane_off, limit);   // (an L2 hit: read before)
+                    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) HERE: left to the compiler, a path that does not read every
+                                                          // register of `again` costs every block a full wait at the loop's top
+                    // Accumulate again with the true start, code phase, rate and length and THIS block's own sample
+                    // phasors.  The rotated tables carry the 7.5 samples of the two-block rate step for lanes whose
+                    // moments stem from the older table (theta = 7.5 eps); these lanes' do not: G' e^{-j theta}, no
+                    // first-order term, and the factor 1 + 10.625 eps^2 that the other lanes' second-order term leaves
+                    // in their sums (the recorded sums are multiplied by its inverse, off the chain).
+                    spec_a(again.a, pos, rem, step, inv_step, blk, CR, -1ll);
+                    spec_b(CR, false);
                     r = (khd - __builtin_fma(im1d, step + step, rem + rem)) * (0.5 * inv_step) - mid;   // (no move left)
+                    if (ep.y == 0.0) {
+                        const double th = 7.5 * eps;
+                        const double k2 = __builtin_fma(-17.5 * eps, eps, 1.0);   // 1 - theta^2 / 2 + 10.625 eps^2
+                        const double hc = __builtin_fma(th, gs, k2 * gc), hs = __builtin_fma(-th, gc, k2 * gs);
+                        gc = hc;
+                        gs = hs;
+                        eps = 0.0;
+                    }
                 }
             }
         }
+
+#ifdef T3_DIAG_AT
+        if (it == T3_DIAG_AT && (blockIdx.x & 7) == 7 && unit == 4 && tid == 8) {
+            int budget_ = 1 << 20;
+            while (lds_peek(&C.xflag) != it + 1 && --budget_) __builtin_amdgcn_s_sleep(1);
+            const double stP_ = C.stp[1], sP_ = C.start[1];
+            const int ii = i0 + 8;
+            const double tt = ramp_at(ii, stP_, sP_);
+            printf("[t3 diag] it %d pos %lld blk %d i %d rem %a step %a inv %a stpP %a startP %a t %.17g ceil %.1f | khd %.1f mid %.3f im1d %.1f r-0.5 %.6e direct %d\n",
+                   it, (long long)pos, blk, ii, rem, step, inv_step, stP_, sP_, tt, ceil(tt), khd, mid, im1d, r - 0.5, (int)direct);
+        }
+#endif
+        T3_TS(2);
+        T2STAMP(prof_on, 2);   // group phasor, where the block really lies, the boundary's guard
         if (!direct) {
             // 1.0 where the boundary crossed a sample downwards / upwards (arithmetic on the sign bit; the candidates of a
             // lane that cannot change are zero, whatever r is)
@@ -504,15 +731,20 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
             aQ2 = __builtin_fma(beL, fQ, alL * tQ);
         }
 #ifdef T3_CHECK
-        // (diagnosis build) every lane's six sums against the direct evaluation
-        if (!direct) {
+        // (diagnosis build) every lane's six sums against the direct evaluation: the first blocks, and every block whose
+        // start or length the pass had mispredicted
+#ifndef T3_CHECK_ALL
+#define T3_CHECK_ALL 0
+#endif
+        if ((!direct || T3_CHECK_ALL) && (it < 6 || chk_moved || T3_CHECK_ALL)) {
             const T2Raw<SB> again = t2_load<SB>(rec, (pos & ~15ll) + lane_off, limit);
             int budget = 1 << 20;
             while (lds_peek(&C.xflag) != it + 1 && --budget) __builtin_amdgcn_s_sleep(1);
             const double stE = C.stp[0], stP = C.stp[1], stL = C.stp[2];
             const double sE = C.start[0], sP = C.start[1], sL = C.start[2];
-            const double e75 = 7.5 * eps;
-            const double hc = __builtin_fma(e75, gs, gc), hs = __builtin_fma(-e75, gc, gs);
+            const double e75 = 7.5 * ep.x;
+            const double gc0 = chk_gc, gs0 = chk_gs;
+            const double hc = __builtin_fma(e75, gs0, gc0), hs = __builtin_fma(-e75, gc0, gs0);
             double dI0 = 0.0, dQ0 = 0.0, dI1 = 0.0, dQ1 = 0.0, dI2 = 0.0, dQ2 = 0.0;
             const int j0 = g * 16 - (int)(pos & 15);
             for (int b = 0; b < 16; ++b) {
@@ -533,13 +765,22 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
                 }
             }
             const double e_ = fabs(aI0 - dI0) + fabs(aQ0 - dQ0) + fabs(aI1 - dI1) + fabs(aQ1 - dQ1) + fabs(aI2 - dI2) + fabs(aQ2 - dQ2);
-            if (e_ > 1e-3 && blockIdx.x < 8 * 19 && (blockIdx.x & 7) == 0 && it < 6)
-                printf("[t3 check] it %d unit %d tid %d i0 %d cut %d blk %d khd %.1f mid %.3f r %.6f | E %.4f/%.4f P %.4f/%.4f L %.4f/%.4f | al %.0f %.0f %.0f be %.0f %.0f %.0f | t %.3f f %.3f eps %.3e\n",
-                       it, unit, tid, i0, cut, blk, khd, mid, r, aI0, dI0, aI1, dI1, aI2, dI2, alE, alP, alL, beE, beP, beL, tc, fc, eps);
+#ifdef T3_CHECK_AT
+            if (it == T3_CHECK_AT && (blockIdx.x & 7) == 7) {
+                double sa = aI1, sd = dI1;
+                for (int o = 32; o >= 1; o >>= 1) { sa += __shfl_xor(sa, o); sd += __shfl_xor(sd, o); }
+                if (lane == 0) printf("[t3 at] unit %2d wave %d: prompt I of the wave %.4f, direct %.4f, direct flag %d blk %d cut %d\n", unit, tid >> 6, sa, sd, (int)direct, blk, cut);
+            }
+#endif
+            if (e_ > 1e-3)
+                printf("[t3 check] ch %d it %d unit %d tid %d i0 %d cut %d blk %d dpos %d khd %.1f mid %.3f r %.6f bsw %d | E %.4f/%.4f P %.4f/%.4f L %.4f/%.4f | al %.0f %.0f %.0f be %.0f %.0f %.0f | t %.3f f %.3f eps %.3e\n",
+                       (int)(blockIdx.x & 7), it, unit, tid, i0, cut, blk, chk_dpos, khd, mid, r, bsw_s, aI0, dI0, aI1, dI1, aI2, dI2, alE, alP, alL, beE, beP, beL, tc, fc, ep.x);
         }
 #endif
+        T2STAMP(prof_on, 4);   // patch, first-order correction, rotation, three arms
         // fixed point: the raw bits of fma(a, 2^28, 1.5 2^52) are bias + round(a 2^28); sums of them carry the sum of the
         // integers in their low 48 bits whatever the biases add up to
+        T3_TS(3);
         const double lane_fix = uns ? T2_FIX * 0.5 : T2_FIX;
         constexpr unsigned long long res_mask = 0xFFFFFFFFFFFFull;
         unsigned long long q[6];
@@ -557,6 +798,7 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
         // transposing reduction inside each row of 16 lanes; exchange order I_P Q_P I_E Q_E I_L Q_L
         unsigned long long vpe, vl;
         t3_reduce6(q, odd1, odd2, vpe, vl);
+        T3_TS(4);
         {
             const int rl = lane & 15;
             if (rl < 6) {
@@ -575,18 +817,36 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
         }
         T2STAMP(prof_on, 5);   // published (or handed to the lanes that publish)
         __builtin_amdgcn_s_setprio(0);
-        } else if (it + 1 < ms) {
-            // ======== the other set's block: this set accumulates the NEXT block with this block's rates (in the shadow).
-            // Its first sample is pos + blk; its code phase is rem + blk step - 1023 up to the roundings of the
-            // reference's linspace (1e-12 chips: the final pass sees the exact value, its guard is 2.7e-9); its length
-            // the one this code phase gives at this block's rate.
-            const double nrem = __builtin_fma((double)blk, step, rem) - 1023.0;
-            int nblk = (int)ceil((1023.0 - nrem) * inv_step);
-            nblk = nblk < 1 ? 1 : nblk;
-            const long long npos = pos + blk;
-            if (__builtin_expect((npos & ~15ll) != (npos_pred & ~15ll), 0))    // (the bytes were requested for a block start
-                nraw = t2_load<SB>(rec, (npos & ~15ll) + lane_off, limit);     //  in another 16-byte window: once in ~100 blocks)
-            spec(nraw, npos, nrem, step, inv_step, nblk, CR, npos + 2ll * nblk);
+        if (it + 2 < ms) {
+            // ======== part A of the pass of this set's NEXT block, it + 2, with this block's rates (in the shadow of this
+            // block's exchange and loop filter).  Its first sample is pos + blk + (the length block it + 1 will most likely
+            // have), its code phase follows from this block's; the final pass sees the exact values (its guard is 2.7e-9).
+            long long p2 = pos;
+            double rm2 = rem;
+            int bl2 = blk;
+            advance(p2, rm2, bl2, step, inv_step);
+            advance(p2, rm2, bl2, step, inv_step);
+            if (__builtin_expect((p2 & ~15ll) != (npos_pred & ~15ll), 0)) {    // (the bytes were requested for a block start
+                nraw = t2_load<SB>(rec, (p2 & ~15ll) + lane_off, limit);       //  in another 16-byte window)
+                held = nraw.a;
+            }
+            long long p4 = p2;
+            double rm4 = rm2;
+            int bl4 = bl2;
+            advance(p4, rm4, bl4, step, inv_step);
+            advance(p4, rm4, bl4, step, inv_step);
+            spec_a(held, p2, rm2, step, inv_step, bl2, CR, p4);
+            pend_b = true;
+        }
+        } else if (pend_b) {
+            // ======== part B of that pass: the table is the one part A ran with - the block before this one's
+#ifdef T3_EXP_SLEEPB
+            __builtin_amdgcn_s_sleep(T3_EXP_SLEEPB);
+#endif
+            spec_b(S.carr[par ^ 1], true);
+            pend_b = false;
+            held = nraw.a;           // (requested a period ago: no wait to speak of)
+            asm volatile("" : "+v"(held.x), "+v"(held.y), "+v"(held.z), "+v"(held.w));
         }
         pos += blk;
         T2STAMP(prof_on, 6);   // next block's speculative pass
@@ -597,7 +857,118 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
     }
     T2_FP_PRINT(prof_on && lane == 0, 0, 8)
     T3_WB_PRINT(wb_on, "map", ms)
+#ifdef T3_COUNT
+    if (lane == 0 && (blockIdx.x & 7) == 0 && blockIdx.x < 8 * 20 && (n_ev[0] | n_ev[2] | n_ev[3]))
+        printf("[t3 count] unit %2d wave %d: %d blocks, start / length mispredicted %d, patched %d, accumulated again %d, direct %d\n", unit, tid >> 6, it, n_ev[0], n_ev[1], n_ev[2], n_ev[3]);
+#endif
     return it;
+}
+
+// TWO POLLS IN FLIGHT.  A granule is seen one round trip after the load that finds it left, so with one load at a time the
+// sums wait half a round trip on average for the next load to leave; two loads half a round trip apart halve that.  The
+// load that is still in flight when the other one has found the sums lands LATER, in the middle of the loop filter: its
+// destination must be a register the compiler never allocates.  So the whole poll is one asm statement on the physical
+// registers v[244:255], which nothing else in this kernel uses (the kernel needs ~220; tests/test_cabi_and_host.py checks
+// the disassembly), and the next poll starts by waiting for what the last one left.
+// Returns the number of rounds left (0: nothing found in `rounds` rounds - the caller looks at the abort word and polls
+// again); x: the granule of every active lane.  Call with the lanes that poll as the active lanes.
+#ifndef T3_POLL_GAP
+#define T3_POLL_GAP 5              // s_sleep units (64 cycles) between the first two loads
+#endif
+#ifndef T3_POLL2
+#define T3_POLL2 3                 // bit 0: the PLL wave, bit 1: the DLL wave (0: one load at a time, for comparison)
+#endif
+#define T3_STR2(x) #x
+#define T3_STR(x) T3_STR2(x)
+__device__ __forceinline__ int t3_poll1(unsigned long long& x, const unsigned long long* p, unsigned long long tag, int rounds) {
+    unsigned long long t;
+    int left;
+    asm volatile(
+        "s_waitcnt vmcnt(0)\n\t"
+        "global_load_dwordx2 v[252:253], %[p], off sc1\n\t"
+        "s_sleep " T3_STR(T3_POLL_GAP) "\n\t"
+        "global_load_dwordx2 v[254:255], %[p], off sc1\n\t"
+        "s_mov_b32 %[n], %[r]\n"
+        "1:\n\t"
+        "s_waitcnt vmcnt(1)\n\t"
+        "v_lshrrev_b64 %[t], 48, v[252:253]\n\t"
+        "v_cmp_eq_u64_e32 vcc, %[tag], %[t]\n\t"
+        "s_cmp_eq_u64 vcc, exec\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "global_load_dwordx2 v[252:253], %[p], off sc1\n\t"
+        "s_waitcnt vmcnt(1)\n\t"
+        "v_lshrrev_b64 %[t], 48, v[254:255]\n\t"
+        "v_cmp_eq_u64_e32 vcc, %[tag], %[t]\n\t"
+        "s_cmp_eq_u64 vcc, exec\n\t"
+        "s_cbranch_scc1 3f\n\t"
+        "global_load_dwordx2 v[254:255], %[p], off sc1\n\t"
+        "s_sub_u32 %[n], %[n], 1\n\t"
+        "s_cmp_lg_u32 %[n], 0\n\t"
+        "s_cbranch_scc1 1b\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "s_branch 4f\n"
+        "2:\n\t"
+        "v_mov_b64 %[x], v[252:253]\n\t"
+        "s_branch 4f\n"
+        "3:\n\t"
+        "v_mov_b64 %[x], v[254:255]\n"
+        "4:\n"
+        : [x] "+v"(x), [t] "=&v"(t), [n] "=&s"(left)
+        : [p] "v"(p), [tag] "s"(tag), [r] "s"(rounds)
+        : "vcc", "scc", "memory", "v252", "v253", "v254", "v255");
+    return left;
+}
+// the same for two granules per lane (p1, p2)
+__device__ __forceinline__ int t3_poll2(unsigned long long& x1, unsigned long long& x2, const unsigned long long* p1,
+                                        const unsigned long long* p2, unsigned long long tag, int rounds) {
+    unsigned long long t, m;
+    int left;
+    asm volatile(
+        "s_waitcnt vmcnt(0)\n\t"
+        "global_load_dwordx2 v[244:245], %[p1], off sc1\n\t"
+        "global_load_dwordx2 v[246:247], %[p2], off sc1\n\t"
+        "s_sleep " T3_STR(T3_POLL_GAP) "\n\t"
+        "global_load_dwordx2 v[248:249], %[p1], off sc1\n\t"
+        "global_load_dwordx2 v[250:251], %[p2], off sc1\n\t"
+        "s_mov_b32 %[n], %[r]\n"
+        "1:\n\t"
+        "s_waitcnt vmcnt(2)\n\t"
+        "v_lshrrev_b64 %[t], 48, v[244:245]\n\t"
+        "v_cmp_eq_u64_e32 vcc, %[tag], %[t]\n\t"
+        "v_lshrrev_b64 %[t], 48, v[246:247]\n\t"
+        "v_cmp_eq_u64_e64 %[m], %[tag], %[t]\n\t"
+        "s_and_b64 vcc, vcc, %[m]\n\t"
+        "s_cmp_eq_u64 vcc, exec\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "global_load_dwordx2 v[244:245], %[p1], off sc1\n\t"
+        "global_load_dwordx2 v[246:247], %[p2], off sc1\n\t"
+        "s_waitcnt vmcnt(2)\n\t"
+        "v_lshrrev_b64 %[t], 48, v[248:249]\n\t"
+        "v_cmp_eq_u64_e32 vcc, %[tag], %[t]\n\t"
+        "v_lshrrev_b64 %[t], 48, v[250:251]\n\t"
+        "v_cmp_eq_u64_e64 %[m], %[tag], %[t]\n\t"
+        "s_and_b64 vcc, vcc, %[m]\n\t"
+        "s_cmp_eq_u64 vcc, exec\n\t"
+        "s_cbranch_scc1 3f\n\t"
+        "global_load_dwordx2 v[248:249], %[p1], off sc1\n\t"
+        "global_load_dwordx2 v[250:251], %[p2], off sc1\n\t"
+        "s_sub_u32 %[n], %[n], 1\n\t"
+        "s_cmp_lg_u32 %[n], 0\n\t"
+        "s_cbranch_scc1 1b\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "s_branch 4f\n"
+        "2:\n\t"
+        "v_mov_b64 %[x1], v[244:245]\n\t"
+        "v_mov_b64 %[x2], v[246:247]\n\t"
+        "s_branch 4f\n"
+        "3:\n\t"
+        "v_mov_b64 %[x1], v[248:249]\n\t"
+        "v_mov_b64 %[x2], v[250:251]\n"
+        "4:\n"
+        : [x1] "+v"(x1), [x2] "+v"(x2), [t] "=&v"(t), [m] "=&s"(m), [n] "=&s"(left)
+        : [p1] "v"(p1), [p2] "v"(p2), [tag] "s"(tag), [r] "s"(rounds)
+        : "vcc", "scc", "memory", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251");
+    return left;
 }
 
 // ================================ PLL (wave 4) ================================
@@ -612,6 +983,8 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
     long long acc_map = 0, acc_xch = 0, acc_flt = 0, t_top = 0, t_arr = 0;   // SGX_TRK_PROFILE=1: per-member phase times
     double carrBasis = cc.acquiredFreq;
     double remCarr = 0.0, w_cur = (cc.acquiredFreq * 2.0) * M_PI, oldCarrNco = 0.0, oldCarrErr = 0.0;
+    double w_prev = w_cur;           // the rate of the block BEFORE the current one (block 0: its own): the next block's moments
+                                     // were accumulated with that block's sample phasors
     const double two_pi = 2 * M_PI;
     double k_a = K.k_carr_a, k_b = K.k_carr_b, inv_2pi = K.inv_2pi, c_hi = K.inv_2pifs_hi, c_lo = K.inv_2pifs_lo,
            inv_fs = K.inv_fs, fs = K.fs;
@@ -631,12 +1004,16 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
     double unfix = 1.0 / t2_fix_of<1>(P, K.n_units, K.uns != 0);
     T2_PIN(unfix);
     const bool w3 = lane >= 48;
-    const double ctr = w3 ? 7.5 : 0.0;
+    double ctr_fs = w3 ? 7.5 * K.inv_fs : 0.0;   // the map's moments are taken about the group's centre
+    T2_PIN(ctr_fs);
     const bool mine = (lane & 31) < P;
     unsigned long long* const xabort = xbase + T3_XABORT;
     // record values of the block just finished (member 0), posted after the barrier: carrFreq I_P Q_P pllDiscr pllDiscrFilt
     double r_cf = 0.0, r_ip = 0.0, r_qp = 0.0, r_err = 0.0, r_nco = 0.0;
     double s2_blk = 1.0;             // 1 - 10.625 eps^2 of the block being processed
+#ifdef T3_POLLSTAT
+    long long ps_t = 0, ps_n = 0;
+#endif
     T2_FP_DECL
     T3_WB_DECL
     (void)prof_on;
@@ -676,7 +1053,13 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
         }
         // the next block's table entry of this lane at the CURRENT rate, in full; the sums then only turn it
         const int mi = t3_carr_mult(lane, unit, head_next);
-        double mf = ((double)mi + ctr) * inv_fs;     // m / fs: the rate step dw turns the entry by dw * mf radians
+        // the rate step dw turns the entry by dw m / fs radians, W3 by 7.5 samples of the TWO-block step dw + d1 more (the next
+        // block's moments stem from the table of the block before this one): dw (m / fs + 7.5 / fs) + d1 7.5 / fs
+        const double d1 = w_cur - w_prev;
+        double mf = __builtin_fma((double)mi, inv_fs, ctr_fs);
+        double ang0 = d1 * ctr_fs;
+        double dw_lim = fabs(d1) <= 3.0 * dw_max ? dw_max : -1.0;   // (both steps within the rotation's and the expansion's range)
+        T2_PIN(ang0); T2_PIN(dw_lim);
         double cs_p, sn_p;
         t2_carr_entry(c_hi, c_lo, inv_2pi, w_cur, rc, mi, w3, cs_p, sn_p);
         T2_PIN(cs_p); T2_PIN(sn_p); T2_PIN(mf); T2_PIN(rc);   // (keeps all of this ahead of the wait)
@@ -686,6 +1069,24 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
         unsigned long long x = 0;
         int budget = T2_POLL_BUDGET;
         bool gave_up = false;
+#if defined(T3_POLL2) && (T3_POLL2 & 1)
+        for (;;) {
+            int left = 1;
+#ifdef T3_POLLSTAT
+            const long long tq0 = (long long)__builtin_amdgcn_s_memtime();
+#endif
+            if (mine) left = t3_poll1(x, gp, tag, 16);
+#ifdef T3_POLLSTAT
+            ps_t += (long long)__builtin_amdgcn_s_memtime() - tq0;
+            ps_n += 2 * (16 - __builtin_amdgcn_readfirstlane(left)) + 1;
+#endif
+            if (__builtin_amdgcn_readfirstlane(left) != 0) break;
+            if ((budget -= 16) <= 0 || lds_peek(&S.flag[1]) != 0) {
+                gave_up = true;
+                break;
+            }
+        }
+#else
         for (;;) {
             if (mine) x = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (__all(!mine || (x >> 48) == tag)) break;
@@ -696,12 +1097,22 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
                 }
             }
         }
+#endif
         T2STAMP(prof_on, 8);   // waiting for the sums
         if (prof) {
             t_arr = (long long)__builtin_amdgcn_s_memtime();
+#ifdef T3_TSEC
+            const long long tp = lds_peek64(&S.tsec[par]);
+#else
             const long long tp = lds_peek64(&S.tpub[par]);
+#endif
+#ifdef T3_PROF_PAR   // (diagnosis) phase times of the even (0) / odd (1) blocks only: figures are per TWO blocks then
+            if ((it & 1) == T3_PROF_PAR)
+#endif
+            {
             acc_map += tp - t_top;       // barrier release -> this member's publish
             acc_xch += t_arr - tp;       // this member's publish -> every member's sums visible
+            }
         }
         // sum of the units' payloads (integers: exact, order-free); lanes that poll nothing hold 0
         unsigned long long q = ((unsigned long long)(unsigned)((int)(short)(unsigned short)(x >> 32) + bias_hi) << 32) | (unsigned)x;
@@ -724,16 +1135,16 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
         oldCarrErr = carrError;
         T2PROBE(prof_on, 9);   // discriminator + NCO
         // carrier tables of the next block: the prepared entry turned by the rate step (exact: w_new - w_cur is)
-        double s2_next = 1.0;
+        double eps_next = 0.0;
         if (it + 1 < ms) {
             const double dw = w_new - w_cur;
             double cs, sn, eps_n, respec_n;
-            if (__builtin_expect(fabs(dw) <= dw_max, 1)) {
+            if (__builtin_expect(fabs(dw) <= dw_lim, 1)) {
                 double es, ec;
-                sgx_rot_small(dw * mf, rk, es, ec);
+                sgx_rot_small(__builtin_fma(dw, mf, ang0), rk, es, ec);
                 cs = __builtin_fma(cs_p, ec, -(sn_p * es));
                 sn = __builtin_fma(cs_p, es, sn_p * ec);
-                eps_n = dw * inv_fs;
+                eps_n = (dw + d1) * inv_fs;          // (w_new - w_prev) / fs
                 respec_n = 0.0;
             } else {
                 t2_carr_entry(c_hi, c_lo, inv_2pi, w_new, rc, mi, w3, cs, sn);
@@ -742,16 +1153,11 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
             }
             S.carr[par ^ 1].T[lane] = make_double2(cs, sn);
             if (lane == 0) *reinterpret_cast<double2*>(&S.carr[par ^ 1].eps) = make_double2(eps_n, respec_n);
-            s2_next = __builtin_fma(-10.625 * eps_n, eps_n, 1.0);
+            eps_next = eps_n;
         }
+        w_prev = w_cur;
         w_cur = w_new;
         remCarr = rc;
-        r_cf = carrFreq;
-        r_ip = I_P * (s2_blk * unfix);
-        r_qp = Q_P * (s2_blk * unfix);
-        s2_blk = s2_next;
-        r_err = carrError;
-        r_nco = carrNco;
         if (gave_up && lane == 0) {
             S.flag[1] = 1;
             atomicCAS(err, 0, 1 + ch);
@@ -761,6 +1167,16 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
         T3_WB(wb_on);
         __builtin_amdgcn_s_setprio(1);   // what follows until the next poll is off the chain: the final pass (2) issues first,
                                          // the speculative pass (0) after it
+        __builtin_amdgcn_sched_barrier(0);
+        r_cf = carrFreq;                 // (the block's record values: nobody waits for these)
+        r_ip = I_P * (s2_blk * unfix);
+        r_qp = Q_P * (s2_blk * unfix);
+        s2_blk = __builtin_fma(-10.625 * eps_next, eps_next, 1.0);
+        r_err = carrError;
+        r_nco = carrNco;
+#ifdef T3_PROF_PAR
+        if ((it & 1) == T3_PROF_PAR)
+#endif
         if (prof) acc_flt += (long long)__builtin_amdgcn_s_memtime() - t_arr;   // sums visible -> barrier released
         T2STAMP(prof_on, 11);
     }
@@ -784,6 +1200,9 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
     }
     T2_FP_PRINT(prof_on && lane == 0, 8, 12)
     T3_WB_PRINT(wb_on, "pll", ms)
+#ifdef T3_POLLSTAT
+    if (lane == 0 && ch == 0 && (unit == 0 || unit == 10)) printf("[t3 pollstat] unit %d: %.1f cycles in the poll per block, %.2f loads checked per block -> %.0f cycles per load\n", unit, (double)ps_t / it, (double)ps_n / it, (double)ps_t / (double)ps_n);
+#endif
     return it;
 }
 
@@ -831,9 +1250,9 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
         T3Code& N = S.code[par ^ 1];
         if (owner && it > 0) {
             double* R = S.rec[par ^ 1];
-            // rows 1 / 3 hold I / Q of early (r_ve) and late (r_vl) -> series 4 (I_E), 6 (Q_E), 5 (I_L), 8 (Q_L)
-            if (lane == 16) { R[4] = r_ve; R[5] = r_vl; }
-            if (lane == 48) { R[6] = r_ve; R[8] = r_vl; }
+            // rows 1 / 3 hold the early / late arm's I (r_ve) and Q (r_vl) -> series 4 (I_E), 6 (Q_E), 5 (I_L), 8 (Q_L)
+            if (lane == 16) { R[4] = r_ve; R[6] = r_vl; }
+            if (lane == 48) { R[5] = r_ve; R[8] = r_vl; }
             if (lane == 0) {
                 R[0] = (double)(pos + file_off);   // position after block it - 1 = first sample of block it
                 R[1] = r_cf;
@@ -882,12 +1301,25 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
         unsigned lim = (unsigned)(lim1 < lim3 ? lim1 : lim3);
         T2_PIN(a_next); T2_PIN(lim);
         __builtin_amdgcn_s_setprio(3);
-        const unsigned long long* gp1 = xbase + (par * 6 + 2 + (lane >> 5)) * T3_XLINE + (lane & 31);
-        const unsigned long long* gp2 = gp1 + 2 * T3_XLINE;
+        // lanes 0..31 follow the early arm, lanes 32..63 the late one: gp1 the I sums (words 2 | 4), gp2 the Q sums (3 | 5)
+        const unsigned long long* gp1 = xbase + (par * 6 + 2 + 2 * (lane >> 5)) * T3_XLINE + (lane & 31);
+        const unsigned long long* gp2 = gp1 + T3_XLINE;
         const unsigned long long tag = (unsigned long long)((unsigned)(it + 1) & 0xFFFFu);
         unsigned long long x1 = 0, x2 = 0, xa = 0;
         int budget = T2_POLL_BUDGET;
         bool gave_up = false;
+#if defined(T3_POLL2) && (T3_POLL2 & 2)
+        for (;;) {
+            int left = 1;
+            if (mine) left = t3_poll2(x1, x2, gp1, gp2, tag, 8);
+            if (__builtin_amdgcn_readfirstlane(left) != 0) break;
+            xa = __hip_atomic_load(xabort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (xa != 0 || (budget -= 8) <= 0) {
+                gave_up = true;
+                break;
+            }
+        }
+#else
         for (;;) {
             if (mine) {
                 x1 = __hip_atomic_load(gp1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -902,30 +1334,22 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
                 }
             }
         }
+#endif
         T2STAMP(prof_on, 12);  // waiting for the sums
         // T8 DLL (tracking.py:238-251).  Integer sums over the units (exact, order-free; lanes that poll nothing hold 0):
-        // rows 1 and 3 then hold I and Q of the early (q1) and of the late arm (q2)
+        // row 1 then holds the early arm's I (q1) and Q (q2), row 3 the late arm's; the two envelopes are ONE register
         unsigned long long q1 = ((unsigned long long)(unsigned)((int)(short)(unsigned short)(x1 >> 32) + bias_hi) << 32) | (unsigned)x1;
         unsigned long long q2 = ((unsigned long long)(unsigned)((int)(short)(unsigned short)(x2 >> 32) + bias_hi) << 32) | (unsigned)x2;
-        q1 = dpp_addl_xor1(q1, q1);
-        q2 = dpp_addl_xor1(q2, q2);
-        q1 = dpp_addl_xor2(q1, q1);
-        q2 = dpp_addl_xor2(q2, q2);
-        q1 = dpp_addl_hmir(q1, q1);
-        q2 = dpp_addl_hmir(q2, q2);
-        q1 = dpp_addl_mir(q1, q1);
-        q2 = dpp_addl_mir(q2, q2);
-        q1 = t3_addl_bc15(q1);
-        q2 = t3_addl_bc15(q2);
-        const double ve = __longlong_as_double((long long)q1) - T2_MAGIC;   // row 1: I_E, row 3: Q_E (in units of the fixed
-        const double vl = __longlong_as_double((long long)q2) - T2_MAGIC;   // row 1: I_L, row 3: Q_L  point: the discriminator is a ratio)
-        const double sqe = ve * ve, sql = vl * vl;
-        const double e2 = sqe + dpp_bcast<0x143, 0xC>(sqe);  // row 3: I_E^2 + Q_E^2 (row_bcast:31: lane 31 to rows 2, 3)
-        const double l2 = sql + dpp_bcast<0x143, 0xC>(sql);  // row 3: I_L^2 + Q_L^2
-        const double mE = sgx_sqrt1_pos(e2), mL = sgx_sqrt1_pos(l2);   // (two zero envelopes: NaN, as in the reference)
-        const double ce_lane = sgx_div1(mE - mL, mE + mL);   // row 3: (E - L) / (E + L)
-        const double codeError = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ce_lane), 48),
-                                                  __builtin_amdgcn_readlane(__double2loint(ce_lane), 48));
+        t3_reduce2_half(q1, q2);
+        const double vi = __longlong_as_double((long long)q1) - T2_MAGIC;   // row 1: I_E, row 3: I_L (in units of the fixed
+        const double vq = __longlong_as_double((long long)q2) - T2_MAGIC;   // row 1: Q_E, row 3: Q_L  point: the discriminator is a ratio)
+        const double m2 = __builtin_fma(vq, vq, vi * vi);   // row 1: I_E^2 + Q_E^2, row 3: I_L^2 + Q_L^2
+        const double mm = sgx_sqrt1_pos(m2);                // (two zero envelopes: NaN, as in the reference)
+        const double mE = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mm), 16),
+                                           __builtin_amdgcn_readlane(__double2loint(mm), 16));
+        const double mL = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mm), 48),
+                                           __builtin_amdgcn_readlane(__double2loint(mm), 48));
+        const double codeError = sgx_div1(mE - mL, mE + mL);   // (E - L) / (E + L), uniform
         const double codeNco = oldCodeNco + k_a * (codeError - oldCodeErr) + codeError * k_b;
         const double cf_new = basis - codeNco;
         oldCodeNco = codeNco;
@@ -951,11 +1375,6 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
         cf = cf_new;
         blk = blk_n;
         stop = stop_n;
-        r_ve = ve * (s2_blk * unfix);
-        r_vl = vl * (s2_blk * unfix);
-        r_cf = cf_new;
-        r_err = codeError;
-        r_nco = codeNco;
         if (gave_up && lane == 0) {
             S.flag[1] = 1;
             if (xa == 0) {
@@ -966,12 +1385,18 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
         T2STAMP(prof_on, 14);  // next block's code parameters
         T3_WB(wb_on);
         __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_sched_barrier(0);
+        r_ve = vi * (s2_blk * unfix);    // (the block's record values: nobody waits for these)
+        r_vl = vq * (s2_blk * unfix);
+        r_cf = cf_new;
+        r_err = codeError;
+        r_nco = codeNco;
         T2STAMP(prof_on, 15);
     }
     if (owner && it > 0 && it == ms) {
         double* R = S.rec[(it - 1) & 1];
-        if (lane == 16) { R[4] = r_ve; R[5] = r_vl; }
-        if (lane == 48) { R[6] = r_ve; R[8] = r_vl; }
+        if (lane == 16) { R[4] = r_ve; R[6] = r_vl; }
+        if (lane == 48) { R[5] = r_ve; R[8] = r_vl; }
         if (lane == 0) {
             R[0] = (double)(pos + file_off);
             R[1] = r_cf;
@@ -1022,7 +1447,7 @@ __device__ __forceinline__ int t3_rec_role(T3Shared& S, const TrkConst& K, const
         const T3Code& C = S.code[par];
         if (C.stop) break;
         if (lane < 20) {
-            long long a = ((C.pos + 3ll * C.blk) & ~127ll) + (long long)unit * T3_UNIT + 128ll * (lane - 1);
+            long long a = ((C.pos + 6ll * C.blk) & ~127ll) + (long long)unit * T3_UNIT + 128ll * (lane - 1);
             a = a < 0 ? 0 : (a > limit ? limit : a);
             if (K.mark == nullptr || (unsigned long long)(a + 128) <= mark_seen)   // (a streaming record: only what is resident)
                 asm volatile("global_load_dword %0, %1, off" : "+v"(dummy) : "v"(rec + a) : "memory");
