@@ -279,7 +279,7 @@ int sgx_track_kind(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const s
     bool used_v2 = false;
     // what the launches so far have established: the record's streaming has been tried (and stalled), a member of a
     // cooperative layout timed out (the next launch runs with one workgroup per channel)
-    bool stream_tried = false, fallback_one = false;
+    bool stream_tried = false, fallback_one = false, v3_off = false;
     int used_members = 0;
     hipError_t e = hipSuccess;
     int h_err = 0;
@@ -287,7 +287,7 @@ int sgx_track_kind(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const s
     // something else occupies the CUs a member times out (bounded spins) and flags the channel: the launch is
     // then repeated once with one workgroup per channel, which needs no co-residency.  A streaming record whose
     // watermark stalls is repeated on the resident record first, with the same decomposition: at most three launches.
-    for (int launches = 0; launches < 3; ++launches) {
+    for (int launches = 0; launches < 4; ++launches) {
         SGX_HIP(hipMemcpyAsync(d_ch, hc.data(), sizeof(TrkChan) * (size_t)n_ch, hipMemcpyHostToDevice, st));
         SGX_HIP(hipMemsetAsync(aux + sz_ch, 0, sz_done + sz_xch + 256, st));   // done, every polled word, err
         if (!direct) trk_fill_kernel<<<(unsigned)((elems + 255) / 256), 256, 0, st>>>(d_out, ms, (long long)elems);
@@ -298,7 +298,7 @@ int sgx_track_kind(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const s
         const bool want_stream = r->loader && !r->load_done.load() && launches == 0 && !(se2 && se2[0] == '0') && v2;
         K.split = fallback_one ? 1 : split0;                     // a member timed out: no co-residency needed with one
         K.n_units = n_units2;
-        bool v3 = use_v3 && !fallback_one;
+        bool v3 = use_v3 && !fallback_one && !v3_off;
         if (v3) {
             reserved.n = sgx_cu_reserve(c->device, cus_total, ch8 * n_units3);
             if (reserved.n == 0) v3 = false;                     // (the CUs are taken: the layouts below need fewer)
@@ -387,6 +387,13 @@ int sgx_track_kind(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const s
             continue;
         }
         h_err &= ~TRK_ERR_STREAM;
+        if (e == hipSuccess && (h_err & TRK_ERR_SCALE) && !v3_off) {
+            // sums beyond the room of the speculative kernel's 2^30 fixed point (a record far stronger than any front end
+            // delivers): the round-3 kernel, whose 2^28 holds full-scale samples that all line up, tracks it
+            v3_off = true;
+            continue;
+        }
+        h_err &= ~TRK_ERR_SCALE;
         if (e == hipSuccess && (h_err & TRK_ERR_RANGE) == 0) h_err &= 0xFFFF;
         if (e == hipSuccess && (h_err & TRK_ERR_RANGE)) {
             sgx_set_error("tracking: channel %d reached a block longer than the %d units of %d samples the kernel "

@@ -53,6 +53,17 @@
 #define T3_XABORT (12 * T3_XLINE)
 #define T3_XPLACE (12 * T3_XLINE + 8)
 #define T3_XCH_STRIDE 512          // words per channel (sgx_trk.hip sizes the allocation with the same figure)
+// Fixed-point scale of a granule's 48-bit payload: 2^30 (sgx_trk2.hip: 2^28).  A lane's six sums are rounded to it before
+// the order-free integer reductions, 2 387 lanes x 20 units of them per block: at 2^28 that rounding was the largest
+// difference between this kernel's sums and the reference's own (9e-13 relative against 4e-13 from the reference's carrier
+// argument; the code NCO disagrees by an ulp in 3 % of the blocks because of it, and the code phases of two
+// implementations then drift apart until a sample within 1e-11 chips of a chip boundary falls on different sides).
+// A unit's total must stay below 2^17 (the default scene's prompt sums: 7 500 per unit): the PLL wave looks at the units'
+// prompt granules behind the barrier and a record whose sums pass HALF the room is tracked by sgx_trk2.hip instead
+// (TRK_ERR_SCALE, the host repeats the launch).
+#ifndef T3_FIX
+#define T3_FIX 1073741824.0
+#endif
 
 struct __attribute__((aligned(128))) T3Code {   // code side of a block's parameters (DLL wave -> everybody), by block parity
     // chain part: written right before the barrier that starts the block
@@ -237,7 +248,7 @@ template <int SB>
 __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict__ rec, long long rec_alloc, int ms,
                                            long long pos0, int unit, int set, int tid, unsigned long long* __restrict__ xbase,
                                            bool fast, double step_nom, double spacing, bool uns, bool prof_on,
-                                           bool prof_any, bool wb_on) {
+                                           bool prof_any, bool wb_on, int* __restrict__ err) {
     static_assert(SB == 1, "one-byte samples");
     const int lane = tid & 63;
     const long long limit = rec_alloc - 16;                  // bytes: the last 16-byte word that may be loaded
@@ -272,6 +283,7 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
     double ppc = 0.0, pps = 0.0, pp1c = 0.0, pp1s = 0.0;     // ... one sample LATER
     double alE = 0.0, alP = 0.0, alL = 0.0;                  // arm a's sum = al_a (all) + be_a (front)
     double beE = 0.0, beP = 0.0, beL = 0.0;
+    double dfr = 0.0;                // 10.625 - (mean of (b - 7.5)^2 over the front's samples) / 2: see the final pass
     double khd = 0.0;                // the half-chip boundary the lane follows
     double mid = 0.0;                // floor(u) + 0.5 of the pass
     double im1d = 0.0;               // (double)(ilo - 1): the anchor sample of the boundary position
@@ -361,6 +373,12 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
         beE = __hiloint2double((int)(odd & d01h), 0);
         beP = __hiloint2double((int)(~odd & d01h), 0);
         beL = __hiloint2double((int)(odd & d12h), 0);
+        {   // second order of the rate step, front part (the final pass says why): n samples b = 0 .. n - 1 in front
+            const int nf = bsw > 16 ? 16 : (bsw < 1 ? 1 : bsw);
+            const double n1 = (double)(nf - 1);
+            const double m2f = __builtin_fma(n1, __builtin_fma((double)(2 * nf - 1), 1.0 / 6.0, -7.5), 56.25);
+            dfr = __builtin_fma(-0.5, m2f, 10.625);
+        }
         // this lane's sums can change only if the boundary is in reach of the group and the group has samples inside the
         // block (its candidates are zero otherwise); EVERY lane watches how far its boundary moves - a boundary that was
         // out of reach and comes two samples nearer has crossed one (code rate steps of a kHz-wide DLL on a channel without
@@ -718,7 +736,18 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
             const double z0s = __builtin_fma(dp, pps, __builtin_fma(dm, pms, fs_));
             const double z1c = __builtin_fma(dp, pp1c, __builtin_fma(dm, pm1c, f1c));
             const double z1s = __builtin_fma(dp, pp1s, __builtin_fma(dm, pm1s, f1s));
-            const double Fc = __builtin_fma(-eps, z1s, z0c), Fs = __builtin_fma(eps, z1c, z0s);
+            // SECOND ORDER: sum x_b B_b e^{j eps (b - 7.5)} lacks - eps^2 / 2 sum x_b B_b (b - 7.5)^2 here, which for a signal
+            // that is constant over the samples summed is (eps^2 / 2) (mean of (b - 7.5)^2 over them) times the sum: 10.625
+            // eps^2 for all sixteen - the factor the RECORDED sums are divided by, off the chain - but another figure for the n
+            // samples in front of the boundary.  With rate steps over TWO blocks the difference (1e-12 of an arm's sum, slowly
+            // varying with where the boundaries lie in the groups) moved the code NCO by 1e-12 Hz for thousands of blocks on
+            // end; the front gets the factor that leaves it with the same 1 + 10.625 eps^2 as everything else.
+#ifdef T3_NOFFR
+            const double ffr = 1.0;
+#else
+            const double ffr = __builtin_fma(eps * eps, dfr, 1.0);
+#endif
+            const double Fc = __builtin_fma(-eps, z1s, z0c) * ffr, Fs = __builtin_fma(eps, z1c, z0s) * ffr;
             const double Tc = __builtin_fma(-eps, t1s, tc), Ts = __builtin_fma(eps, t1c, ts);
             // rotate by the group phasor: cos part -> Q, sin part -> I (tracking.py:205-207)
             const double tQ = __builtin_fma(gc, Tc, -(gs * Ts)), tI = __builtin_fma(gs, Tc, gc * Ts);
@@ -781,7 +810,7 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
         // fixed point: the raw bits of fma(a, 2^28, 1.5 2^52) are bias + round(a 2^28); sums of them carry the sum of the
         // integers in their low 48 bits whatever the biases add up to
         T3_TS(3);
-        const double lane_fix = uns ? T2_FIX * 0.5 : T2_FIX;
+        const double lane_fix = uns ? T3_FIX * 0.5 : T3_FIX;
         constexpr unsigned long long res_mask = 0xFFFFFFFFFFFFull;
         unsigned long long q[6];
         {
@@ -988,11 +1017,23 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
     const double two_pi = 2 * M_PI;
     double k_a = K.k_carr_a, k_b = K.k_carr_b, inv_2pi = K.inv_2pi, c_hi = K.inv_2pifs_hi, c_lo = K.inv_2pifs_lo,
            inv_fs = K.inv_fs, fs = K.fs;
+    double k_ab = k_a + k_b;
+    T2_PIN(k_ab);
     T2_PIN(k_a); T2_PIN(k_b); T2_PIN(inv_2pi); T2_PIN(c_hi); T2_PIN(c_lo); T2_PIN(inv_fs); T2_PIN(carrBasis);
     T2_PIN(fs);
     // the largest rate step the rotation takes: the farthest table entry is sample n_units * UNIT of the block
     double dw_max = SGX_ROT_MAX / ((double)(K.n_units * T3_UNIT) * K.inv_fs);
     T2_PIN(dw_max);
+    // ... and the largest TWO-block step the map's expansion takes (eps = step / fs): what it leaves out, (7.5 eps)^2 times a
+    // few tenths that depend on where the boundaries lie in the groups, went into the code NCO's integrator during the
+    // pull-in (steps of 50 Hz and more) and stayed there - the code phase then drifts from the reference's by 1e-15 chips
+    // per block for the rest of the run.  Beyond 20 Hz (1e-12 left out; 3.4 sigma of a locked 45 dB-Hz channel's steps) the
+    // tables are evaluated in full and the map accumulates again, exactly.
+#ifndef T3_DW2_HZ
+#define T3_DW2_HZ 20.0
+#endif
+    double dw2_lim = 2.0 * M_PI * T3_DW2_HZ;
+    T2_PIN(dw2_lim);
     const int ms = K.ms;
     SgxAtanCoef ak = sgx_atan_coef();
     SgxRotCoef rk = sgx_rot_coef();
@@ -1001,7 +1042,7 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
     T2_PIN(rk.c0); T2_PIN(rk.c1); T2_PIN(rk.c2); T2_PIN(rk.c3); T2_PIN(rk.c4); T2_PIN(rk.c5);
     // lane 0 of a 32-lane half adds the bits of 1.5 2^52 to its payload: the half's integer sum then IS the double
     const int bias_hi = ((lane & 31) == 0) ? 0x43380000 : 0;
-    double unfix = 1.0 / t2_fix_of<1>(P, K.n_units, K.uns != 0);
+    double unfix = 1.0 / (K.uns != 0 ? T3_FIX * 0.5 : T3_FIX);
     T2_PIN(unfix);
     const bool w3 = lane >= 48;
     double ctr_fs = w3 ? 7.5 * K.inv_fs : 0.0;   // the map's moments are taken about the group's centre
@@ -1058,7 +1099,11 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
         const double d1 = w_cur - w_prev;
         double mf = __builtin_fma((double)mi, inv_fs, ctr_fs);
         double ang0 = d1 * ctr_fs;
-        double dw_lim = fabs(d1) <= 3.0 * dw_max ? dw_max : -1.0;   // (both steps within the rotation's and the expansion's range)
+        double nco_base = __builtin_fma(-k_a, oldCarrErr, oldCarrNco);
+        T2_PIN(nco_base);
+        // ONE test behind the sums: the two-block step within dw2_lim.  With the previous step within it as well, this block's
+        // is within twice that, which the rotation takes (dw_max is 54 Hz at the default front end)
+        double dw_lim = (fabs(d1) <= dw2_lim && 2.0 * dw2_lim <= dw_max) ? dw2_lim : -1.0;
         T2_PIN(ang0); T2_PIN(dw_lim);
         double cs_p, sn_p;
         t2_carr_entry(c_hi, c_lo, inv_2pi, w_cur, rc, mi, w3, cs_p, sn_p);
@@ -1128,7 +1173,10 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
                                             __builtin_amdgcn_readlane(__double2loint(v), 48));
         // T7 PLL (tracking.py:223-235); atan(Q/I) / 2 / pi as one multiplication by RN(1 / (2 pi)) (1.5 ulp)
         const double carrError = sgx_atan_ratio_k(Q_P, I_P, ak) * inv_2pi;
-        const double carrNco = oldCarrNco + k_a * (carrError - oldCarrErr) + carrError * k_b;
+        // carrNco = oldCarrNco + k_a (carrError - oldCarrErr) + carrError k_b, regrouped so that ONE operation follows the
+        // discriminator: (oldCarrNco - k_a oldCarrErr) + carrError (k_a + k_b) - the first bracket is ready before the sums are
+        // (a rounding of 1e-16 relative in another place than the reference's; the NCO is continuous in its inputs)
+        const double carrNco = __builtin_fma(carrError, k_ab, nco_base);
         const double carrFreq = carrBasis + carrNco;
         const double w_new = (carrFreq * 2.0) * M_PI;
         oldCarrNco = carrNco;
@@ -1139,12 +1187,13 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
         if (it + 1 < ms) {
             const double dw = w_new - w_cur;
             double cs, sn, eps_n, respec_n;
-            if (__builtin_expect(fabs(dw) <= dw_lim, 1)) {
+            const double dw2 = dw + d1;              // w_new - w_prev
+            if (__builtin_expect(fabs(dw2) <= dw_lim, 1)) {
                 double es, ec;
                 sgx_rot_small(__builtin_fma(dw, mf, ang0), rk, es, ec);
                 cs = __builtin_fma(cs_p, ec, -(sn_p * es));
                 sn = __builtin_fma(cs_p, es, sn_p * ec);
-                eps_n = (dw + d1) * inv_fs;          // (w_new - w_prev) / fs
+                eps_n = dw2 * inv_fs;
                 respec_n = 0.0;
             } else {
                 t2_carr_entry(c_hi, c_lo, inv_2pi, w_new, rc, mi, w3, cs, sn);
@@ -1168,6 +1217,10 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
         __builtin_amdgcn_s_setprio(1);   // what follows until the next poll is off the chain: the final pass (2) issues first,
                                          // the speculative pass (0) after it
         __builtin_amdgcn_sched_barrier(0);
+        // (a unit's prompt sum beyond half the room of the 48-bit payload: see T3_FIX)
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(mine && (unsigned)((int)(short)(unsigned short)(x >> 32) + 0x4000) > 0x7FFFu) != 0, 0)) {
+            if (lane == 0) atomicOr(err, TRK_ERR_SCALE);
+        }
         r_cf = carrFreq;                 // (the block's record values: nobody waits for these)
         r_ip = I_P * (s2_blk * unfix);
         r_qp = Q_P * (s2_blk * unfix);
@@ -1224,7 +1277,8 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
     // tracking.py:114-121; block 0's chain part and ramp starts were posted before the loop
     double oldCodeNco = 0.0, oldCodeErr = 0.0;
     double k_a = K.k_code_a, k_b = K.k_code_b, basis = K.code_basis;
-    T2_PIN(k_a); T2_PIN(k_b); T2_PIN(basis);
+    double k_ab = k_a + k_b;
+    T2_PIN(k_a); T2_PIN(k_b); T2_PIN(basis); T2_PIN(k_ab);
     const int ms = K.ms;
     double rem = 0.0, cf = K.code_basis;
     long long pos = pos0;
@@ -1233,7 +1287,7 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
     const double off = (l4 == 0) ? -D.spacing : ((l4 == 2) ? D.spacing : 0.0);   // rem - spc == rem + (-spc) exactly
     const int lim3 = K.n_units * T3_UNIT - 15;             // the longest block the units of the launch hold
     const int bias_hi = ((lane & 31) == 0) ? 0x43380000 : 0;   // (see the PLL wave)
-    double unfix = 1.0 / t2_fix_of<1>(P, K.n_units, K.uns != 0);
+    double unfix = 1.0 / (K.uns != 0 ? T3_FIX * 0.5 : T3_FIX);
     T2_PIN(unfix);
     const bool mine = (lane & 31) < P;
     unsigned long long* const xabort = xbase + T3_XABORT;
@@ -1299,7 +1353,8 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
         const long long room = D.rec_len - pos_next;
         const int lim1 = room > (long long)0x3FFFFFFF ? 0x3FFFFFFF : (room < 0 ? 0 : (int)room);
         unsigned lim = (unsigned)(lim1 < lim3 ? lim1 : lim3);
-        T2_PIN(a_next); T2_PIN(lim);
+        double nco_base = __builtin_fma(-k_a, oldCodeErr, oldCodeNco);
+        T2_PIN(a_next); T2_PIN(lim); T2_PIN(nco_base);
         __builtin_amdgcn_s_setprio(3);
         // lanes 0..31 follow the early arm, lanes 32..63 the late one: gp1 the I sums (words 2 | 4), gp2 the Q sums (3 | 5)
         const unsigned long long* gp1 = xbase + (par * 6 + 2 + 2 * (lane >> 5)) * T3_XLINE + (lane & 31);
@@ -1350,7 +1405,7 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
         const double mL = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mm), 48),
                                            __builtin_amdgcn_readlane(__double2loint(mm), 48));
         const double codeError = sgx_div1(mE - mL, mE + mL);   // (E - L) / (E + L), uniform
-        const double codeNco = oldCodeNco + k_a * (codeError - oldCodeErr) + codeError * k_b;
+        const double codeNco = __builtin_fma(codeError, k_ab, nco_base);   // (regrouped like the PLL wave's)
         const double cf_new = basis - codeNco;
         oldCodeNco = codeNco;
         oldCodeErr = codeError;
@@ -1588,7 +1643,7 @@ __global__ __launch_bounds__(T3_THREADS) void trk3_kernel(const int8_t* __restri
     int done;
     if (wave < 4)
         done = t3_map_role<1>(S, rec, K.rec_alloc, K.ms, cc.pos0, unit, wave >> 1, tid, xbase, fast, K.code_basis / K.fs,
-                              K.spacing, K.uns != 0, prof_on, prof != nullptr, wb_on);
+                              K.spacing, K.uns != 0, prof_on, prof != nullptr, wb_on, err);
     else if (wave == 4)
         done = t3_pll_role(S, K, cc, unit, owner, lane, P, ch, xbase, err, prof_on, prof, wb_on);
     else if (wave == 5)

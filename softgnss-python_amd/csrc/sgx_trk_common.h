@@ -257,7 +257,11 @@ __device__ __forceinline__ unsigned xcc_id() {
 // write-through (agent-scope) store.  Either way ONE aligned 8-byte store per granule.
 __device__ __forceinline__ void granule_store(unsigned long long* p, unsigned long long v, bool fast) {
     if (fast)
+#ifdef SGX_GSTORE_ASM   // (diagnosis) the cache-policy bits of the same-XCD granule store: "", "sc0", "nt", "sc0 sc1", "sc0 nt"
+        asm volatile("global_store_dwordx2 %0, %1, off " SGX_GSTORE_ASM : : "v"(p), "v"(v) : "memory");
+#else
         __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
     else
         __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -267,6 +271,7 @@ __device__ __forceinline__ void granule_store(unsigned long long* p, unsigned lo
 // once per several hundred blocks and not once per block.
 #define TRK_ERR_STREAM 0x40000000   // error word: the watermark of a streaming record did not advance in time
 #define TRK_ERR_RANGE 0x20000000    // error word: a block is longer than the units the launch provides
+#define TRK_ERR_SCALE 0x10000000    // error word: sums beyond the room of the speculative kernel's finer fixed point (sgx_trk3.hip)
 
 __device__ __forceinline__ void wait_mark(const unsigned long long* mark, long long need, unsigned long long& seen,
                                           int* err, int ch) {

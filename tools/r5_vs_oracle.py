@@ -53,3 +53,7 @@ for ch in (2, 7):
     rt, rr = rem_series(t, ch, kk), rem_series(r, ch, kk)
     d = rt - rr
     print("ch %d: rem(kernel) - rem(oracle) at block %d: %.3e chips (rem %.12e); max |.| over the blocks before %.3e, rms %.3e" % (ch, kk - 1, d[kk - 1], rr[kk - 1], np.abs(d[:kk]).max(), d[:kk].std()))
+print("rem(kernel) - rem(oracle) in 1e-12 chips at blocks 1000, 2000, ...:")
+for ch in range(r.shape[0]):
+    rt, rr = rem_series(t, ch, kk), rem_series(r, ch, kk)
+    print("  ch %d:" % ch, " ".join("%6.1f" % ((rt[k] - rr[k]) * 1e12) for k in range(1000, kk, 1000)))
