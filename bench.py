@@ -496,6 +496,7 @@ def main():
 
     if rank == 0:
         traffic = pmc_file("_pmc_trk_kernel.json", {"channels": args.channels, "ms": args.ms})
+        chain = pmc_file("_trk_chain.json", {"channels": args.channels, "ms": args.ms})
         tk = ctx.timing()
         trk_name = {2: "trk2_kernel", 3: "trk_kernel_tp", 4: "trk_kernel_multi", 5: "trk3_kernel"}.get(tk.get("track_kernel"), "trk2_kernel")
         prof_avg = trace_avg_ms(trk_name) if (args.channels, args.ms) == (8, 37000) else None
@@ -528,6 +529,15 @@ def main():
                          "measured_stream_read_gbs": read_gbs, "measured_stream_copy_gbs": copy_gbs,
                          "frac_of_measured_read": achieved / read_gbs,
                          "workgroups_per_channel": tk.get("track_members"),
+                         # WHY the fraction is what it is: the per-block dependency chain in shader cycles (SGX_TRK_PROFILE
+                         # phase times of the committed run) and how busy the occupied CUs' vector ALUs are (PMC passes)
+                         "limited_by": "latency of the per-block chain, not bandwidth",
+                         "chain_cycles": ({k: chain[0][k] for k in ("final_pass", "exchange", "loop_filter", "block") if k in chain[0]}
+                                          if chain else None),
+                         "chain_cycles_source": chain[1] if chain else None,
+                         "valu_busy_frac_on_the_occupied_cus": traffic[0].get("valu_busy_frac_on_the_occupied_cus") if traffic else None,
+                         "occupied_cus": traffic[0].get("occupied_cus") if traffic else None,
+                         "valu_insts_per_sample": traffic[0].get("valu_insts_per_sample") if traffic else None,
                          "note": "37 000 dependent steps per channel; %d channels x %d workgroups on as many of the 256 CUs, "
                                  "each on a latency-bound chain (final pass -> exchange -> loop filter): not bandwidth-bound "
                                  "(DESIGN.md section 4.1)" % (args.channels, tk.get("track_members", 0))},

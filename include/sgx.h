@@ -226,6 +226,17 @@ int sgx_track_ex(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset,
                  const sgx_chan_init* ch, int32_t n_ch, int32_t ms,
                  double* out, int32_t* ms_done, int32_t data_type);
 
+/* Which tracking kernel sgx_track_ex runs, and with how many cooperating workgroups (members) per channel - the one rule
+ * the host applies (csrc/sgx_trk.hip: sgx_track_plan), without the diagnostic SGX_TRK_* overrides.  No reference
+ * counterpart (tracking.py:59 is one serial loop); needs no GPU.  n_cus: compute units of the device (256 on an MI355X);
+ * float_in_range != 0: a float32 / float64 record whose window was scanned and can run the typed kernel.
+ *   kernel  2 trk2_kernel (latency mode, any member layout)   3 trk_kernel_tp (throughput mode, > 128 channels)
+ *           4 trk_kernel_multi (< ~15.4 samples per chip)      5 trk3_kernel (speculative latency mode, the headline)
+ *           6 trk_kernel_any (any sample type, sample by sample)
+ *   members workgroups per channel (trk2_kernel with one workgroup per unit AND correlator arm: 3 x units) */
+int sgx_track_plan(const sgx_settings* s, int32_t data_type, int32_t n_ch, int32_t n_cus, int32_t float_in_range,
+                   int32_t* kernel, int32_t* members);
+
 /* Measured HBM rates of this device for the roofline report (no reference counterpart): a read-only stream and a
  * copy (read + write bytes counted) over `bytes` of device memory, `reps` timed launches each, GB/s. */
 int sgx_stream_rates(sgx_ctx* c, size_t bytes, int reps, double* read_gbs, double* copy_gbs);

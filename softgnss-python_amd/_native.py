@@ -91,6 +91,7 @@ _PROTOS = {
     "sgx_acquire_f64": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
     "sgx_track": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, C.c_int32, _P, _P]),
     "sgx_track_ex": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32]),
+    "sgx_track_plan": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "sgx_stream_rates": (C.c_int, [_P, C.c_size_t, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "sgx_probe_stats": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, C.c_double, _P, _P, _P, C.POINTER(C.c_int32)]),
     "sgx_find_preambles": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
@@ -158,6 +159,16 @@ def settings_struct(s):
                     float(s.acqThreshold), float(s.dllDampingRatio), float(s.dllNoiseBandwidth),
                     float(s.dllCorrelatorSpacing), float(s.pllDampingRatio), float(s.pllNoiseBandwidth),
                     int(s.skipNumberOfBytes), int(s.codeLength), int(s.numberOfChannels))
+
+
+def track_plan(settings, data_type=0, n_channels=8, n_cus=256, float_in_range=False):
+    """(kernel, members per channel) sgx_track_ex would run for these settings, sample type and channel count on a device
+    with n_cus compute units - the host's one selection rule (csrc/sgx_trk.hip); needs no GPU."""
+    st = settings_struct(settings)
+    k, mbr = C.c_int32(0), C.c_int32(0)
+    check(lib().sgx_track_plan(C.byref(st), int(data_type), int(n_channels), int(n_cus), 1 if float_in_range else 0,
+                               C.byref(k), C.byref(mbr)))
+    return k.value, mbr.value
 
 
 def scene_struct(scene):

@@ -61,6 +61,91 @@ __global__ __launch_bounds__(256) void trk_fill_kernel(double* __restrict__ out,
     out[i] = zero ? 0.0 : __longlong_as_double(0x7FF0000000000000ll);
 }
 
+// ---- WHICH KERNEL, HOW MANY MEMBERS: the one rule (include/sgx.h: sgx_track_plan; tests/test_cabi_and_host.py holds the table)
+//
+//   sample type                      channels   samples / chip      spacing   -> kernel                        members per channel
+//   any but int8/uint8/int16/float*  any        any                 any          6 trk_kernel_any              min(units, CUs / ch8, 10)
+//   float32 / float64 out of range   any        any                 any          6 trk_kernel_any              (as above)
+//   uint8 / int16 / float            any        < ~15.4 (multi)     any          6 trk_kernel_any              (as above)
+//   int8                             any        < ~15.4 (multi)     any          4 trk_kernel_multi            min(units, CUs / ch8, 10)
+//   int8 / uint8 / int16             > 128 and CUs / ch8 < 2        any          3 trk_kernel_tp               1
+//   int8 / uint8                     ch8 x 2 units <= CUs, 18 samples < 1/2 chip, spacing 1/2
+//                                                                                5 trk3_kernel                 2 x units (128-group units)
+//   everything else                                                              2 trk2_kernel                 3 x units (one per unit and arm)
+//                                                                                                              while 3 ch8 units <= CUs and not float,
+//                                                                                                              else min(units, CUs / ch8)
+//   (ch8 = channels rounded up to 8; units = ceil((samplesPerCode + 94) / 16 / 256); a cooperative launch that cannot be
+//   resident, or whose member timed out, is repeated with ONE member per channel by sgx_track_kind)
+struct TrkPlan {
+    int kernel, members;
+    int multi, use_any, use_tp, use_v2, use_v3, arm_split, split, n_units, n_units3;
+};
+
+// (split_env: SGX_TRK_SPLIT or 0; arms_env: 0 unset, 3 SGX_TRK_ARMS=3, 1 any other value; v3_off: SGX_TRK_V3=0 - diagnostics)
+static TrkPlan trk_plan(const sgx_settings& S, int kind, int n_ch, long long n_code, int cus_total, bool floaty,
+                        int split_env = 0, int arms_env = 0, bool v3_off = false) {
+    TrkPlan P;
+    const int sample_bytes = sgx_dt_bytes(kind);
+    P.multi = (15.0 * 1.001 * S.codeFreqBasis / S.samplingFreq >= 1.0) ? 1 : 0;
+    if (P.multi) floaty = false;
+    const bool typed = kind == SGX_DT_INT8 || kind == SGX_DT_UINT8 || kind == SGX_DT_INT16 || floaty;
+    P.use_any = (!typed || (P.multi && kind != SGX_DT_INT8)) ? 1 : 0;
+    const int ch8 = ((n_ch + 7) / 8) * 8;
+    P.n_units = (int)((n_code + 64 + 15 + 15) / 16 + TRK_THREADS - 1) / TRK_THREADS;
+    int split = cus_total / ch8;
+    if (split > P.n_units) split = P.n_units;
+    if ((P.multi || P.use_any) && split > TRK_MAX_SPLIT) split = TRK_MAX_SPLIT;
+    if (split < 1) split = 1;
+    if (split_env >= 1 && split_env <= split) split = split_env;
+    P.split = split;
+    P.use_tp = (!P.use_any && !floaty && !P.multi && split == 1 && n_ch > 128) ? 1 : 0;
+    P.use_v2 = (!P.use_any && !P.multi && !P.use_tp) ? 1 : 0;
+    P.arm_split = (P.use_v2 && !floaty && split == P.n_units && P.n_units >= 2 && 3 * ch8 * P.n_units <= cus_total &&
+                   split_env == 0 && arms_env != 3) ? 1 : 0;
+    // The speculative kernel (sgx_trk3.hip) serves all three arms from one lane, which rests on a 16-sample group (and one
+    // sample on either side of it) meeting at most ONE chip boundary of ANY arm: the arms' boundaries lie at code phases
+    // 0, d and 1 - d (mod 1 chip; d = dllCorrelatorSpacing), so the smallest gap between two DIFFERENT ones must exceed 18
+    // samples of code phase (1 % margin for the code NCO) - and its fused half-chip ramp puts the early / late boundaries
+    // on the ODD half chips: spacing 1/2 exactly.  int8 / uint8 records, one workgroup per unit of 128 groups, while
+    // 8-padded channels x units fit the CUs.
+    P.n_units3 = 2 * P.n_units;
+    {
+        const double d = S.dllCorrelatorSpacing, e = 1.0 - d;
+        double pts[3] = {0.0, d < e ? d : e, d < e ? e : d};
+        double gap = 2.0;
+        for (int i = 0; i < 3; ++i) {
+            const double g = (i < 2 ? pts[i + 1] : pts[0] + 1.0) - pts[i];
+            if (g > 1e-9 && g < gap) gap = g;
+        }
+        const double stepn = S.codeFreqBasis / S.samplingFreq;
+        P.use_v3 = (P.use_v2 && sample_bytes == 1 && P.n_units3 >= 2 && P.n_units3 <= T3_MAXP && ch8 * P.n_units3 <= cus_total &&
+                    fabs(d - 0.5) < 1e-12 && 18.0 * stepn * 1.01 <= gap && split_env == 0 && arms_env == 0 && !v3_off) ? 1 : 0;
+    }
+    if (P.use_any) { P.kernel = 6; P.members = split; }
+    else if (P.use_tp) { P.kernel = 3; P.members = 1; }
+    else if (P.use_v3) { P.kernel = 5; P.members = P.n_units3; }
+    else if (P.use_v2) { P.kernel = 2; P.members = (P.arm_split && split > 1) ? 3 * split : split; }
+    else { P.kernel = 4; P.members = split; }
+    return P;
+}
+
+extern "C" int sgx_track_plan(const sgx_settings* s, int32_t data_type, int32_t n_ch, int32_t n_cus, int32_t float_in_range,
+                              int32_t* kernel, int32_t* members) {
+    SGX_CHECK_ARG(s && kernel && members && n_ch >= 1 && n_cus >= 1);
+    if (sgx_dt_bytes(data_type) == 0) {
+        sgx_set_error("sgx_track_plan: data_type %d is not one of SGX_DT_* (include/sgx.h)", (int)data_type);
+        return SGX_E_ARG;
+    }
+    int64_t n_code = 0;
+    const int rc = sgx_samples_per_code(s, &n_code);
+    if (rc != SGX_OK) return rc;
+    const bool fl = (data_type == SGX_DT_FLOAT32 || data_type == SGX_DT_FLOAT64) && float_in_range != 0;
+    const TrkPlan P = trk_plan(*s, data_type, n_ch, (long long)n_code, n_cus, fl);
+    *kernel = P.kernel;
+    *members = P.members;
+    return SGX_OK;
+}
+
 // sample_bytes: 1 (int8 record) or 2 (little-endian int16 record; the record handle holds the file's BYTES).  The
 // reference seeks skipNumberOfBytes + codePhase BYTES whatever the sample type and reports fid.tell(), also bytes
 // (tracking.py:107, 255); so a two-byte channel may start on an odd byte - its samples then straddle the file's - and
@@ -109,12 +194,8 @@ int sgx_track_kind(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const s
     K.rec_len = (long long)r->n;                         // bytes; two-byte samples: the kernel divides (per-channel shift)
     K.rec_alloc = (long long)r->n + SGX_IF_PAD - (sample_bytes - 1);   // bytes, less the largest per-channel shift
     K.mark = nullptr;
-    // 16 consecutive samples span 15 code-phase steps: below one chip (with margin for the code NCO's excursions)
-    // a group holds at most one switch per ramp, which the fast map relies on
-    K.multi = (15.0 * 1.001 * S.codeFreqBasis / S.samplingFreq >= 1.0) ? 1 : 0;
-    K.uns = sample_uns ? 1 : 0;
-    K.kind = kind;
-    bool floaty = (kind == SGX_DT_FLOAT32 || kind == SGX_DT_FLOAT64) && fscale > 0.0 && !K.multi;
+    // (a float record the typed kernel can take: in range, no channel starting inside a sample, not switched off)
+    bool floaty = (kind == SGX_DT_FLOAT32 || kind == SGX_DT_FLOAT64) && fscale > 0.0;
     for (int i = 0; i < n_ch && floaty; ++i) {
         // (a channel that starts inside a sample reads other values than the ones that were scanned)
         const long long p0 = skip_bytes + (long long)ch[i].codePhase - rec_file_offset;
@@ -124,20 +205,29 @@ int sgx_track_kind(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const s
         const char* fe = getenv("SGX_TRK_FLOAT_TYPED");   // '0': float records always on the per-sample kernel
         if (fe && fe[0] == '0') floaty = false;
     }
+    int cus_total = 0;
+    SGX_HIP(hipDeviceGetAttribute(&cus_total, hipDeviceAttributeMultiprocessorCount, c->device));
+    // THE RULE (trk_plan above), with the diagnostic overrides of this process's environment
+    const char* se = getenv("SGX_TRK_SPLIT");
+    const char* ae = getenv("SGX_TRK_ARMS");
+    const char* v3e = getenv("SGX_TRK_V3");
+    const TrkPlan P0 = trk_plan(S, kind, n_ch, (long long)c->n_code, cus_total, floaty, (se && atoi(se) >= 1) ? atoi(se) : 0,
+                                ae ? (ae[0] == '3' ? 3 : 1) : 0, v3e && v3e[0] == '0');
+    K.multi = P0.multi;
+    if (K.multi) floaty = false;
+    K.uns = sample_uns ? 1 : 0;
+    K.kind = kind;
     K.fscale = floaty ? fscale : 1.0;
-    const bool typed = kind == SGX_DT_INT8 || kind == SGX_DT_UINT8 || kind == SGX_DT_INT16 || floaty;
-    const bool use_any = !typed || (K.multi && kind != SGX_DT_INT8);
+    const bool use_any = P0.use_any != 0;
     K.file_off = rec_file_offset;
     K.ms = ms;
     K.n_ch = n_ch;
-    int cus_total = 0;
-    SGX_HIP(hipDeviceGetAttribute(&cus_total, hipDeviceAttributeMultiprocessorCount, c->device));
     const int ch8 = ((n_ch + 7) / 8) * 8;
     {
         // units needed by the longest possible block, worst alignment.  A block is samplesPerCode +- 1 samples long
         // while the code NCO stays near its basis; the allowance of 64 samples corresponds to a code-rate error of
         // 0.17 % (1.7 kHz at 1.023 MHz), three orders of magnitude beyond what the DLL's filter can command.
-        K.n_units = (int)((c->n_code + 64 + 15 + 15) / 16 + TRK_THREADS - 1) / TRK_THREADS;
+        K.n_units = P0.n_units;
         if (K.n_units > 16) {
             sgx_set_error("samplesPerCode %lld needs %d units, the tracking kernel holds 16", (long long)c->n_code,
                           K.n_units);
@@ -145,13 +235,7 @@ int sgx_track_kind(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const s
         }
         // members (cooperating workgroups) per channel: one workgroup per CU, all of a cooperative launch must be
         // resident at once (they wait for each other), so members * channels <= CU count
-        int split = cus_total / ch8;
-        if (split > K.n_units) split = K.n_units;
-        if ((K.multi || use_any) && split > TRK_MAX_SPLIT) split = TRK_MAX_SPLIT;
-        if (split < 1) split = 1;
-        const char* se = getenv("SGX_TRK_SPLIT");
-        if (se && atoi(se) >= 1 && atoi(se) <= split) split = atoi(se);
-        K.split = split;
+        K.split = P0.split;
         const char* fe = getenv("SGX_TRK_FASTX");
         K.fast_xcd = (fe && fe[0] == '0') ? 0 : 1;
         K.nb_base = (int)c->n_code - 3;
@@ -235,35 +319,12 @@ int sgx_track_kind(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const s
     // Which kernel: the low-rate variant when a group can hold several switches of a ramp; throughput mode for more
     // than 128 int8 channels (one workgroup per channel anyway); the latency-mode kernel otherwise - with one workgroup
     // per (unit, correlator arm) when three times the CUs of one-per-unit are free (SGX_TRK_ARMS=3 keeps one per unit).
-    const bool use_tp = !use_any && !floaty && !K.multi && K.split == 1 && n_ch > 128;   // (int8, uint8, int16)
-    const bool use_v2 = !use_any && !K.multi && !use_tp;
-    const char* ae = getenv("SGX_TRK_ARMS");
-    const bool arm_split = use_v2 && !floaty && K.split == K.n_units && K.n_units >= 2 && 3 * ch8 * K.n_units <= cus_total &&
-                           !getenv("SGX_TRK_SPLIT") && !(ae && ae[0] == '3');
-    // The speculative kernel (sgx_trk3.hip) serves all three arms from one lane, which rests on a 16-sample group (and one
-    // sample on either side of it) meeting at most ONE chip boundary of ANY arm: the arms' boundaries lie at code phases
-    // 0, d and 1 - d (mod 1 chip; d = dllCorrelatorSpacing), so the smallest gap between two DIFFERENT ones must exceed 18
-    // samples of code phase (1 % margin for the code NCO).  E and L sharing theirs (d = 1/2) is fine.  int8 / uint8
-    // records, one workgroup per unit of 128 groups, while 8-padded channels x units fit the CUs.
+    const bool use_tp = P0.use_tp != 0;
+    const bool use_v2 = P0.use_v2 != 0;
+    const bool arm_split = P0.arm_split != 0;
+    const bool use_v3 = P0.use_v3 != 0;
     const int n_units2 = K.n_units;
-    const int n_units3 = 2 * n_units2;   // (units of half the size: the same room for a code NCO that left its basis)
-    bool use_v3 = false;
-    {
-        const double d = S.dllCorrelatorSpacing, e = 1.0 - d;
-        double pts[3] = {0.0, d < e ? d : e, d < e ? e : d};
-        double gap = 2.0;
-        for (int i = 0; i < 3; ++i) {
-            const double g = (i < 2 ? pts[i + 1] : pts[0] + 1.0) - pts[i];
-            if (g > 1e-9 && g < gap) gap = g;
-        }
-        const double stepn = S.codeFreqBasis / S.samplingFreq;
-        const char* v3e = getenv("SGX_TRK_V3");
-        // (the kernel's fused half-chip ramp puts the early / late boundaries on the ODD half chips: spacing 1/2 exactly;
-        // any other spacing whose gaps happen to pass at a higher sampling rate runs sgx_trk2.hip)
-        use_v3 = use_v2 && sample_bytes == 1 && n_units3 >= 2 && n_units3 <= T3_MAXP && ch8 * n_units3 <= cus_total &&
-                 fabs(d - 0.5) < 1e-12 && 18.0 * stepn * 1.01 <= gap && !getenv("SGX_TRK_SPLIT") && !ae &&
-                 !(v3e && v3e[0] == '0');
-    }
+    const int n_units3 = P0.n_units3;   // (units of half the size: the same room for a code NCO that left its basis)
     const char* le = getenv("SGX_TRK_LDSPAD");   // dynamic LDS per workgroup (bytes); default: one workgroup per CU
     const int lds_pad_coop = le ? atoi(le) : 90112;
     const int split0 = K.split;

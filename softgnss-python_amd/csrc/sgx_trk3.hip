@@ -1,5 +1,5 @@
 // TrackingResult.track on gfx950, the SPECULATIVE latency-mode kernel (reference tracking.py:13-295; SURVEY.md section 9
-// T1-T9).  Round 4.  What the per-block chain  sums -> discriminators -> NCOs -> next block's parameters -> sums  of
+// T1-T9).  Rounds 4-5.  What the per-block chain  sums -> discriminators -> NCOs -> next block's parameters -> sums  of
 // sgx_trk2.hip still held was the whole map: block k + 1's samples were multiplied and added only after block k's loop
 // filter had posted the block's code rate, carrier rate and length.  But those three move by tiny, bounded amounts from
 // block to block, and everything else about block k + 1 - its first sample, its code phase, its carrier start phase - is
@@ -29,20 +29,28 @@
 //             full and says so): the wave accumulates again on the chain.  Chip indices are therefore bit-identical to
 //             code[int64(ceil(linspace(...)))] (tracking.py:166-188) always.
 //
-// Members: one workgroup per unit of 128 groups x 16 samples (19 units at 38.192 Msps): two SETS of two MAP waves, a PLL
-// wave, a DLL wave and a RECORD wave.  The sets take the blocks in turn: while one set runs the final pass of block k
-// (on the chain), the other accumulates block k + 1 (in the shadow) - a map wave's speculative pass and its final pass
-// are ~2 100 + ~1 000 cycles of instruction issue, more than a code period is meant to last, and this way neither waits
-// for the other.  With one third of the sample work of the arm-split layout the 8-channel launch occupies 152 CUs.  Exchange, loop filters, record path
-// and abort protocol are those of sgx_trk2.hip (granules {16-bit epoch | 48-bit fixed point}, order-free integer sums,
-// redundant filters in every member).
+// Members: one workgroup per unit of 128 groups x 16 samples (20 units at 38.192 Msps: the 8-channel launch occupies 160 CUs):
+// two SETS of two MAP waves, a PLL wave, a DLL wave and a RECORD wave.  The sets take the blocks in turn.
+//
+// Round 5: the pass runs TWO blocks ahead, in two parts around the block barrier.  With the pass of block k + 1 in the
+// shadow of block k (round 4) a set's pass - 380 instructions, 2 400 cycles alone and 3 200 next to the filter waves - filled
+// the period: every cycle taken off the chain made the pass the critical path.  Now a set runs the final pass of block k,
+// then part A of the pass of block k + 2 (edges, boundary, chips, candidates: what needs the block's geometry), arrives at
+// the barrier, and runs part B (the sixteen samples' moments) in the first half of block k + 1's period: no map wave is
+// near the chain any more, and the SIMDs are quiet while the loop filter runs.  Block k + 2's geometry is block k's moved on
+// with block k's rates: its start is off by a sample in 3 % of the blocks and its length in 5 %.  The samples' ABSOLUTE
+// positions and phases do not depend on where the block was taken to start, so the lanes keep their moments with their block
+// indices moved; the one or two samples that enter or leave at the block's first and last lane are PATCHED in (raw byte, the
+// pass's sample phasor); the rate step is the one over two blocks (eps = (w_{k+2} - w_k) / fs, W3 turned by 7.5 samples of
+// it).  What the expansion leaves out grows with the square of that step: the front part carries its own second-order
+// factor, and steps beyond 20 Hz (the pull-in) are evaluated exactly - tables in full, accumulate again - because the
+// residue of those first blocks sat in the code NCO's integrator for the rest of the run (code phase 1e-11 chips from the
+// reference's after 10 000 blocks: enough to put a sample 3e-12 chips from a chip boundary on the other side).
+// Exchange: granules {16-bit epoch | 48-bit fixed point, 2^30}, order-free integer sums, redundant filters in every member;
+// the filter waves keep TWO polls in flight (reserved registers v[244:255]).  Record path and abort protocol are those of
+// sgx_trk2.hip.
 #include "sgx_trk2_parts.h"
 
-#ifdef T3_TSEC
-#define T3_TS(n) do { if (T3_TSEC == (n) && prof_any && (tid & 127) == 0) S.tsec[par] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define T3_TS(n) do { } while (0)
-#endif
 #define T3_LANES 128               // map lanes = groups per unit (two waves)
 #define T3_UNIT (T3_LANES * 16)    // samples per unit
 #define T3_THREADS 448             // 2 x 2 map waves (two SETS, alternating blocks) + PLL wave (4) + DLL wave (5) + record wave (6)
@@ -100,7 +108,6 @@ struct T3Shared {
     int flag[4];                    // [0] same-XCD placement, [1] abort seen by this workgroup
     int rflag[4];                   // [0] PLL wave, [1] DLL wave: number of blocks whose record values are in rec[]
     long long tpub[2];              // (profiling) time stamp of the member's publish, by block parity
-    long long tsec[2];              // (diagnosis, -DT3_TSEC=n) time stamp of point n of the final pass
 };
 
 // Two 64-bit values per lane -> sums over lanes 0..31 (rows 1) and 32..63 (rows 3) of either, the two chains interleaved
@@ -512,7 +519,6 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
         if ((it & 1) == set) {
         // ======== this set's block: the final pass (on the chain) ========
         __builtin_amdgcn_s_setprio(2);
-        T3_TS(1);
         double eps = ep.x;
         // group phasor G' = W1'[tid & 15] * W2'[(tid >> 4) & 7] * W3' (rotated tables)
         double gc, gs;
@@ -712,19 +718,6 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
                 }
             }
         }
-
-#ifdef T3_DIAG_AT
-        if (it == T3_DIAG_AT && (blockIdx.x & 7) == 7 && unit == 4 && tid == 8) {
-            int budget_ = 1 << 20;
-            while (lds_peek(&C.xflag) != it + 1 && --budget_) __builtin_amdgcn_s_sleep(1);
-            const double stP_ = C.stp[1], sP_ = C.start[1];
-            const int ii = i0 + 8;
-            const double tt = ramp_at(ii, stP_, sP_);
-            printf("[t3 diag] it %d pos %lld blk %d i %d rem %a step %a inv %a stpP %a startP %a t %.17g ceil %.1f | khd %.1f mid %.3f im1d %.1f r-0.5 %.6e direct %d\n",
-                   it, (long long)pos, blk, ii, rem, step, inv_step, stP_, sP_, tt, ceil(tt), khd, mid, im1d, r - 0.5, (int)direct);
-        }
-#endif
-        T3_TS(2);
         T2STAMP(prof_on, 2);   // group phasor, where the block really lies, the boundary's guard
         if (!direct) {
             // 1.0 where the boundary crossed a sample downwards / upwards (arithmetic on the sign bit; the candidates of a
@@ -742,11 +735,7 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
             // samples in front of the boundary.  With rate steps over TWO blocks the difference (1e-12 of an arm's sum, slowly
             // varying with where the boundaries lie in the groups) moved the code NCO by 1e-12 Hz for thousands of blocks on
             // end; the front gets the factor that leaves it with the same 1 + 10.625 eps^2 as everything else.
-#ifdef T3_NOFFR
-            const double ffr = 1.0;
-#else
             const double ffr = __builtin_fma(eps * eps, dfr, 1.0);
-#endif
             const double Fc = __builtin_fma(-eps, z1s, z0c) * ffr, Fs = __builtin_fma(eps, z1c, z0s) * ffr;
             const double Tc = __builtin_fma(-eps, t1s, tc), Ts = __builtin_fma(eps, t1c, ts);
             // rotate by the group phasor: cos part -> Q, sin part -> I (tracking.py:205-207)
@@ -809,7 +798,6 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
         T2STAMP(prof_on, 4);   // patch, first-order correction, rotation, three arms
         // fixed point: the raw bits of fma(a, 2^28, 1.5 2^52) are bias + round(a 2^28); sums of them carry the sum of the
         // integers in their low 48 bits whatever the biases add up to
-        T3_TS(3);
         const double lane_fix = uns ? T3_FIX * 0.5 : T3_FIX;
         constexpr unsigned long long res_mask = 0xFFFFFFFFFFFFull;
         unsigned long long q[6];
@@ -827,7 +815,6 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
         // transposing reduction inside each row of 16 lanes; exchange order I_P Q_P I_E Q_E I_L Q_L
         unsigned long long vpe, vl;
         t3_reduce6(q, odd1, odd2, vpe, vl);
-        T3_TS(4);
         {
             const int rl = lane & 15;
             if (rl < 6) {
@@ -869,9 +856,6 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
         }
         } else if (pend_b) {
             // ======== part B of that pass: the table is the one part A ran with - the block before this one's
-#ifdef T3_EXP_SLEEPB
-            __builtin_amdgcn_s_sleep(T3_EXP_SLEEPB);
-#endif
             spec_b(S.carr[par ^ 1], true);
             pend_b = false;
             held = nraw.a;           // (requested a period ago: no wait to speak of)
@@ -1146,11 +1130,7 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
         T2STAMP(prof_on, 8);   // waiting for the sums
         if (prof) {
             t_arr = (long long)__builtin_amdgcn_s_memtime();
-#ifdef T3_TSEC
-            const long long tp = lds_peek64(&S.tsec[par]);
-#else
             const long long tp = lds_peek64(&S.tpub[par]);
-#endif
 #ifdef T3_PROF_PAR   // (diagnosis) phase times of the even (0) / odd (1) blocks only: figures are per TWO blocks then
             if ((it & 1) == T3_PROF_PAR)
 #endif

@@ -257,11 +257,7 @@ __device__ __forceinline__ unsigned xcc_id() {
 // write-through (agent-scope) store.  Either way ONE aligned 8-byte store per granule.
 __device__ __forceinline__ void granule_store(unsigned long long* p, unsigned long long v, bool fast) {
     if (fast)
-#ifdef SGX_GSTORE_ASM   // (diagnosis) the cache-policy bits of the same-XCD granule store: "", "sc0", "nt", "sc0 sc1", "sc0 nt"
-        asm volatile("global_store_dwordx2 %0, %1, off " SGX_GSTORE_ASM : : "v"(p), "v"(v) : "memory");
-#else
         __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
     else
         __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

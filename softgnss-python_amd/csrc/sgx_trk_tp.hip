@@ -34,6 +34,15 @@
 #ifndef TP_THREADS
 #define TP_THREADS 256
 #endif
+// workgroups per CU the register allocation is cut for, per sample type (MODE 0 int8, 1 uint8, 2 int16): -DTP_OCC2=1 gives
+// the int16 instance - two planes of samples in flight - the registers of a whole SIMD lane
+#ifndef TP_OCC2
+#define TP_OCC2 2
+#endif
+#ifndef TP_OCC1
+#define TP_OCC1 2
+#endif
+#define TP_OCC_MODE(M) ((M) == 2 ? TP_OCC2 : ((M) == 1 ? TP_OCC1 : TP_OCC))
 #ifndef TP_OCC
 #define TP_OCC 2
 #endif
@@ -295,7 +304,7 @@ __device__ __forceinline__ void tp_apply(double2 gh, double2 gt, double Hc, doub
 }
 
 template <int MODE>
-__global__ __launch_bounds__(TP_THREADS, TP_OCC) void trk_kernel_tp(const int8_t* __restrict__ rec0,
+__global__ __launch_bounds__(TP_THREADS, TP_OCC_MODE(MODE)) void trk_kernel_tp(const int8_t* __restrict__ rec0,
                                                                 const int8_t* __restrict__ codes,
                                                                 const TrkChan* __restrict__ chans,
                                                                 double* __restrict__ out, int* __restrict__ ms_done,

@@ -518,3 +518,96 @@ def test_division_free_ceil_equals_ieee_ceil(built):
         else:
             a = 1023.0 - rng.uniform(-0.05, 0.05)
         assert int(_math_eval(5, a, step)[0]) == math.ceil(a / step), (a, step)
+
+
+def test_tracking_kernel_selection_table(built):
+    """The host's one rule for which tracking kernel runs with how many workgroups per channel (csrc/sgx_trk.hip: trk_plan, the
+    table in front of it; exported as sgx_track_plan, no GPU needed) - data type x channels x sampling rate x correlator
+    spacing -> kernel, members.  kernel: 2 trk2_kernel, 3 trk_kernel_tp, 4 trk_kernel_multi, 5 trk3_kernel, 6 trk_kernel_any."""
+    m = pkg()
+    N = m._native
+    DT = dict(int8=0, int16=1, uint8=2, float32=3, float64=4, uint16=5, float16=10)
+
+    def plan(dt="int8", ch=8, fs=38.192e6, d=0.5, cus=256, fl=False):
+        s = m.Settings()
+        s.samplingFreq, s.dllCorrelatorSpacing = fs, d
+        return N.track_plan(s, DT[dt], ch, cus, fl)
+
+    table = [
+        # the headline: 8 channels of the default front end -> the speculative kernel, 20 units of 128 groups
+        (dict(), (5, 20)),
+        (dict(dt="uint8"), (5, 20)),
+        (dict(ch=12), (2, 10)),                   # 16 padded channels x 20 units do not fit 256 CUs: one workgroup per unit
+        (dict(ch=4), (5, 20)),
+        # other spacings, other rates: the round-3 kernel, one workgroup per unit and arm while 3 x units x ch8 CUs are free
+        (dict(d=0.25), (2, 30)),
+        (dict(d=0.4), (2, 30)),
+        (dict(fs=60e6, d=0.32), (2, 15)),         # (the gap test alone would have let the speculative kernel in: ADVICE r4)
+        (dict(fs=60e6, d=0.5), (5, 30)),
+        (dict(fs=16.3676e6), (2, 15)),           # 16 samples per chip: 18 samples span more than half a chip
+        # int16 and float records never run the speculative kernel
+        (dict(dt="int16"), (2, 30)),
+        (dict(dt="float32", fl=True), (2, 10)),
+        (dict(dt="float64", fl=True), (2, 10)),
+        (dict(dt="float32", fl=False), (6, 10)),  # out of range / not scanned: sample by sample
+        (dict(dt="uint16"), (6, 10)),
+        (dict(dt="float16"), (6, 10)),
+        # many channels: members shrink with the CUs left, throughput mode beyond 128 channels
+        (dict(ch=16), (2, 10)),
+        (dict(ch=64), (2, 4)),
+        (dict(ch=128), (2, 2)),
+        (dict(ch=129), (3, 1)),
+        (dict(ch=3072, dt="int16"), (3, 1)),
+        (dict(ch=3072, dt="float32", fl=True), (2, 1)),
+        # fewer than ~15.4 samples per chip: a group can hold several switches of one ramp
+        (dict(fs=5.456e6), (4, 2)),
+        (dict(fs=5.456e6, dt="uint8"), (6, 2)),
+        (dict(fs=4.092e6, ch=200), (4, 1)),
+        # a smaller device
+        (dict(cus=64), (2, 8)),
+        (dict(cus=8), (2, 1)),
+    ]
+    got = [plan(**kw) for kw, _ in table]
+    bad = [(kw, g, want) for (kw, want), g in zip(table, got) if g != want]
+    assert not bad, bad
+
+
+def test_reserved_poll_registers_are_touched_by_nothing_else(tmp_path):
+    """csrc/sgx_trk3.hip keeps two poll loads in flight while the loop filter runs; the load that lands late writes v[244:255],
+    which therefore must appear in the speculative kernel's code ONLY inside the poll's asm statements."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "trk3.s")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip",
+                        "-I", os.path.join(root, "include"), "-I", os.path.join(root, "softgnss-python_amd", "csrc"),
+                        "-S", "--cuda-device-only", "-o", out, os.path.join(root, "softgnss-python_amd", "csrc", "sgx_trk3.hip")],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    import re
+    reserved = re.compile(r"\bv(24[4-9]|25[0-5])\b|\bv\[(\d+):(\d+)\]")
+    in_asm, hits_in, hits_out, spills = False, 0, [], None
+    for line in open(out):
+        t = line.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+        elif t.startswith(";;#ASMEND"):
+            in_asm = False
+        elif t.startswith(".vgpr_spill_count:"):
+            spills = int(t.split(":")[1])
+        elif t and not t.startswith((";", ".")):
+            touched = False
+            for mm in reserved.finditer(t):
+                if mm.group(1) or (int(mm.group(3)) >= 244 and int(mm.group(2)) <= 255):
+                    touched = True
+            if touched:
+                if in_asm:
+                    hits_in += 1
+                else:
+                    hits_out.append(t)
+    assert hits_in >= 10                       # the poll is there
+    assert not hits_out, hits_out[:5]
+    assert spills == 0
