@@ -888,6 +888,9 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
 #ifndef T3_POLL_GAP
 #define T3_POLL_GAP 5              // s_sleep units (64 cycles) between the first two loads
 #endif
+#ifndef T3_POLL_GAP3
+#define T3_POLL_GAP3 2             // ... between the PLL wave's three loads
+#endif
 #ifndef T3_POLL2
 #define T3_POLL2 3                 // bit 0: the PLL wave, bit 1: the DLL wave (0: one load at a time, for comparison)
 #endif
@@ -896,24 +899,33 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
 __device__ __forceinline__ int t3_poll1(unsigned long long& x, const unsigned long long* p, unsigned long long tag, int rounds) {
     unsigned long long t;
     int left;
+    // (THREE loads in flight here: the PLL wave's chain is the longer of the two filter waves')
     asm volatile(
         "s_waitcnt vmcnt(0)\n\t"
+        "global_load_dwordx2 v[250:251], %[p], off sc1\n\t"
+        "s_sleep " T3_STR(T3_POLL_GAP3) "\n\t"
         "global_load_dwordx2 v[252:253], %[p], off sc1\n\t"
-        "s_sleep " T3_STR(T3_POLL_GAP) "\n\t"
+        "s_sleep " T3_STR(T3_POLL_GAP3) "\n\t"
         "global_load_dwordx2 v[254:255], %[p], off sc1\n\t"
         "s_mov_b32 %[n], %[r]\n"
         "1:\n\t"
-        "s_waitcnt vmcnt(1)\n\t"
-        "v_lshrrev_b64 %[t], 48, v[252:253]\n\t"
+        "s_waitcnt vmcnt(2)\n\t"
+        "v_lshrrev_b64 %[t], 48, v[250:251]\n\t"
         "v_cmp_eq_u64_e32 vcc, %[tag], %[t]\n\t"
         "s_cmp_eq_u64 vcc, exec\n\t"
         "s_cbranch_scc1 2f\n\t"
-        "global_load_dwordx2 v[252:253], %[p], off sc1\n\t"
-        "s_waitcnt vmcnt(1)\n\t"
-        "v_lshrrev_b64 %[t], 48, v[254:255]\n\t"
+        "global_load_dwordx2 v[250:251], %[p], off sc1\n\t"
+        "s_waitcnt vmcnt(2)\n\t"
+        "v_lshrrev_b64 %[t], 48, v[252:253]\n\t"
         "v_cmp_eq_u64_e32 vcc, %[tag], %[t]\n\t"
         "s_cmp_eq_u64 vcc, exec\n\t"
         "s_cbranch_scc1 3f\n\t"
+        "global_load_dwordx2 v[252:253], %[p], off sc1\n\t"
+        "s_waitcnt vmcnt(2)\n\t"
+        "v_lshrrev_b64 %[t], 48, v[254:255]\n\t"
+        "v_cmp_eq_u64_e32 vcc, %[tag], %[t]\n\t"
+        "s_cmp_eq_u64 vcc, exec\n\t"
+        "s_cbranch_scc1 5f\n\t"
         "global_load_dwordx2 v[254:255], %[p], off sc1\n\t"
         "s_sub_u32 %[n], %[n], 1\n\t"
         "s_cmp_lg_u32 %[n], 0\n\t"
@@ -921,14 +933,17 @@ __device__ __forceinline__ int t3_poll1(unsigned long long& x, const unsigned lo
         "s_waitcnt vmcnt(0)\n\t"
         "s_branch 4f\n"
         "2:\n\t"
-        "v_mov_b64 %[x], v[252:253]\n\t"
+        "v_mov_b64 %[x], v[250:251]\n\t"
         "s_branch 4f\n"
         "3:\n\t"
+        "v_mov_b64 %[x], v[252:253]\n\t"
+        "s_branch 4f\n"
+        "5:\n\t"
         "v_mov_b64 %[x], v[254:255]\n"
         "4:\n"
         : [x] "+v"(x), [t] "=&v"(t), [n] "=&s"(left)
         : [p] "v"(p), [tag] "s"(tag), [r] "s"(rounds)
-        : "vcc", "scc", "memory", "v252", "v253", "v254", "v255");
+        : "vcc", "scc", "memory", "v250", "v251", "v252", "v253", "v254", "v255");
     return left;
 }
 // the same for two granules per lane (p1, p2)
@@ -1107,7 +1122,7 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
             if (mine) left = t3_poll1(x, gp, tag, 16);
 #ifdef T3_POLLSTAT
             ps_t += (long long)__builtin_amdgcn_s_memtime() - tq0;
-            ps_n += 2 * (16 - __builtin_amdgcn_readfirstlane(left)) + 1;
+            ps_n += 3 * (16 - __builtin_amdgcn_readfirstlane(left)) + 1;
 #endif
             if (__builtin_amdgcn_readfirstlane(left) != 0) break;
             if ((budget -= 16) <= 0 || lds_peek(&S.flag[1]) != 0) {

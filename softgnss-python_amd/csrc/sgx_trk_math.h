@@ -145,8 +145,10 @@ SGX_HD double sgx_atan_short_k(double z, const SgxAtanCoef& k) {
 // atan(q / i) with the quotient by sgx_div1 and the coefficients in registers
 SGX_HD double sgx_atan_ratio_k(double q, double i, const SgxAtanCoef& k) {
     const double z = sgx_div1(q, i);
-    if (fabs(z) <= SGX_ATAN_SHORT_MAX) return sgx_atan_short_k(z, k);
-    return atan(q / i);
+    // (the short polynomial unconditionally, libm behind ONE cold branch: the usual path then runs straight through)
+    double r = sgx_atan_short_k(z, k);
+    if (__builtin_expect(!(fabs(z) <= SGX_ATAN_SHORT_MAX), 0)) r = atan(q / i);
+    return r;
 }
 
 // atan(q / i): the PLL discriminator's argument (tracking.py:223).  Short path while |q / i| <= 0.25 (a locked
