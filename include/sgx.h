@@ -94,8 +94,8 @@ typedef struct sgx_scene {
 /* Timings of the last call, measured with HIP events on the context's stream. */
 typedef struct sgx_timing {
     float acquire_ms;        /* whole sgx_acquire device time */
-    float acq_coarse_ms;     /* mix + FFTs + correlation + peak search */
-    float acq_fine_ms;       /* fine-frequency FFTs */
+    float acq_coarse_ms;     /* mix + FFTs + correlation + peak search; the split is measured with SGX_ACQ_SPLIT_EVENT=1 */
+    float acq_fine_ms;       /* fine-frequency FFTs                     (else: coarse = the whole call, fine = 0)          */
     float track_ms;          /* the tracking kernel */
     float synth_ms;          /* the generator kernel */
     float track_kernel;      /* which tracking kernel the last sgx_track ran: 2 latency-mode (sgx_trk2.hip), 3 throughput-mode

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(128) void acq_setup_kernel(AcqSetup a, int* __restr
     if (t < a.n_prn) d_prn[t] = a.prn[t];
     if (t < a.n_bins) d_bin[t] = a.bin[t];
     if (t < 32) d_second[t] = 0.0;
-    if (t < 32 && d_arrived) d_arrived[t] = 0;
+    if (t < 64 && d_arrived) d_arrived[t] = 0;   // [32] per PRN, [32] PRNs finished
     if (t == 0) d_sum[0] = 0;
 }
 
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) void acq_front_kernel(AcqSetup su, SgxSig x, P
     if (t < su.n_prn) d_prn[t] = su.prn[t];
     if (t < su.n_bins) d_bin[t] = su.bin[t];
     if (t < 32) d_second[t] = 0.0;
-    if (t < 32) d_arrived[t] = 0;
+    if (t < 64) d_arrived[t] = 0;   // [32] rows finished per PRN, [32] PRNs finished
     if (t == 0) sum_next[0] = 0;
 }
 
@@ -965,39 +965,54 @@ struct CoarseLook {
 static_assert(sizeof(CoarseLook) <= 4096, "one pinned page");
 
 // det (device memory, read by the fine kernels): [0] n_det, [1 + d] PRN index, [33 + d] code phase
-__global__ __launch_bounds__(64) void acq_publish_kernel(const PeakOut* __restrict__ po, const double* __restrict__ second,
-                                                         int n_prn, CoarseLook* __restrict__ host, unsigned long long seq,
-                                                         const int* __restrict__ prn_list, double threshold,
-                                                         long long fine_len, long long n_samples, int* __restrict__ det) {
-    const int t = threadIdx.x;
+// SAME_LAUNCH: the peaks were written by other waves of this launch (device-scope stores): read them the same way.
+template <bool SAME_LAUNCH>
+__device__ __forceinline__ void acq_publish_body(const PeakOut* __restrict__ po, const double* __restrict__ second, int n_prn,
+                                                 CoarseLook* __restrict__ host, const int* __restrict__ prn_list,
+                                                 double threshold, long long fine_len, long long n_samples,
+                                                 int* __restrict__ det, int t) {
     const int* src = reinterpret_cast<const int*>(po);
     int* dst = reinterpret_cast<int*>(&host->po);
-    for (int i = t; i < (int)(sizeof(PeakOut) / sizeof(int)); i += 64) dst[i] = src[i];
-    if (t < n_prn) host->second[t] = second[t];
+    for (int i = t; i < (int)(sizeof(PeakOut) / sizeof(int)); i += 64) dst[i] = SAME_LAUNCH ? ACQ_LD(src + i) : src[i];
+    double sec = 0.0, pk = 0.0;
+    int ie = 0, cp = 0;
+    if (t < n_prn) {
+        sec = SAME_LAUNCH ? ACQ_LD(second + t) : second[t];
+        pk = SAME_LAUNCH ? ACQ_LD(po->peak + t) : po->peak[t];
+        ie = SAME_LAUNCH ? ACQ_LD(po->index_error + t) : po->index_error[t];
+        cp = SAME_LAUNCH ? ACQ_LD(po->cph + t) : po->cph[t];
+        host->second[t] = sec;
+    }
     if (det) {
         // acquisition.py:164-166: detected iff peak / second peak > acqThreshold; the list in ascending PRN position
-        const bool hit = t < n_prn && po->index_error[t] == 0 && (po->peak[t] / second[t]) > threshold;
+        const bool hit = t < n_prn && ie == 0 && (pk / sec) > threshold;
         const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
         const int d = __builtin_popcountll(m & ((1ull << t) - 1ull));
-        const bool out = hit && (long long)po->cph[t] + fine_len > n_samples;   // (the reference would fail to broadcast)
+        const bool out = hit && (long long)cp + fine_len > n_samples;   // (the reference would fail to broadcast)
         const unsigned long long mo = __builtin_amdgcn_ballot_w64(out);
         if (hit) {
             det[1 + d] = prn_list[t];
-            det[33 + d] = po->cph[t];
+            det[33 + d] = cp;
             host->det_slot[d] = t;
-            host->det_phase[d] = po->cph[t];
+            host->det_phase[d] = cp;
         }
         if (t == 0) {
             det[80] = 0;                                    // fine_rows_kernel's arrival counter
             det[0] = mo ? 0 : __builtin_popcountll(m);      // (an error: the fine kernels have nothing to do)
             host->n_det = __builtin_popcountll(m);
             host->range_error = mo ? 1 + __builtin_ctzll(mo) : 0;
-        }
+            host->seq = 0ull;   // device-led: `host` is a device-side copy of the page; fine_rows_kernel's last workgroup
+        }                       // copies it to the real one and the host waits for seq2
     }
-    if (det) {         // device-led: `host` is a device-side copy of the page; fine_rows_kernel's last workgroup copies it
-        if (t == 0) host->seq = 0ull;   // to the real one and the host waits for seq2
-        return;
-    }
+}
+
+__global__ __launch_bounds__(64) void acq_publish_kernel(const PeakOut* __restrict__ po, const double* __restrict__ second,
+                                                         int n_prn, CoarseLook* __restrict__ host, unsigned long long seq,
+                                                         const int* __restrict__ prn_list, double threshold,
+                                                         long long fine_len, long long n_samples, int* __restrict__ det) {
+    const int t = threadIdx.x;
+    acq_publish_body<false>(po, second, n_prn, host, prn_list, threshold, fine_len, n_samples, det, t);
+    if (det) return;
     __threadfence_system();
     __syncthreads();
     if (t == 0) __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1116,6 +1131,112 @@ __global__ __launch_bounds__(64) void acq_rowmax_peak_kernel(const double* __res
         acq_peak_one(rowmax, rowarg, n_prn + lane, 0, n_prn, out_per_prn, n_bins, n_blocks, noncoh, N, spc, po, sa, row_map);
 }
 
+// The peak of one PRN on every lane of the wave (acq_peak_one's scan, result broadcast).
+__device__ __forceinline__ AcqCand acq_peak_scan(const double* __restrict__ pm, const int* __restrict__ pa, int lane,
+                                                 int n_bins, int n_blocks, int noncoh) {
+    AcqCand c;
+    c.v = -1.0;
+    c.k = -1;
+    c.a = c.b = 0;
+    for (int k = lane; k < n_bins; k += 64) c = acq_peak_join(c, acq_peak_bin(pm, pa, n_bins, n_blocks, noncoh != 0, k));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        AcqCand o;
+        o.v = __shfl_down(c.v, off);
+        o.k = __shfl_down(c.k, off);
+        o.a = __shfl_down(c.a, off);
+        o.b = __shfl_down(c.b, off);
+        c = acq_peak_join(c, o);
+    }
+    c.v = __shfl(c.v, 0);
+    c.k = __shfl(c.k, 0);
+    c.a = __shfl(c.a, 0);
+    c.b = __shfl(c.b, 0);
+    return c;
+}
+
+struct PublishArgs {
+    CoarseLook* stage;          // device-side copy of the result page, or null: a publish kernel follows
+    const int* prn_list;
+    double threshold;
+    long long fine_len, n_samples;
+    int* det;
+};
+
+// Round 5: row maxima, peak, SECOND PEAK and the detection list in one launch, from the rows kernel's per-residue
+// (maximum, maximum of the others, first index) triples - the winning row is not transformed again (two launches, 39 us
+// of the 8-rank shard of config 4) and no publish kernel follows (10 us).  A wave finishes one output row; the wave that
+// finishes the last row of a PRN goes on to that PRN's block choice, global peak, exclusion list (acquisition.py:129-162)
+// and the maximum over the allowed indices: the excluded ones are fewer than `nres` consecutive indices, at most one per
+// residue, so a residue contributes its maximum if that is allowed and else the maximum of its others - the same powers
+// the first pass formed.  The wave that finishes the last PRN decides the detections (acquisition.py:164-166).
+__global__ __launch_bounds__(64) void acq_rowtop2_peak_kernel(const double* __restrict__ b1, const double* __restrict__ b2,
+                                                              const int* __restrict__ i1, int nres,
+                                                              double* __restrict__ rowmax, int* __restrict__ rowarg,
+                                                              int* __restrict__ arrived, int n_prn, int out_per_prn,
+                                                              int n_bins, int n_blocks, int noncoh, long long N, int spc,
+                                                              PeakOut* __restrict__ po, double* __restrict__ second,
+                                                              PublishArgs pub) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    double best = -1.0;
+    int arg = 0;
+    for (int r = lane; r < nres; r += 64) {
+        const double v = b1[(long long)row * nres + r];
+        const int i = i1[(long long)row * nres + r];
+        if (v > best || (v == best && i < arg)) {
+            best = v;
+            arg = i;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_down(best, o);
+        const int oi = __shfl_down(arg, o);
+        if (ov > best || (ov == best && oi < arg)) {
+            best = ov;
+            arg = oi;
+        }
+    }
+    const int pi = row / out_per_prn;
+    int last = 0;
+    if (lane == 0) {
+        ACQ_ST(rowmax + row, best);
+        ACQ_ST(rowarg + row, arg);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // both written through before the arrival is counted
+        last = __hip_atomic_fetch_add(arrived + pi, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == out_per_prn;
+    }
+    last = __builtin_amdgcn_readfirstlane(last);
+    if (!last) return;
+    const AcqCand c = acq_peak_scan(rowmax + (long long)pi * out_per_prn, rowarg + (long long)pi * out_per_prn, lane, n_bins,
+                                    n_blocks, noncoh);
+    int lo0, hi0, lo1, hi1;
+    const int bad = acq_peak_ranges(c.a, N, spc, &lo0, &hi0, &lo1, &hi1);
+    double sec = 0.0;
+    if (!bad) {
+        const long long wrow = ((long long)pi * out_per_prn + (noncoh ? c.k : c.b * n_bins + c.k)) * nres;
+        for (int r = lane; r < nres; r += 64) {
+            const int idx = i1[wrow + r];
+            const double v1 = b1[wrow + r], v2 = b2[wrow + r];   // (both: three independent loads)
+            const bool in = (idx >= lo0 && idx < hi0) || (idx >= lo1 && idx < hi1);
+            sec = fmax(sec, in ? v1 : v2);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) sec = fmax(sec, __shfl_down(sec, o));
+    int done = 0;
+    if (lane == 0) {
+        ACQ_ST(po->peak + pi, c.v);
+        ACQ_ST(po->cph + pi, c.a);
+        ACQ_ST(po->fbi + pi, c.k);
+        ACQ_ST(po->index_error + pi, bad);
+        ACQ_ST(second + pi, sec);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        done = __hip_atomic_fetch_add(arrived + 32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == n_prn;
+    }
+    done = __builtin_amdgcn_readfirstlane(done);
+    if (!done || !pub.stage) return;
+    acq_publish_body<true>(po, second, n_prn, pub.stage, pub.prn_list, pub.threshold, pub.fine_len, pub.n_samples, pub.det,
+                           lane);
+}
+
 // The acquisition on the four-step transform (sgx_fft.hip): every 38192-point transform is two kernels with register-resident
 // sub-transforms, the mixed-signal spectra are computed once per (block, phi) and read with a circular shift, results
 // land where they are needed (no device-to-device copies) and the host looks at the device ONCE, at the very end of the
@@ -1190,17 +1311,28 @@ static int acquire_four_step(sgx_ctx* c, SgxSig x, size_t n_samples, const int32
     if ((rc = ensure_buf((void**)&c->d_work[1], &c->cap_w1, work_rows * row_bytes)) != SGX_OK) return rc;
     if ((rc = ensure_buf((void**)&c->d_fwd, &c->cap_fwd, (size_t)(rows_fwd + n_prn) * row_bytes)) != SGX_OK) return rc;
     const int nblk = sgx_fft4_row_blocks();
+    const int nres = sgx_fft4_residues();
     const int rows_out_all = n_prn * (noncoh ? n_bins : rows_per_prn);
+    // Round 5: peak and second peak from ONE pass (acq_rowtop2_peak_kernel) when the exclusion list leaves out fewer than
+    // `nres` consecutive indices (2 spc of them at most: any sampling rate below 111 MHz); SGX_ACQ_TOP2=0: the round-4
+    // sequence, which transforms each PRN's winning row a second time
+    const char* t2e = getenv("SGX_ACQ_TOP2");
+    const bool top2 = 2 * spc + 1 <= nres && !(t2e && t2e[0] == '0');
     size_t pow_need = (size_t)rows_out_all * nblk * 12 + 4096;
     if (noncoh && pow_need < (size_t)n_prn * sizeof(double) * (size_t)N) pow_need = (size_t)n_prn * sizeof(double) * (size_t)N;
-    // [per-workgroup maxima | their indices | row maxima | row indices], then (non-coherent) the second-peak power rows
-    const size_t red_bytes = ((size_t)rows_out_all * nblk * 12 + (size_t)rows_out_all * 12 + 1023) / 256 * 256;
+    // [per-workgroup maxima | their indices] or [per-residue maxima | second maxima | indices], [row maxima | row indices],
+    // then (non-coherent, round-4 sequence) the second-peak power rows
+    const size_t part_bytes = (((size_t)rows_out_all * (top2 ? (size_t)nres * 20 : (size_t)nblk * 12)) + 255) / 256 * 256;
+    const size_t red_bytes = (part_bytes + (size_t)rows_out_all * 12 + 1023) / 256 * 256;
     if ((rc = ensure_buf((void**)&c->d_pow, &c->cap_pow, red_bytes + pow_need)) != SGX_OK) return rc;
     char* red = (char*)c->d_pow;
     double* d_pmax = (double*)red;
     int* d_parg = (int*)(red + (size_t)rows_out_all * nblk * 8);
-    double* d_rowmax = (double*)(red + (size_t)rows_out_all * nblk * 12);
-    int* d_rowarg = (int*)(red + (size_t)rows_out_all * nblk * 12 + (size_t)rows_out_all * 8);
+    double* d_t2b1 = (double*)red;
+    double* d_t2b2 = d_t2b1 + (size_t)rows_out_all * nres;
+    int* d_t2i1 = (int*)(d_t2b2 + (size_t)rows_out_all * nres);
+    double* d_rowmax = (double*)(red + part_bytes);
+    int* d_rowarg = (int*)(red + part_bytes + (size_t)rows_out_all * 8);
     double* d_power = (double*)(red + red_bytes);
 
     char* dsm = (char*)c->d_small;
@@ -1272,20 +1404,58 @@ static int acquire_four_step(sgx_ctx* c, SgxSig x, size_t n_samples, const int32
         fu.prn_base = p0;
         fu.n_blocks = n_blocks;
         fu.blocks_fast = noncoh ? 1 : 0;
-        fu.pmax = d_pmax + (size_t)p0 * out_per_prn * nblk;
-        fu.parg = d_parg + (size_t)p0 * out_per_prn * nblk;
+        if (top2) {
+            fu.t2_b1 = d_t2b1 + (size_t)p0 * out_per_prn * nres;
+            fu.t2_b2 = d_t2b2 + (size_t)p0 * out_per_prn * nres;
+            fu.t2_i1 = d_t2i1 + (size_t)p0 * out_per_prn * nres;
+        } else {
+            fu.pmax = d_pmax + (size_t)p0 * out_per_prn * nblk;
+            fu.parg = d_parg + (size_t)p0 * out_per_prn * nblk;
+        }
         fu.inv_n = inv_n;
         fu.sum_blocks = noncoh ? n_blocks : 1;
         rc = sgx_fft4_forward(&c->plan_code, nullptr, c->d_work[0], nullptr, (int64_t)np * rows_per_prn, st, &fu);
         if (rc != SGX_OK) return rc;
     }
-    // ---- device: row maxima, then per PRN block choice, global peak, exclusion list; the rows the second-peak search
-    //      reads ------------------------------------------------------------------------------------------------------
+    // ---- the fine search is queued right behind the coarse one: the detections are decided on the device
+    //      (acquisition.py:164-166) and the fine kernels read their list, so the host looks ONCE, at the very end ----------
+    const unsigned long long seq = ++c->look_seq;
+    const long long fine_len = 10 * N;
+    const long long npts = 8ll << (long long)ceil(log2((double)fine_len));
+    const long long uniq = (long long)ceil((double)(npts + 1) / 2.0);
+    const char* fv1 = getenv("SGX_ACQ_FINE_V1");
+    const char* dl0 = getenv("SGX_ACQ_DEVICE_LED");
+    const bool device_led = sgx_fft_fine_supported(npts) && !(fv1 && fv1[0] == '1') && !(dl0 && dl0[0] == '0') && n_prn <= 32;
+    int* d_det = (int*)(dsm + 640000);
+    double* d_pv = (double*)(dsm + 65536);
+    long long* d_pi = (long long*)(dsm + 400000);
+    if (device_led) {
+        // (before the last coarse kernels are queued: nothing of the host's between them and the fine kernels)
+        rc = sgx_fft_plan_create(&c->plan_fine, npts);
+        if (rc != SGX_OK) return rc;
+        const int max_rows = (n_prn + 1) / 2;   // two real signals per complex row; only the detections' rows are touched
+        if ((rc = ensure_buf((void**)&c->d_fine[0], &c->cap_f0, (size_t)max_rows * sizeof(cplx) * (size_t)npts)) != SGX_OK) return rc;
+    }
+    // (device-led: into a device-side copy of the page - a kernel that writes host memory ends with a flush the next one
+    // waits for, 5 us in front of the fine search)
+    CoarseLook* const d_stage = (CoarseLook*)(dsm + 700000);
+    // ---- device: row maxima, then per PRN block choice, global peak, exclusion list, second peak -----------------------
     PeakOut* d_po = (PeakOut*)(dsm + 620000);
     SecondArgs* d_sa = (SecondArgs*)(dsm + 600000);
-    acq_rowmax_peak_kernel<<<rows_out_all, 64, 0, st>>>(d_pmax, d_parg, nblk, d_rowmax, d_rowarg, d_arrived, n_prn,
-                                                        out_per_prn, n_bins, n_blocks, noncoh, N, spc, d_po, d_sa, d_map);
-    {
+    if (top2) {
+        PublishArgs pub;
+        pub.stage = device_led ? d_stage : nullptr;
+        pub.prn_list = d_prn;
+        pub.threshold = S.acqThreshold;
+        pub.fine_len = fine_len;
+        pub.n_samples = (long long)n_samples;
+        pub.det = d_det;
+        acq_rowtop2_peak_kernel<<<rows_out_all, 64, 0, st>>>(d_t2b1, d_t2b2, d_t2i1, nres, d_rowmax, d_rowarg, d_arrived, n_prn,
+                                                             out_per_prn, n_bins, n_blocks, noncoh, N, spc, d_po, d_second, pub);
+    } else {
+        acq_rowmax_peak_kernel<<<rows_out_all, 64, 0, st>>>(d_pmax, d_parg, nblk, d_rowmax, d_rowarg, d_arrived, n_prn,
+                                                            out_per_prn, n_bins, n_blocks, noncoh, N, spc, d_po, d_sa, d_map);
+        // the rows the second-peak search reads, transformed again
         const int rows2 = n_prn * (noncoh ? n_blocks : 1);
         Fft4Fuse fu;
         fu.mul_x = c->d_fwd;
@@ -1306,31 +1476,12 @@ static int acquire_four_step(sgx_ctx* c, SgxSig x, size_t n_samples, const int32
         rc = sgx_fft4_forward(&c->plan_code, nullptr, c->d_work[0], nullptr, rows2, st, &fu);
         if (rc != SGX_OK) return rc;
     }
-    // ---- the fine search, queued right behind the coarse one: the publish kernel decides the detections on the device
-    //      (acquisition.py:164-166) and the fine kernels read its list, so the host looks ONCE, at the very end ----------
-    const unsigned long long seq = ++c->look_seq;
-    const long long fine_len = 10 * N;
-    const long long npts = 8ll << (long long)ceil(log2((double)fine_len));
-    const long long uniq = (long long)ceil((double)(npts + 1) / 2.0);
-    const char* fv1 = getenv("SGX_ACQ_FINE_V1");
-    const char* dl0 = getenv("SGX_ACQ_DEVICE_LED");
-    const bool device_led = sgx_fft_fine_supported(npts) && !(fv1 && fv1[0] == '1') && !(dl0 && dl0[0] == '0') && n_prn <= 32;
-    int* d_det = (int*)(dsm + 640000);
-    double* d_pv = (double*)(dsm + 65536);
-    long long* d_pi = (long long*)(dsm + 400000);
-    if (device_led) {
-        // (before the publish kernel is queued: nothing of the host's between it and the fine kernels)
-        rc = sgx_fft_plan_create(&c->plan_fine, npts);
-        if (rc != SGX_OK) return rc;
-        const int max_rows = (n_prn + 1) / 2;   // two real signals per complex row; only the detections' rows are touched
-        if ((rc = ensure_buf((void**)&c->d_fine[0], &c->cap_f0, (size_t)max_rows * sizeof(cplx) * (size_t)npts)) != SGX_OK) return rc;
-    }
-    // (device-led: into a device-side copy of the page - a kernel that writes host memory ends with a flush the next one
-    // waits for, 5 us in front of the fine search)
-    CoarseLook* const d_stage = (CoarseLook*)(dsm + 700000);
-    acq_publish_kernel<<<1, 64, 0, st>>>(d_po, d_second, n_prn, device_led ? d_stage : (CoarseLook*)c->d_look, seq, d_prn,
-                                         S.acqThreshold, fine_len, (long long)n_samples, device_led ? d_det : nullptr);
-    hipEventRecord(c->ev[1], st);
+    if (!top2 || !device_led)
+        acq_publish_kernel<<<1, 64, 0, st>>>(d_po, d_second, n_prn, device_led ? d_stage : (CoarseLook*)c->d_look, seq, d_prn,
+                                             S.acqThreshold, fine_len, (long long)n_samples, device_led ? d_det : nullptr);
+    // (an event between the coarse and the fine kernels holds the fine search back by 6-8 us: recorded on request only)
+    static const bool split_event = getenv("SGX_ACQ_SPLIT_EVENT") && getenv("SGX_ACQ_SPLIT_EVENT")[0] == '1';
+    if (split_event || !device_led) hipEventRecord(c->ev[1], st);
     SGX_HIP(hipGetLastError());
     if (device_led) {
         rc = sgx_fft_fine_search(&c->plan_fine, x, c->d_codes, nullptr, nullptr, n_prn, fine_len, d_sum, (double)n_samples, ts,
@@ -1395,8 +1546,13 @@ static int acquire_four_step(sgx_ctx* c, SgxSig x, size_t n_samples, const int32
         rc = acquire_fine(c, x, n_samples, det_prn, det_phase, det_slot, d_sum, carrFreq, codePhase, fineIdx);
         if (rc != SGX_OK) return rc;
     }
-    hipEventElapsedTime(&c->timing.acq_coarse_ms, c->ev[0], c->ev[1]);
-    hipEventElapsedTime(&c->timing.acq_fine_ms, c->ev[1], c->ev[2]);
     hipEventElapsedTime(&c->timing.acquire_ms, c->ev[0], c->ev[2]);
+    if (split_event || !device_led) {
+        hipEventElapsedTime(&c->timing.acq_coarse_ms, c->ev[0], c->ev[1]);
+        hipEventElapsedTime(&c->timing.acq_fine_ms, c->ev[1], c->ev[2]);
+    } else {
+        c->timing.acq_coarse_ms = c->timing.acquire_ms;
+        c->timing.acq_fine_ms = 0.0f;
+    }
     return SGX_OK;
 }

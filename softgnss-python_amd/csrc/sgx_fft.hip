@@ -508,6 +508,9 @@ struct F4Args {
     int sum_blocks;         // > 1: powers of this many consecutive input rows are added first (input row = row * sum_blocks + b)
     const int* sec;         // rows kernel, MODE 4: [5][32] row / lo0 / hi0 / lo1 / hi1 of the second-peak search
     double* second_out;     // [32]
+    double* t2_b1;          // rows kernel, MODE 5: [rows][217] per output residue: maximum, maximum of the others, first index
+    double* t2_b2;
+    int* t2_i1;
 };
 
 __device__ __forceinline__ cplx f4_twiddle(const F4Args& a, long long t) {
@@ -984,6 +987,52 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(F4R_WAVES_N
         }
         return;
     }
+    if (MODE == 5) {
+        // Per output residue k1 = k mod 217 (176 outputs, eleven lanes): the maximum, its first index, and the maximum of
+        // the OTHER 175.  The second-peak search excludes fewer than 217 consecutive indices around the peak - at most one
+        // per residue - so the row's maximum over the allowed indices is max_k1 (index allowed ? first : second), exactly,
+        // and the winning row need not be transformed again (round 5; acq_rowtop2_peak_kernel).
+        double b1 = -1.0, b2 = -1.0;
+        int i1 = 0x7FFFFFFF;
+        if (s2) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {   // (ascending index: the first of equal maxima stays, its twin is the second)
+                const double v = acc[c];
+                const bool gt = v > b1;
+                b2 = fmax(b2, fmin(b1, v));
+                b1 = gt ? v : b1;
+                i1 = gt ? idx0 + N1 * 11 * c : i1;
+            }
+        }
+        __syncthreads();
+        double* s_b1 = reinterpret_cast<double*>(buf);
+        double* s_b2 = s_b1 + CB * 11;
+        int* s_i1 = reinterpret_cast<int*>(s_b2 + CB * 11);
+        if (s2) {
+            s_b1[tid] = b1;
+            s_b2[tid] = b2;
+            s_i1[tid] = i1;
+        }
+        __syncthreads();
+        if (tid < CB) {
+            double B1 = s_b1[tid * 11], B2 = s_b2[tid * 11];
+            int I1 = s_i1[tid * 11];
+#pragma unroll
+            for (int d = 1; d < 11; ++d) {
+                const double c1 = s_b1[tid * 11 + d], c2 = s_b2[tid * 11 + d];
+                const int ci = s_i1[tid * 11 + d];
+                const bool take = c1 > B1 || (c1 == B1 && ci < I1);
+                B2 = fmax(fmax(B2, c2), take ? B1 : c1);
+                B1 = take ? c1 : B1;
+                I1 = take ? ci : I1;
+            }
+            const long long o = row * N1 + k10 + tid;
+            a.t2_b1[o] = B1;
+            a.t2_b2[o] = B2;
+            a.t2_i1[o] = I1;
+        }
+        return;
+    }
     double best = -1.0;
     int arg = 0x7FFFFFFF;
     if (s2) {
@@ -1031,6 +1080,7 @@ static int f4_ensure_sub_tables(int dev) {
     return SGX_OK;
 }
 int sgx_fft4_row_blocks(void) { return F4_N1 / F4_CB; }
+int sgx_fft4_residues(void) { return F4_N1; }
 
 template <int MODE>
 static void f4_launch_cols(const F4Args& a, int64_t rows, hipStream_t st) {
@@ -1116,6 +1166,13 @@ int sgx_fft4_forward(const FftPlan* p, const cplx* in, cplx* work, cplx* out, in
         a.inv_n = fuse->inv_n;
         a.sum_blocks = sum_blocks;
         f4_launch_rows<4>(a, rows / sum_blocks, st);
+    } else if (fuse && fuse->t2_b1) {
+        a.t2_b1 = fuse->t2_b1;
+        a.t2_b2 = fuse->t2_b2;
+        a.t2_i1 = fuse->t2_i1;
+        a.inv_n = fuse->inv_n;
+        a.sum_blocks = sum_blocks;
+        f4_launch_rows<5>(a, rows / sum_blocks, st);
     } else if (fuse && fuse->pmax) {
         a.pmax = fuse->pmax;
         a.parg = fuse->parg;

@@ -172,6 +172,11 @@ struct Fft4Fuse {
     // the second-peak search (acquisition.py:162) without a stored row
     const int* sec = nullptr;
     double* second_out = nullptr;
+    // ... or, per output row and residue k mod sgx_fft4_residues(): the maximum power, the maximum of the residue's other
+    // powers and the maximum's first index ([rows / sum_blocks][residues] each): peak AND second peak from one pass
+    double* t2_b1 = nullptr;
+    double* t2_b2 = nullptr;
+    int* t2_i1 = nullptr;
 };
 bool sgx_fft_fine_supported(int64_t npts);
 int sgx_fft_fine_partials(void);
@@ -186,6 +191,7 @@ int sgx_fft_fine_search(const FftPlan* plan, SgxSig x, const int8_t* codes, cons
                         int* stage_dst = nullptr, int stage_words = 0);
 bool sgx_fft4_supported(int64_t n);
 int sgx_fft4_row_blocks(void);
+int sgx_fft4_residues(void);
 int sgx_fft4_forward(const FftPlan* p, const cplx* in, cplx* work, cplx* out, int64_t rows, hipStream_t st,
                      const Fft4Fuse* fuse);
 

@@ -826,7 +826,7 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
                     const unsigned long long tot = prev + mine;
                     S.acc[par][word] = 0ull;
                     const unsigned long long gran = ((unsigned long long)((unsigned)(it + 1) & 0xFFFFu) << 48) | (tot & 0xFFFFFFFFFFFFull);
-                    granule_store(xbase + (par * 6 + word) * T3_XLINE + unit, gran, fast);
+                    granule_store(xbase + ((((par * 3 + (word >> 1)) * T3_XLINE + unit) << 1) | (word & 1)), gran, fast);
                     if (prof_any && word == 0) S.tpub[par] = (long long)__builtin_amdgcn_s_memtime();
                 }
             }
@@ -946,40 +946,35 @@ __device__ __forceinline__ int t3_poll1(unsigned long long& x, const unsigned lo
         : "vcc", "scc", "memory", "v250", "v251", "v252", "v253", "v254", "v255");
     return left;
 }
-// the same for two granules per lane (p1, p2)
+// The DLL wave's poll: an arm's I and Q granules of a unit lie side by side and ONE 16-byte load per look fetches both
+// (round 5; before: two 8-byte loads per look, two looks in flight - this wave found its sums 430 cycles after the PLL wave
+// found its own and was the last at the barrier of every block, profiles/r05_trk_phase_profile.txt).  Three in flight.
+#define T3_TAGSEL 0x07060302u      // v_perm_b32: {upper half of the first source, upper half of the second}
 __device__ __forceinline__ int t3_poll2(unsigned long long& x1, unsigned long long& x2, const unsigned long long* p1,
                                         const unsigned long long* p2, unsigned long long tag, int rounds) {
-    unsigned long long t, m;
+    (void)p2;
+    unsigned t;
     int left;
+    const unsigned tag2 = (unsigned)tag | ((unsigned)tag << 16);
+#define T3_P2_CHECK(r0, r1, r3, lbl)                                   \
+        "s_waitcnt vmcnt(2)\n\t"                                        \
+        "v_perm_b32 %[t], v" #r3 ", v" #r1 ", %[sel]\n\t"               \
+        "v_cmp_eq_u32_e32 vcc, %[tag2], %[t]\n\t"                       \
+        "s_cmp_eq_u64 vcc, exec\n\t"                                    \
+        "s_cbranch_scc1 " lbl "\n\t"                                    \
+        "global_load_dwordx4 v[" #r0 ":" #r3 "], %[p], off sc1\n\t"
     asm volatile(
         "s_waitcnt vmcnt(0)\n\t"
-        "global_load_dwordx2 v[244:245], %[p1], off sc1\n\t"
-        "global_load_dwordx2 v[246:247], %[p2], off sc1\n\t"
-        "s_sleep " T3_STR(T3_POLL_GAP) "\n\t"
-        "global_load_dwordx2 v[248:249], %[p1], off sc1\n\t"
-        "global_load_dwordx2 v[250:251], %[p2], off sc1\n\t"
+        "global_load_dwordx4 v[244:247], %[p], off sc1\n\t"
+        "s_sleep " T3_STR(T3_POLL_GAP3) "\n\t"
+        "global_load_dwordx4 v[248:251], %[p], off sc1\n\t"
+        "s_sleep " T3_STR(T3_POLL_GAP3) "\n\t"
+        "global_load_dwordx4 v[252:255], %[p], off sc1\n\t"
         "s_mov_b32 %[n], %[r]\n"
         "1:\n\t"
-        "s_waitcnt vmcnt(2)\n\t"
-        "v_lshrrev_b64 %[t], 48, v[244:245]\n\t"
-        "v_cmp_eq_u64_e32 vcc, %[tag], %[t]\n\t"
-        "v_lshrrev_b64 %[t], 48, v[246:247]\n\t"
-        "v_cmp_eq_u64_e64 %[m], %[tag], %[t]\n\t"
-        "s_and_b64 vcc, vcc, %[m]\n\t"
-        "s_cmp_eq_u64 vcc, exec\n\t"
-        "s_cbranch_scc1 2f\n\t"
-        "global_load_dwordx2 v[244:245], %[p1], off sc1\n\t"
-        "global_load_dwordx2 v[246:247], %[p2], off sc1\n\t"
-        "s_waitcnt vmcnt(2)\n\t"
-        "v_lshrrev_b64 %[t], 48, v[248:249]\n\t"
-        "v_cmp_eq_u64_e32 vcc, %[tag], %[t]\n\t"
-        "v_lshrrev_b64 %[t], 48, v[250:251]\n\t"
-        "v_cmp_eq_u64_e64 %[m], %[tag], %[t]\n\t"
-        "s_and_b64 vcc, vcc, %[m]\n\t"
-        "s_cmp_eq_u64 vcc, exec\n\t"
-        "s_cbranch_scc1 3f\n\t"
-        "global_load_dwordx2 v[248:249], %[p1], off sc1\n\t"
-        "global_load_dwordx2 v[250:251], %[p2], off sc1\n\t"
+        T3_P2_CHECK(244, 245, 247, "2f")
+        T3_P2_CHECK(248, 249, 251, "3f")
+        T3_P2_CHECK(252, 253, 255, "5f")
         "s_sub_u32 %[n], %[n], 1\n\t"
         "s_cmp_lg_u32 %[n], 0\n\t"
         "s_cbranch_scc1 1b\n\t"
@@ -991,11 +986,17 @@ __device__ __forceinline__ int t3_poll2(unsigned long long& x1, unsigned long lo
         "s_branch 4f\n"
         "3:\n\t"
         "v_mov_b64 %[x1], v[248:249]\n\t"
-        "v_mov_b64 %[x2], v[250:251]\n"
+        "v_mov_b64 %[x2], v[250:251]\n\t"
+        "s_branch 4f\n"
+        "5:\n\t"
+        "v_mov_b64 %[x1], v[252:253]\n\t"
+        "v_mov_b64 %[x2], v[254:255]\n"
         "4:\n"
-        : [x1] "+v"(x1), [x2] "+v"(x2), [t] "=&v"(t), [m] "=&s"(m), [n] "=&s"(left)
-        : [p1] "v"(p1), [p2] "v"(p2), [tag] "s"(tag), [r] "s"(rounds)
-        : "vcc", "scc", "memory", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251");
+        : [x1] "+v"(x1), [x2] "+v"(x2), [t] "=&v"(t), [n] "=&s"(left)
+        : [p] "v"(p1), [tag2] "s"(tag2), [r] "s"(rounds), [sel] "s"(T3_TAGSEL)
+        : "vcc", "scc", "memory", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254",
+          "v255");
+#undef T3_P2_CHECK
     return left;
 }
 
@@ -1108,7 +1109,7 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
         t2_carr_entry(c_hi, c_lo, inv_2pi, w_cur, rc, mi, w3, cs_p, sn_p);
         T2_PIN(cs_p); T2_PIN(sn_p); T2_PIN(mf); T2_PIN(rc);   // (keeps all of this ahead of the wait)
         __builtin_amdgcn_s_setprio(3);
-        const unsigned long long* gp = xbase + (par * 6 + (lane >> 5)) * T3_XLINE + (lane & 31);
+        const unsigned long long* gp = xbase + ((((par * 3 + 0) * T3_XLINE + (lane & 31)) << 1) | (lane >> 5));   // (I_P, Q_P of a unit lie side by side)
         const unsigned long long tag = (unsigned long long)((unsigned)(it + 1) & 0xFFFFu);
         unsigned long long x = 0;
         int budget = T2_POLL_BUDGET;
@@ -1241,11 +1242,13 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
         __builtin_amdgcn_s_waitcnt(0xc07f);
         if (lane == 0) lds_poke(&S.rflag[0], it);
     }
+#ifndef T3_PROF_DLL
     if (prof && lane == 0) {
         prof[ch * T2_PROF_STRIDE + unit] = acc_map;
         prof[ch * T2_PROF_STRIDE + 64 + unit] = acc_xch;
         prof[ch * T2_PROF_STRIDE + 128 + unit] = acc_flt;
     }
+#endif
     T2_FP_PRINT(prof_on && lane == 0, 8, 12)
     T3_WB_PRINT(wb_on, "pll", ms)
 #ifdef T3_POLLSTAT
@@ -1267,8 +1270,9 @@ struct T3DllConst {
 __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const T3DllConst& D, long long pos0, int blk0,
                                            int stop0, bool owner, int lane, int P, int ch,
                                            unsigned long long* __restrict__ xbase, int* __restrict__ err, bool prof_on,
-                                           long long file_off, bool wb_on) {
-    (void)wb_on;
+                                           long long file_off, bool wb_on, long long* __restrict__ prof = nullptr,
+                                           int unit = -1) {
+    (void)wb_on; (void)prof; (void)unit;
     // tracking.py:114-121; block 0's chain part and ramp starts were posted before the loop
     double oldCodeNco = 0.0, oldCodeErr = 0.0;
     double k_a = K.k_code_a, k_b = K.k_code_b, basis = K.code_basis;
@@ -1291,12 +1295,18 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
     T2_FP_DECL
     T3_WB_DECL
     (void)prof_on;
+#ifdef T3_PROF_DLL   // (diagnosis, SGX_TRK_PROFILE=1) the three phase times of the profile are the DLL wave's: release -> poll
+    long long dp_in = 0, dp_wait = 0, dp_post = 0, dp_t0 = 0, dp_t1 = 0, dp_t2 = 0;   // entered -> sums found -> at the barrier
+#endif
     __builtin_amdgcn_s_setprio(3);
     int it = 0;
     for (; it < ms; ++it) {
         const int par = it & 1;
         T3Code& C = S.code[par];
         T3Code& N = S.code[par ^ 1];
+#ifdef T3_PROF_DLL
+        if (prof) dp_t0 = (long long)__builtin_amdgcn_s_memtime();
+#endif
         if (owner && it > 0) {
             double* R = S.rec[par ^ 1];
             // rows 1 / 3 hold the early / late arm's I (r_ve) and Q (r_vl) -> series 4 (I_E), 6 (Q_E), 5 (I_L), 8 (Q_L)
@@ -1352,12 +1362,15 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
         T2_PIN(a_next); T2_PIN(lim); T2_PIN(nco_base);
         __builtin_amdgcn_s_setprio(3);
         // lanes 0..31 follow the early arm, lanes 32..63 the late one: gp1 the I sums (words 2 | 4), gp2 the Q sums (3 | 5)
-        const unsigned long long* gp1 = xbase + (par * 6 + 2 + 2 * (lane >> 5)) * T3_XLINE + (lane & 31);
-        const unsigned long long* gp2 = gp1 + T3_XLINE;
+        const unsigned long long* gp1 = xbase + (((par * 3 + 1 + (lane >> 5)) * T3_XLINE + (lane & 31)) << 1);   // 16 bytes: I and Q
+        const unsigned long long* gp2 = gp1 + 1;
         const unsigned long long tag = (unsigned long long)((unsigned)(it + 1) & 0xFFFFu);
         unsigned long long x1 = 0, x2 = 0, xa = 0;
         int budget = T2_POLL_BUDGET;
         bool gave_up = false;
+#ifdef T3_PROF_DLL
+        if (prof) dp_t1 = (long long)__builtin_amdgcn_s_memtime();
+#endif
 #if defined(T3_POLL2) && (T3_POLL2 & 2)
         for (;;) {
             int left = 1;
@@ -1384,6 +1397,9 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
                 }
             }
         }
+#endif
+#ifdef T3_PROF_DLL
+        if (prof) dp_t2 = (long long)__builtin_amdgcn_s_memtime();
 #endif
         T2STAMP(prof_on, 12);  // waiting for the sums
         // T8 DLL (tracking.py:238-251).  Integer sums over the units (exact, order-free; lanes that poll nothing hold 0):
@@ -1433,6 +1449,13 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
             }
         }
         T2STAMP(prof_on, 14);  // next block's code parameters
+#ifdef T3_PROF_DLL
+        if (prof) {
+            dp_in += dp_t1 - dp_t0;
+            dp_wait += dp_t2 - dp_t1;
+            dp_post += (long long)__builtin_amdgcn_s_memtime() - dp_t2;
+        }
+#endif
         T3_WB(wb_on);
         __builtin_amdgcn_s_setprio(1);
         __builtin_amdgcn_sched_barrier(0);
@@ -1457,6 +1480,13 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
         if (lane == 0) lds_poke(&S.rflag[1], it);
     }
     T2_FP_PRINT(prof_on && lane == 0, 12, 16)
+#ifdef T3_PROF_DLL
+    if (prof && lane == 0) {
+        prof[ch * T2_PROF_STRIDE + unit] = dp_in;
+        prof[ch * T2_PROF_STRIDE + 64 + unit] = dp_wait;
+        prof[ch * T2_PROF_STRIDE + 128 + unit] = dp_post;
+    }
+#endif
     T3_WB_PRINT(wb_on, "dll", ms)
     return it;
 }
@@ -1542,6 +1572,7 @@ __global__ __launch_bounds__(T3_THREADS) void trk3_kernel(const int8_t* __restri
         S.flag[tid] = 0;
         S.rflag[tid] = 0;
     }
+
     if (tid < 16) S.acc[tid >> 3][tid & 7] = 0ull;
     if (tid < 2) {
         S.code[tid].xflag = 0;
@@ -1642,7 +1673,7 @@ __global__ __launch_bounds__(T3_THREADS) void trk3_kernel(const int8_t* __restri
     else if (wave == 4)
         done = t3_pll_role(S, K, cc, unit, owner, lane, P, ch, xbase, err, prof_on, prof, wb_on);
     else if (wave == 5)
-        done = t3_dll_role(S, K, D, cc.pos0, blk0, stop0, owner, lane, P, ch, xbase, err, prof_on, K.file_off, wb_on);
+        done = t3_dll_role(S, K, D, cc.pos0, blk0, stop0, owner, lane, P, ch, xbase, err, prof_on, K.file_off, wb_on, prof, unit);
     else
         done = t3_rec_role(S, K, rec, unit, ch, owner, lane, o, err, mark_seen, wb_on);
 
