@@ -1295,11 +1295,19 @@ static int acquire_four_step(sgx_ctx* c, SgxSig x, size_t n_samples, const int32
     // any more - that is 0.94 -> 0.80 ms for config 2 and 3.43 -> 3.24 ms for config 4 (tools/acq_chunk_probe.py; the
     // round-2 kernels measured no difference).
     int chunk_rows = 348;
+    // Round 5: the PRN chunks alternate between TWO queues, each with its own intermediate of half the size: the columns
+    // kernel is bound by its stores and the rows kernel by its loads, and with two chunks in flight the one's stores overlap
+    // the other's loads (SGX_ACQ_STREAMS=1: one queue).  Only where a half-size chunk still holds a whole PRN.  Measured:
+    // 0.822 -> 0.805 ms for config 2 - both kernels move their bytes at 3-5 TB/s over the same fabric (the intermediate lives
+    // in the Infinity Cache), there is little left to overlap; a producer / consumer fusion of the two has no more to win.
+    const char* se = getenv("SGX_ACQ_STREAMS");
+    bool two_q = !(se && se[0] == '1') && n_prn >= 2 && chunk_rows / 2 >= rows_per_prn;
     {
         const char* ce = getenv("SGX_ACQ_CHUNK_ROWS");
         if (ce && atoi(ce) > 0) chunk_rows = atoi(ce);
         if (chunk_rows > ACQ_MAX_ROWS) chunk_rows = ACQ_MAX_ROWS;
     }
+    if (two_q) chunk_rows /= 2;
     int prn_chunk = chunk_rows / rows_per_prn;
     if (prn_chunk < 1) prn_chunk = 1;
     if (prn_chunk > n_prn) prn_chunk = n_prn;
@@ -1392,7 +1400,22 @@ static int acquire_four_step(sgx_ctx* c, SgxSig x, size_t n_samples, const int32
     // ---- correlation, all PRN chunks queued back to back; row maxima of every PRN collected on the device -----------
     const double inv_n = 1.0 / (double)N;
     const int out_per_prn = noncoh ? n_bins : rows_per_prn;
-    for (int p0 = 0; p0 < n_prn; p0 += prn_chunk) {
+    hipStream_t st2 = st;
+    if (two_q) {
+        if (!c->acq_stream2) {
+            int least = 0, greatest = 0;
+            SGX_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            if (c->priority == 0) SGX_HIP(hipStreamCreateWithFlags(&c->acq_stream2, hipStreamNonBlocking));
+            else SGX_HIP(hipStreamCreateWithPriority(&c->acq_stream2, hipStreamNonBlocking, c->priority < 0 ? greatest : least));
+            for (int i = 0; i < 2; ++i) SGX_HIP(hipEventCreateWithFlags(&c->acq_ev2[i], hipEventDisableTiming));
+        }
+        st2 = c->acq_stream2;
+        // (the second queue's intermediate is the buffer the forward transforms read: they are queued in front)
+        SGX_HIP(hipEventRecord(c->acq_ev2[0], st));
+        SGX_HIP(hipStreamWaitEvent(st2, c->acq_ev2[0], 0));
+    }
+    int chunk_no = 0;
+    for (int p0 = 0; p0 < n_prn; p0 += prn_chunk, ++chunk_no) {
         const int np = (p0 + prn_chunk <= n_prn) ? prn_chunk : (n_prn - p0);
         Fft4Fuse fu;
         fu.mul_x = c->d_fwd;
@@ -1414,8 +1437,13 @@ static int acquire_four_step(sgx_ctx* c, SgxSig x, size_t n_samples, const int32
         }
         fu.inv_n = inv_n;
         fu.sum_blocks = noncoh ? n_blocks : 1;
-        rc = sgx_fft4_forward(&c->plan_code, nullptr, c->d_work[0], nullptr, (int64_t)np * rows_per_prn, st, &fu);
+        const int q = two_q ? (chunk_no & 1) : 0;
+        rc = sgx_fft4_forward(&c->plan_code, nullptr, c->d_work[q], nullptr, (int64_t)np * rows_per_prn, q ? st2 : st, &fu);
         if (rc != SGX_OK) return rc;
+    }
+    if (two_q) {
+        SGX_HIP(hipEventRecord(c->acq_ev2[1], st2));
+        SGX_HIP(hipStreamWaitEvent(st, c->acq_ev2[1], 0));
     }
     // ---- the fine search is queued right behind the coarse one: the detections are decided on the device
     //      (acquisition.py:164-166) and the fine kernels read their list, so the host looks ONCE, at the very end ----------

@@ -214,6 +214,9 @@ extern "C" int sgx_ctx_destroy(sgx_ctx* c) {
     if (c->spare_d) hipFree(c->spare_d);
     if (c->spare_mark) hipFree(c->spare_mark);
     if (c->spare_copy_stream) hipStreamDestroy(c->spare_copy_stream);
+    if (c->acq_stream2) hipStreamDestroy(c->acq_stream2);
+    for (int i = 0; i < 2; ++i)
+        if (c->acq_ev2[i]) hipEventDestroy(c->acq_ev2[i]);
     if (c->h_small) hipHostFree(c->h_small);
     if (c->h_look) hipHostFree(c->h_look);
     for (int i = 0; i < 6; ++i)

@@ -83,6 +83,8 @@ struct sgx_ctx {
     int device = 0;
     int priority = 0;            // stream priority class of the context: -1 high, 0 normal, +1 low
     hipStream_t stream = nullptr;
+    hipStream_t acq_stream2 = nullptr;        // second queue of the correlation batch (created on first use)
+    hipEvent_t acq_ev2[2] = {nullptr, nullptr};
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     sgx_timing timing;
     int64_t n_code = 0;          // samplesPerCode

@@ -161,8 +161,9 @@ def test_acquire_variants_agree(default_record):
     (SGX_ACQ_FINE_V1=1), the round-1 correlation that mixes every Doppler bin (SGX_ACQ_V1=1), the host deciding the
     detections between the coarse and the fine search (SGX_ACQ_DEVICE_LED=0), the call's front as four launches
     (SGX_ACQ_FRONT=0), the round-4 second-peak search that transforms the winning row again instead of reading the
-    per-residue (maximum, maximum of the others) pairs of the one pass (SGX_ACQ_TOP2=0): same indices, same frequencies,
-    peak metrics equal to rounding (the last three: bit for bit)."""
+    per-residue (maximum, maximum of the others) pairs of the one pass (SGX_ACQ_TOP2=0), the correlation batch on one queue
+    instead of two (SGX_ACQ_STREAMS=1): same indices, same frequencies, peak metrics equal to rounding (the last four: bit
+    for bit)."""
     g = load_golden("acq_default.npz")
     m = pkg()
     s = m.Settings()
@@ -172,7 +173,7 @@ def test_acquire_variants_agree(default_record):
     assert np.array_equal(ref.codePhase, g["codePhase"]) and np.array_equal(ref.carrFreq, g["carrFreq"])
     for env in ({"SGX_ACQ_SPIN": "0"}, {"SGX_ACQ_FINE_V1": "1"}, {"SGX_ACQ_V1": "1"}, {"SGX_ACQ_DEVICE_LED": "0"},
                 {"SGX_ACQ_FRONT": "0"}, {"SGX_ACQ_DEVICE_LED": "0", "SGX_ACQ_SPIN": "0"}, {"SGX_ACQ_TOP2": "0"},
-                {"SGX_ACQ_TOP2": "0", "SGX_ACQ_DEVICE_LED": "0"}):
+                {"SGX_ACQ_TOP2": "0", "SGX_ACQ_DEVICE_LED": "0"}, {"SGX_ACQ_STREAMS": "1"}):
         os.environ.update(env)
         try:
             a = m.AcquisitionResult(s, device=0)
@@ -183,7 +184,7 @@ def test_acquire_variants_agree(default_record):
         assert np.array_equal(a.codePhase, ref.codePhase) and np.array_equal(a.carrFreq, ref.carrFreq), env
         assert np.array_equal(a.internals["freqBin"], ref.internals["freqBin"]), env
         assert np.allclose(a.peakMetric, ref.peakMetric, rtol=1e-9, atol=0), env
-        if "SGX_ACQ_DEVICE_LED" in env or "SGX_ACQ_FRONT" in env or "SGX_ACQ_TOP2" in env:
+        if "SGX_ACQ_DEVICE_LED" in env or "SGX_ACQ_FRONT" in env or "SGX_ACQ_TOP2" in env or "SGX_ACQ_STREAMS" in env:
             assert np.array_equal(a.peakMetric, ref.peakMetric), env
 
 
