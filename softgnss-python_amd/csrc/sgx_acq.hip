@@ -1302,12 +1302,20 @@ static int acquire_four_step(sgx_ctx* c, SgxSig x, size_t n_samples, const int32
     // in the Infinity Cache), there is little left to overlap; a producer / consumer fusion of the two has no more to win.
     const char* se = getenv("SGX_ACQ_STREAMS");
     bool two_q = !(se && se[0] == '1') && n_prn >= 2 && chunk_rows / 2 >= rows_per_prn;
+    // ... or, non-coherent sums (rows ordered PRN, bin, block): a PRN's rows in runs of Doppler bins
+    int bin_runs = 1;
+    if (!(se && se[0] == '1') && !two_q && noncoh && rows_per_prn > chunk_rows / 2 && rows_per_prn <= chunk_rows && n_bins >= 2) {
+        bin_runs = (rows_per_prn + chunk_rows / 2 - 1) / (chunk_rows / 2);
+        if (bin_runs > n_bins) bin_runs = n_bins;
+        two_q = bin_runs >= 2;
+        if (!two_q) bin_runs = 1;
+    }
     {
         const char* ce = getenv("SGX_ACQ_CHUNK_ROWS");
         if (ce && atoi(ce) > 0) chunk_rows = atoi(ce);
         if (chunk_rows > ACQ_MAX_ROWS) chunk_rows = ACQ_MAX_ROWS;
     }
-    if (two_q) chunk_rows /= 2;
+    if (two_q && bin_runs == 1) chunk_rows /= 2;
     int prn_chunk = chunk_rows / rows_per_prn;
     if (prn_chunk < 1) prn_chunk = 1;
     if (prn_chunk > n_prn) prn_chunk = n_prn;
@@ -1415,32 +1423,36 @@ static int acquire_four_step(sgx_ctx* c, SgxSig x, size_t n_samples, const int32
         SGX_HIP(hipStreamWaitEvent(st2, c->acq_ev2[0], 0));
     }
     int chunk_no = 0;
-    for (int p0 = 0; p0 < n_prn; p0 += prn_chunk, ++chunk_no) {
-        const int np = (p0 + prn_chunk <= n_prn) ? prn_chunk : (n_prn - p0);
-        Fft4Fuse fu;
-        fu.mul_x = c->d_fwd;
-        fu.mul_f = d_codefd;
-        fu.bin_map = d_binmap;
-        fu.n_bins = n_bins;
-        fu.n_phi = n_phi;
-        fu.rows_per_prn = rows_per_prn;
-        fu.prn_base = p0;
-        fu.n_blocks = n_blocks;
-        fu.blocks_fast = noncoh ? 1 : 0;
-        if (top2) {
-            fu.t2_b1 = d_t2b1 + (size_t)p0 * out_per_prn * nres;
-            fu.t2_b2 = d_t2b2 + (size_t)p0 * out_per_prn * nres;
-            fu.t2_i1 = d_t2i1 + (size_t)p0 * out_per_prn * nres;
-        } else {
-            fu.pmax = d_pmax + (size_t)p0 * out_per_prn * nblk;
-            fu.parg = d_parg + (size_t)p0 * out_per_prn * nblk;
+    const int bins_per_run = (n_bins + bin_runs - 1) / bin_runs;
+    for (int p0 = 0; p0 < n_prn; p0 += prn_chunk)
+        for (int bin0 = 0; bin0 < n_bins; bin0 += bins_per_run, ++chunk_no) {
+            const int np = (p0 + prn_chunk <= n_prn) ? prn_chunk : (n_prn - p0);
+            const int nb = bin_runs == 1 ? n_bins : (bin0 + bins_per_run <= n_bins ? bins_per_run : n_bins - bin0);
+            Fft4Fuse fu;
+            fu.mul_x = c->d_fwd;
+            fu.mul_f = d_codefd;
+            fu.bin_map = d_binmap + bin0;    // (a run of bins is a batch of its own with fewer bins)
+            fu.n_bins = nb;
+            fu.n_phi = n_phi;
+            fu.rows_per_prn = bin_runs == 1 ? rows_per_prn : nb * n_blocks;
+            fu.prn_base = p0;
+            fu.n_blocks = n_blocks;
+            fu.blocks_fast = noncoh ? 1 : 0;
+            const size_t out0 = ((size_t)p0 * out_per_prn + (size_t)bin0);
+            if (top2) {
+                fu.t2_b1 = d_t2b1 + out0 * nres;
+                fu.t2_b2 = d_t2b2 + out0 * nres;
+                fu.t2_i1 = d_t2i1 + out0 * nres;
+            } else {
+                fu.pmax = d_pmax + out0 * nblk;
+                fu.parg = d_parg + out0 * nblk;
+            }
+            fu.inv_n = inv_n;
+            fu.sum_blocks = noncoh ? n_blocks : 1;
+            const int q = two_q ? (chunk_no & 1) : 0;
+            rc = sgx_fft4_forward(&c->plan_code, nullptr, c->d_work[q], nullptr, (int64_t)np * fu.rows_per_prn, q ? st2 : st, &fu);
+            if (rc != SGX_OK) return rc;
         }
-        fu.inv_n = inv_n;
-        fu.sum_blocks = noncoh ? n_blocks : 1;
-        const int q = two_q ? (chunk_no & 1) : 0;
-        rc = sgx_fft4_forward(&c->plan_code, nullptr, c->d_work[q], nullptr, (int64_t)np * rows_per_prn, q ? st2 : st, &fu);
-        if (rc != SGX_OK) return rc;
-    }
     if (two_q) {
         SGX_HIP(hipEventRecord(c->acq_ev2[1], st2));
         SGX_HIP(hipStreamWaitEvent(st, c->acq_ev2[1], 0));
