@@ -1300,6 +1300,11 @@ static int acquire_four_step(sgx_ctx* c, SgxSig x, size_t n_samples, const int32
     // the other's loads (SGX_ACQ_STREAMS=1: one queue).  Only where a half-size chunk still holds a whole PRN.  Measured:
     // 0.822 -> 0.805 ms for config 2 - both kernels move their bytes at 3-5 TB/s over the same fabric (the intermediate lives
     // in the Infinity Cache), there is little left to overlap; a producer / consumer fusion of the two has no more to win.
+    {
+        const char* ce = getenv("SGX_ACQ_CHUNK_ROWS");
+        if (ce && atoi(ce) > 0) chunk_rows = atoi(ce);
+        if (chunk_rows > ACQ_MAX_ROWS) chunk_rows = ACQ_MAX_ROWS;
+    }
     const char* se = getenv("SGX_ACQ_STREAMS");
     bool two_q = !(se && se[0] == '1') && n_prn >= 2 && chunk_rows / 2 >= rows_per_prn;
     // ... or, non-coherent sums (rows ordered PRN, bin, block): a PRN's rows in runs of Doppler bins
@@ -1310,13 +1315,8 @@ static int acquire_four_step(sgx_ctx* c, SgxSig x, size_t n_samples, const int32
         two_q = bin_runs >= 2;
         if (!two_q) bin_runs = 1;
     }
-    {
-        const char* ce = getenv("SGX_ACQ_CHUNK_ROWS");
-        if (ce && atoi(ce) > 0) chunk_rows = atoi(ce);
-        if (chunk_rows > ACQ_MAX_ROWS) chunk_rows = ACQ_MAX_ROWS;
-    }
     if (two_q && bin_runs == 1) chunk_rows /= 2;
-    int prn_chunk = chunk_rows / rows_per_prn;
+    int prn_chunk = bin_runs > 1 ? 1 : chunk_rows / rows_per_prn;   // (a run of bins belongs to ONE PRN)
     if (prn_chunk < 1) prn_chunk = 1;
     if (prn_chunk > n_prn) prn_chunk = n_prn;
     const size_t row_bytes = sizeof(cplx) * (size_t)N;

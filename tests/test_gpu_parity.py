@@ -1129,6 +1129,40 @@ def test_config4_full_noncoherent_acquisition_against_the_oracle(default_record)
     assert np.count_nonzero(a.carrFreq) == 8
 
 
+def test_acquisition_chunks_and_queues_do_not_change_the_result(default_record):
+    """The correlation batch is cut into PRN chunks (SGX_ACQ_CHUNK_ROWS rows each) that alternate between two queues
+    (SGX_ACQ_STREAMS); non-coherent sums whose PRN does not fit half a chunk go in runs of Doppler bins.  Every cut gives the
+    same bits (a wrong output offset of the bin runs with more than one PRN per chunk went unnoticed in round 5 until a
+    chunk size off the default was tried)."""
+    m = pkg()
+    s = m.Settings()
+    n = s.samplesPerCode
+    x = default_record[:20 * n]
+
+    def run(env):
+        os.environ.update(env)
+        try:
+            a2 = m.AcquisitionResult(s, device=0)
+            a2.acquire(x[:11 * n])
+            a4 = m.AcquisitionResult(s, device=0)
+            a4.acquire(x, n_blocks=10, noncoh=True, prn_indices=list(range(12)))
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        return a2, a4
+
+    r2, r4 = run({"SGX_ACQ_STREAMS": "1"})
+    assert np.count_nonzero(r2.carrFreq) == 8
+    for env in ({}, {"SGX_ACQ_CHUNK_ROWS": "120"}, {"SGX_ACQ_CHUNK_ROWS": "200"}, {"SGX_ACQ_CHUNK_ROWS": "580"},
+                {"SGX_ACQ_CHUNK_ROWS": "1160"}, {"SGX_ACQ_CHUNK_ROWS": "1160", "SGX_ACQ_STREAMS": "1"},
+                {"SGX_ACQ_CHUNK_ROWS": "60"}):
+        a2, a4 = run(dict(env))
+        for a, r in ((a2, r2), (a4, r4)):
+            assert np.array_equal(a.peakMetric, r.peakMetric), env
+            assert np.array_equal(a.codePhase, r.codePhase) and np.array_equal(a.carrFreq, r.carrFreq), env
+            assert np.array_equal(a.internals["freqBin"], r.internals["freqBin"]), env
+
+
 def test_config5_full_64_replicated_channels(full_run):
     """BASELINE config 5 at its full size on one GPU: 64 channels (8 initialisations x 8 replicas) x 37 000 ms.
     Replicas are bit-identical; block boundaries equal the 8-channel run's, sums agree to rounding (the launch
