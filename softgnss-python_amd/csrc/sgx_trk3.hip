@@ -166,7 +166,11 @@ __device__ __forceinline__ unsigned long long t3_addl_bc15(unsigned long long v)
 #define T3_WB_DECL long long wb_acc[2] = {0, 0}, wb_t = (long long)__builtin_amdgcn_s_memtime();
 #define T3_WB(on)                                                                \
     do {                                                                         \
-        if (on) wb_acc[it & 1] += (long long)__builtin_amdgcn_s_memtime() - wb_t; \
+        if (on) {                                                                \
+            const long long d_ = (long long)__builtin_amdgcn_s_memtime() - wb_t;  \
+            wb_acc[0] += (it & 1) ? 0 : d_;   /* (constant indices: registers) */ \
+            wb_acc[1] += (it & 1) ? d_ : 0;                                       \
+        }                                                                        \
         wg_barrier();                                                            \
         if (on) wb_t = (long long)__builtin_amdgcn_s_memtime();                  \
     } while (0)
@@ -949,6 +953,9 @@ __device__ __forceinline__ int t3_poll1(unsigned long long& x, const unsigned lo
 // The DLL wave's poll: an arm's I and Q granules of a unit lie side by side and ONE 16-byte load per look fetches both
 // (round 5; before: two 8-byte loads per look, two looks in flight - this wave found its sums 430 cycles after the PLL wave
 // found its own and was the last at the barrier of every block, profiles/r05_trk_phase_profile.txt).  Three in flight.
+#ifndef T3_POLL_GAPD
+#define T3_POLL_GAPD T3_POLL_GAP3    // s_sleep units between the DLL wave's three loads
+#endif
 #define T3_TAGSEL 0x07060302u      // v_perm_b32: {upper half of the first source, upper half of the second}
 __device__ __forceinline__ int t3_poll2(unsigned long long& x1, unsigned long long& x2, const unsigned long long* p1,
                                         const unsigned long long* p2, unsigned long long tag, int rounds) {
@@ -966,9 +973,9 @@ __device__ __forceinline__ int t3_poll2(unsigned long long& x1, unsigned long lo
     asm volatile(
         "s_waitcnt vmcnt(0)\n\t"
         "global_load_dwordx4 v[244:247], %[p], off sc1\n\t"
-        "s_sleep " T3_STR(T3_POLL_GAP3) "\n\t"
+        "s_sleep " T3_STR(T3_POLL_GAPD) "\n\t"
         "global_load_dwordx4 v[248:251], %[p], off sc1\n\t"
-        "s_sleep " T3_STR(T3_POLL_GAP3) "\n\t"
+        "s_sleep " T3_STR(T3_POLL_GAPD) "\n\t"
         "global_load_dwordx4 v[252:255], %[p], off sc1\n\t"
         "s_mov_b32 %[n], %[r]\n"
         "1:\n\t"
@@ -1451,9 +1458,14 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
         T2STAMP(prof_on, 14);  // next block's code parameters
 #ifdef T3_PROF_DLL
         if (prof) {
+#ifdef T3_PROF_PAR   // (even (0) / odd (1) blocks only: figures are per TWO blocks then)
+            if ((it & 1) == T3_PROF_PAR)
+#endif
+            {
             dp_in += dp_t1 - dp_t0;
             dp_wait += dp_t2 - dp_t1;
             dp_post += (long long)__builtin_amdgcn_s_memtime() - dp_t2;
+            }
         }
 #endif
         T3_WB(wb_on);
