@@ -611,3 +611,32 @@ def test_reserved_poll_registers_are_touched_by_nothing_else(tmp_path):
     assert hits_in >= 10                       # the poll is there
     assert not hits_out, hits_out[:5]
     assert spills == 0
+
+
+def test_throughput_kernel_spills_nothing_among_its_dot_products(tmp_path):
+    """csrc/sgx_trk_tp.hip: the uint8 and int16 instances spill registers (5 and 44 at two workgroups per CU) - block-level
+    values, stored once and reloaded once per block around the chip loop.  None of that may sit among the dot products
+    (the chip loop's body): the compiled code of every instance has no scratch access between its first and last
+    v_dot4_i32_i8."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "tp.s")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip",
+                        "-I", os.path.join(root, "include"), "-I", os.path.join(root, "softgnss-python_amd", "csrc"),
+                        "-S", "--cuda-device-only", "-o", out, os.path.join(root, "softgnss-python_amd", "csrc", "sgx_trk_tp.hip")],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = open(out).read().splitlines()
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_Z13trk_kernel_tpILi\dEE", l)]
+    assert len(starts) == 3
+    for a, b in zip(starts, starts[1:] + [len(lines)]):
+        body = lines[a:b]
+        dots = [k for k, l in enumerate(body) if "v_dot4_i32_i8" in l]
+        assert len(dots) >= 32
+        inside = [body[k].strip() for k in range(min(dots), max(dots) + 1) if "scratch_" in body[k]]
+        assert not inside, (lines[a][:30], inside[:3])
