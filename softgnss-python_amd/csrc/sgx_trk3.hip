@@ -1532,6 +1532,9 @@ __device__ __forceinline__ int t3_rec_role(T3Shared& S, const TrkConst& K, const
     const long long span = 2ll * K.n_units * T3_UNIT + 64;   // bytes: a block and the window of the prefetch behind it
     const long long limit = K.rec_alloc - 16;
     unsigned dummy = 0;
+#ifdef T3_REC_LAT
+    long long rl_acc = 0;
+#endif
     T3_WB_DECL
     int it = 0;
     for (; it < ms; ++it) {
@@ -1544,6 +1547,13 @@ __device__ __forceinline__ int t3_rec_role(T3Shared& S, const TrkConst& K, const
             if (K.mark == nullptr || (unsigned long long)(a + 128) <= mark_seen)   // (a streaming record: only what is resident)
                 asm volatile("global_load_dword %0, %1, off" : "+v"(dummy) : "v"(rec + a) : "memory");
         }
+#ifdef T3_REC_LAT   // (diagnosis) how long the far prefetch is under way: the CU returns vector loads in order
+        {
+            const long long t0_ = (long long)__builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(dummy) : : "memory");
+            rl_acc += (long long)__builtin_amdgcn_s_memtime() - t0_;
+        }
+#endif
         if (owner && it > 0) t3_rec_store(S, it - 1, m, lane, o, err, ch);
         {   // (a resident record: mark_seen is all ones and this returns at once)
             const long long need = C.pos + 4 * span;
@@ -1551,6 +1561,9 @@ __device__ __forceinline__ int t3_rec_role(T3Shared& S, const TrkConst& K, const
         }
         T3_WB(wb_on);
     }
+#ifdef T3_REC_LAT
+    if (lane == 0 && ch == 0 && (unit == 0 || unit == 10)) printf("[t3 rec] unit %d: the far prefetch returns %.0f cycles after its issue (mean of %d blocks)\n", unit, (double)rl_acc / it, it);
+#endif
     T3_WB_PRINT(wb_on, "rec", ms)
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(dummy) : : "memory");   // (no request outlives the wave's registers)
     return it;
