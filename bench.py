@@ -469,6 +469,8 @@ def main():
                         ts.append(ctx.timing()["acquire_ms"])
                     worst = max(worst, min(ts))
                 emu = {"emulated_8rank_ms": worst, "emulated_speedup": dev_one / worst,
+                       # what a rank spends beyond an eighth of the one-GPU search: the part that does not shard
+                       "emulated_remainder_us": (worst - dev_one / 8.0) * 1e3,
                        "emulated_note": "device time of the slowest 4-PRN shard of an 8-rank run, timed on this one GPU, against "
                                         "device_ms_n1; the ncclAllGather of 160 bytes per rank is not in it"}
             cfg4 = {"workload": "configs[3]: 32 PRNs x 10 ms non-coherent, %d PRN/GPU, peaks all-gathered (%s)"
