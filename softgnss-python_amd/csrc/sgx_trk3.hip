@@ -51,6 +51,14 @@
 // sgx_trk2.hip.
 #include "sgx_trk2_parts.h"
 
+// issue priorities off the chain: the speculative pass (parts A and B) and the filter waves' work in front of their polls;
+// on the chain: the final pass 2, the filter waves from their poll to the barrier 3
+#ifndef T3_PRIO_SPEC
+#define T3_PRIO_SPEC 0
+#endif
+#ifndef T3_PRIO_PRE
+#define T3_PRIO_PRE 1
+#endif
 #define T3_LANES 128               // map lanes = groups per unit (two waves)
 #define T3_UNIT (T3_LANES * 16)    // samples per unit
 #define T3_THREADS 448             // 2 x 2 map waves (two SETS, alternating blocks) + PLL wave (4) + DLL wave (5) + record wave (6)
@@ -836,7 +844,7 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
             }
         }
         T2STAMP(prof_on, 5);   // published (or handed to the lanes that publish)
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(T3_PRIO_SPEC);
         if (it + 2 < ms) {
             // ======== part A of the pass of this set's NEXT block, it + 2, with this block's rates (in the shadow of this
             // block's exchange and loop filter).  Its first sample is pos + blk + (the length block it + 1 will most likely
@@ -1217,7 +1225,7 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
         }
         T2STAMP(prof_on, 10);  // carrier tables
         T3_WB(wb_on);
-        __builtin_amdgcn_s_setprio(1);   // what follows until the next poll is off the chain: the final pass (2) issues first,
+        __builtin_amdgcn_s_setprio(T3_PRIO_PRE);   // what follows until the next poll is off the chain: the final pass (2) issues first,
                                          // the speculative pass (0) after it
         __builtin_amdgcn_sched_barrier(0);
         // (a unit's prompt sum beyond half the room of the 48-bit payload: see T3_FIX)
@@ -1469,7 +1477,7 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
         }
 #endif
         T3_WB(wb_on);
-        __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(T3_PRIO_PRE);
         __builtin_amdgcn_sched_barrier(0);
         r_ve = vi * (s2_blk * unfix);    // (the block's record values: nobody waits for these)
         r_vl = vq * (s2_blk * unfix);
