@@ -237,6 +237,13 @@ int sgx_track_ex(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset,
 int sgx_track_plan(const sgx_settings* s, int32_t data_type, int32_t n_ch, int32_t n_cus, int32_t float_in_range,
                    int32_t* kernel, int32_t* members);
 
+/* How sgx_acquire cuts the correlation batch of a call into chunks over its (one or two) queues - the host's one rule
+ * (csrc/sgx_acq.hip: acq_plan), without the SGX_ACQ_* overrides; no reference counterpart (acquisition.py:93-133 is one
+ * loop over PRNs and bins); needs no GPU.  chunk_rows <= 0: the default (348).  A chunk is prn_chunk whole PRNs
+ * (bin_runs == 1) or one PRN's rows of bins_per_run Doppler bins (bin_runs > 1, non-coherent sums only). */
+int sgx_acquire_plan(int32_t n_prn, int32_t n_bins, int32_t n_blocks, int32_t noncoh, int32_t chunk_rows,
+                     int32_t max_queues, int32_t* prn_chunk, int32_t* bin_runs, int32_t* bins_per_run, int32_t* queues);
+
 /* Measured HBM rates of this device for the roofline report (no reference counterpart): a read-only stream and a
  * copy (read + write bytes counted) over `bytes` of device memory, `reps` timed launches each, GB/s. */
 int sgx_stream_rates(sgx_ctx* c, size_t bytes, int reps, double* read_gbs, double* copy_gbs);

@@ -92,6 +92,7 @@ _PROTOS = {
     "sgx_track": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, C.c_int32, _P, _P]),
     "sgx_track_ex": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32]),
     "sgx_track_plan": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "sgx_acquire_plan": (C.c_int, [C.c_int32] * 6 + [C.POINTER(C.c_int32)] * 4),
     "sgx_stream_rates": (C.c_int, [_P, C.c_size_t, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "sgx_probe_stats": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, C.c_double, _P, _P, _P, C.POINTER(C.c_int32)]),
     "sgx_find_preambles": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
@@ -169,6 +170,15 @@ def track_plan(settings, data_type=0, n_channels=8, n_cus=256, float_in_range=Fa
     check(lib().sgx_track_plan(C.byref(st), int(data_type), int(n_channels), int(n_cus), 1 if float_in_range else 0,
                                C.byref(k), C.byref(mbr)))
     return k.value, mbr.value
+
+
+def acquire_plan(n_prn=32, n_bins=29, n_blocks=2, noncoh=False, chunk_rows=0, max_queues=2):
+    """(PRNs per chunk, runs of Doppler bins per PRN, bins per run, queues): how sgx_acquire cuts the correlation batch -
+    the host's one rule (csrc/sgx_acq.hip: acq_plan); needs no GPU."""
+    v = [C.c_int32(0) for _ in range(4)]
+    check(lib().sgx_acquire_plan(int(n_prn), int(n_bins), int(n_blocks), 1 if noncoh else 0, int(chunk_rows), int(max_queues),
+                                 *[C.byref(x) for x in v]))
+    return tuple(x.value for x in v)
 
 
 def scene_struct(scene):

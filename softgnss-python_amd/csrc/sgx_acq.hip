@@ -1237,6 +1237,51 @@ __global__ __launch_bounds__(64) void acq_rowtop2_peak_kernel(const double* __re
                            lane);
 }
 
+// How the correlation batch of a call is cut (round 5).  Rows are ordered (PRN, block, bin) - coherent - or (PRN, bin, block)
+// - non-coherent sums; a chunk is whole PRNs (prn_chunk of them) or, for non-coherent sums whose PRN does not fit half a
+// chunk, ONE PRN's rows of a run of Doppler bins (bin_runs runs per PRN: a run is a batch of its own with fewer bins).
+// The chunks alternate between `queues` HIP streams, each with its own intermediate of chunk_rows / queues rows: the columns
+// kernel is bound by its stores and the rows kernel by its loads, and with two chunks in flight the one's stores overlap
+// the other's loads (0.85 -> 0.77 ms for config 2, 3.21 -> 2.89 ms for config 4; both kernels move their bytes at 3-5 TB/s
+// over the same fabric - the intermediate lives in the Infinity Cache - so a producer / consumer fusion has no more to win).
+struct AcqPlan {
+    int prn_chunk, bin_runs, bins_per_run, queues;
+};
+static AcqPlan acq_plan(int n_prn, int n_bins, int n_blocks, bool noncoh, int chunk_rows, int max_queues) {
+    if (chunk_rows > ACQ_MAX_ROWS) chunk_rows = ACQ_MAX_ROWS;
+    if (chunk_rows < 1) chunk_rows = 1;
+    const int rows_per_prn = n_bins * n_blocks;
+    AcqPlan p;
+    p.bin_runs = 1;
+    p.queues = (max_queues >= 2 && n_prn >= 2 && chunk_rows / 2 >= rows_per_prn) ? 2 : 1;
+    if (max_queues >= 2 && p.queues == 1 && noncoh && rows_per_prn > chunk_rows / 2 && rows_per_prn <= chunk_rows && n_bins >= 2) {
+        int runs = (rows_per_prn + chunk_rows / 2 - 1) / (chunk_rows / 2);
+        if (runs > n_bins) runs = n_bins;
+        if (runs >= 2) {
+            p.bin_runs = runs;
+            p.queues = 2;
+        }
+    }
+    if (p.queues == 2 && p.bin_runs == 1) chunk_rows /= 2;
+    p.prn_chunk = p.bin_runs > 1 ? 1 : chunk_rows / rows_per_prn;   // (a run of bins belongs to ONE PRN)
+    if (p.prn_chunk < 1) p.prn_chunk = 1;
+    if (p.prn_chunk > n_prn) p.prn_chunk = n_prn;
+    if (p.queues == 2 && p.bin_runs == 1 && p.prn_chunk > (n_prn + 1) / 2) p.prn_chunk = (n_prn + 1) / 2;   // (both queues get work)
+    p.bins_per_run = (n_bins + p.bin_runs - 1) / p.bin_runs;
+    return p;
+}
+extern "C" int sgx_acquire_plan(int32_t n_prn, int32_t n_bins, int32_t n_blocks, int32_t noncoh, int32_t chunk_rows,
+                                int32_t max_queues, int32_t* prn_chunk, int32_t* bin_runs, int32_t* bins_per_run,
+                                int32_t* queues) {
+    SGX_CHECK_ARG(n_prn >= 1 && n_bins >= 1 && n_blocks >= 1 && prn_chunk && bin_runs && bins_per_run && queues);
+    const AcqPlan p = acq_plan(n_prn, n_bins, n_blocks, noncoh != 0, chunk_rows > 0 ? chunk_rows : 348, max_queues);
+    *prn_chunk = p.prn_chunk;
+    *bin_runs = p.bin_runs;
+    *bins_per_run = p.bins_per_run;
+    *queues = p.queues;
+    return SGX_OK;
+}
+
 // The acquisition on the four-step transform (sgx_fft.hip): every 38192-point transform is two kernels with register-resident
 // sub-transforms, the mixed-signal spectra are computed once per (block, phi) and read with a circular shift, results
 // land where they are needed (no device-to-device copies) and the host looks at the device ONCE, at the very end of the
@@ -1295,30 +1340,14 @@ static int acquire_four_step(sgx_ctx* c, SgxSig x, size_t n_samples, const int32
     // any more - that is 0.94 -> 0.80 ms for config 2 and 3.43 -> 3.24 ms for config 4 (tools/acq_chunk_probe.py; the
     // round-2 kernels measured no difference).
     int chunk_rows = 348;
-    // Round 5: the PRN chunks alternate between TWO queues, each with its own intermediate of half the size: the columns
-    // kernel is bound by its stores and the rows kernel by its loads, and with two chunks in flight the one's stores overlap
-    // the other's loads (SGX_ACQ_STREAMS=1: one queue).  Only where a half-size chunk still holds a whole PRN.  Measured:
-    // 0.822 -> 0.805 ms for config 2 - both kernels move their bytes at 3-5 TB/s over the same fabric (the intermediate lives
-    // in the Infinity Cache), there is little left to overlap; a producer / consumer fusion of the two has no more to win.
     {
         const char* ce = getenv("SGX_ACQ_CHUNK_ROWS");
         if (ce && atoi(ce) > 0) chunk_rows = atoi(ce);
-        if (chunk_rows > ACQ_MAX_ROWS) chunk_rows = ACQ_MAX_ROWS;
     }
     const char* se = getenv("SGX_ACQ_STREAMS");
-    bool two_q = !(se && se[0] == '1') && n_prn >= 2 && chunk_rows / 2 >= rows_per_prn;
-    // ... or, non-coherent sums (rows ordered PRN, bin, block): a PRN's rows in runs of Doppler bins
-    int bin_runs = 1;
-    if (!(se && se[0] == '1') && !two_q && noncoh && rows_per_prn > chunk_rows / 2 && rows_per_prn <= chunk_rows && n_bins >= 2) {
-        bin_runs = (rows_per_prn + chunk_rows / 2 - 1) / (chunk_rows / 2);
-        if (bin_runs > n_bins) bin_runs = n_bins;
-        two_q = bin_runs >= 2;
-        if (!two_q) bin_runs = 1;
-    }
-    if (two_q && bin_runs == 1) chunk_rows /= 2;
-    int prn_chunk = bin_runs > 1 ? 1 : chunk_rows / rows_per_prn;   // (a run of bins belongs to ONE PRN)
-    if (prn_chunk < 1) prn_chunk = 1;
-    if (prn_chunk > n_prn) prn_chunk = n_prn;
+    const AcqPlan plan = acq_plan(n_prn, n_bins, n_blocks, noncoh != 0, chunk_rows, (se && se[0] == '1') ? 1 : 2);
+    const bool two_q = plan.queues == 2;
+    const int bin_runs = plan.bin_runs, prn_chunk = plan.prn_chunk;
     const size_t row_bytes = sizeof(cplx) * (size_t)N;
     size_t work_rows = (size_t)prn_chunk * rows_per_prn;
     if (work_rows < (size_t)(rows_fwd + n_prn)) work_rows = (size_t)(rows_fwd + n_prn);
@@ -1423,7 +1452,7 @@ static int acquire_four_step(sgx_ctx* c, SgxSig x, size_t n_samples, const int32
         SGX_HIP(hipStreamWaitEvent(st2, c->acq_ev2[0], 0));
     }
     int chunk_no = 0;
-    const int bins_per_run = (n_bins + bin_runs - 1) / bin_runs;
+    const int bins_per_run = plan.bins_per_run;
     for (int p0 = 0; p0 < n_prn; p0 += prn_chunk)
         for (int bin0 = 0; bin0 < n_bins; bin0 += bins_per_run, ++chunk_no) {
             const int np = (p0 + prn_chunk <= n_prn) ? prn_chunk : (n_prn - p0);

@@ -640,3 +640,38 @@ def test_throughput_kernel_spills_nothing_among_its_dot_products(tmp_path):
         assert len(dots) >= 32
         inside = [body[k].strip() for k in range(min(dots), max(dots) + 1) if "scratch_" in body[k]]
         assert not inside, (lines[a][:30], inside[:3])
+
+
+def test_acquisition_chunk_plan_covers_every_row_exactly_once():
+    """sgx_acquire_plan (csrc/sgx_acq.hip: acq_plan) cuts the correlation batch into chunks of whole PRNs or - non-coherent
+    sums - of one PRN's runs of Doppler bins, over one or two queues.  Whatever the sizes: every (PRN, bin) belongs to exactly
+    one chunk, a chunk of bin runs holds ONE PRN (round 5: with two it wrote the second PRN's maxima to the first one's
+    slots), a queue's chunk fits its share of the chunk size, and two queues are only used where there are two chunks."""
+    m = pkg()
+    for n_prn in (1, 2, 4, 7, 32):
+        for n_bins in (1, 2, 29, 57):
+            for n_blocks, noncoh in ((1, False), (2, False), (10, True), (3, True), (1, True)):
+                for chunk_rows in (0, 1, 29, 58, 120, 174, 200, 290, 348, 580, 1160, 4000):
+                    for max_q in (1, 2):
+                        prn_chunk, bin_runs, bins_per_run, queues = m._native.acquire_plan(n_prn, n_bins, n_blocks, noncoh,
+                                                                                        chunk_rows, max_q)
+                        what = (n_prn, n_bins, n_blocks, noncoh, chunk_rows, max_q, prn_chunk, bin_runs, bins_per_run, queues)
+                        assert 1 <= prn_chunk <= n_prn and 1 <= bin_runs <= n_bins and 1 <= queues <= max_q, what
+                        if bin_runs > 1:
+                            assert noncoh and prn_chunk == 1 and queues == 2, what
+                        seen = {}
+                        chunks = 0
+                        for p0 in range(0, n_prn, prn_chunk):
+                            for b0 in range(0, n_bins, bins_per_run):
+                                nb = n_bins if bin_runs == 1 else min(bins_per_run, n_bins - b0)
+                                chunks += 1
+                                for p in range(p0, min(p0 + prn_chunk, n_prn)):
+                                    for b in range(b0, b0 + nb):
+                                        seen[(p, b)] = seen.get((p, b), 0) + 1
+                                rows = min(prn_chunk, n_prn - p0) * nb * n_blocks
+                                limit = min(chunk_rows if chunk_rows > 0 else 348, 2048)
+                                if rows > n_bins * n_blocks or bin_runs > 1:       # (more than one PRN, or a part of one)
+                                    assert rows <= max(limit // queues, 1) + (n_blocks * bins_per_run if bin_runs > 1 else 0), what
+                        assert len(seen) == n_prn * n_bins and set(seen.values()) == {1}, what
+                        if queues == 2:
+                            assert chunks >= 2, what
