@@ -47,7 +47,8 @@
 // residue of those first blocks sat in the code NCO's integrator for the rest of the run (code phase 1e-11 chips from the
 // reference's after 10 000 blocks: enough to put a sample 3e-12 chips from a chip boundary on the other side).
 // Exchange: granules {16-bit epoch | 48-bit fixed point, 2^30}, order-free integer sums, redundant filters in every member;
-// the filter waves keep TWO polls in flight (reserved registers v[244:255]).  Record path and abort protocol are those of
+// an arm's I and Q of a unit side by side; the filter waves keep THREE looks in flight (the PLL wave 8-byte loads, the DLL
+// wave one 16-byte load per look; reserved registers v[244:255]).  Record path and abort protocol are those of
 // sgx_trk2.hip.
 #include "sgx_trk2_parts.h"
 
@@ -889,7 +890,7 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
     return it;
 }
 
-// TWO POLLS IN FLIGHT.  A granule is seen one round trip after the load that finds it left, so with one load at a time the
+// SEVERAL LOOKS IN FLIGHT.  A granule is seen one round trip after the load that finds it left, so with one load at a time the
 // sums wait half a round trip on average for the next load to leave; two loads half a round trip apart halve that.  The
 // load that is still in flight when the other one has found the sums lands LATER, in the middle of the loop filter: its
 // destination must be a register the compiler never allocates.  So the whole poll is one asm statement on the physical
@@ -898,7 +899,7 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
 // Returns the number of rounds left (0: nothing found in `rounds` rounds - the caller looks at the abort word and polls
 // again); x: the granule of every active lane.  Call with the lanes that poll as the active lanes.
 #ifndef T3_POLL_GAP
-#define T3_POLL_GAP 5              // s_sleep units (64 cycles) between the first two loads
+#define T3_POLL_GAP 5              // (the round-4 DLL poll's gap between its two pairs of loads; unused since round 5)
 #endif
 #ifndef T3_POLL_GAP3
 #define T3_POLL_GAP3 2             // ... between the PLL wave's three loads
