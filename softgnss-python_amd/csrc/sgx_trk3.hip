@@ -196,6 +196,32 @@ __device__ __forceinline__ unsigned long long t3_addl_bc15(unsigned long long v)
 #define T3_WB_PRINT(on, name, n)
 #endif
 
+// Sum of the 48-bit payloads (two's complement) of the granules of lanes 0..31 / 32..63, as a double, in rows 1 / 3 of the
+// wave: the payload is split into a low limb of 24 bits and a sign-extended high limb, whose sums over 32 lanes fit 32 bits -
+// two INDEPENDENT chains of one DPP add per step instead of one chain of add + add-with-carry (the carry is a second
+// dependent instruction in each of the five steps of the PLL wave's chain behind its poll); hi 2^24 + lo is exact.
+__device__ __forceinline__ double t3_sum48_half(unsigned long long x) {
+    const unsigned xl = (unsigned)x, xh = (unsigned)(x >> 32);
+    unsigned lo = xl & 0xFFFFFFu;
+    unsigned hi = (unsigned)((int)(__builtin_amdgcn_alignbit(xh, xl, 24) << 8) >> 8);   // bits 24..47, sign-extended
+    unsigned a, b;
+#define T3_S48(d0, d1, s0, s1, ctl)                                                               \
+        "v_add_u32_dpp " d0 ", " s0 ", " s0 " " ctl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+        "v_add_u32_dpp " d1 ", " s1 ", " s1 " " ctl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+        "s_nop 0\n\t"
+    asm volatile(
+        "s_nop 1\n\t"
+        T3_S48("%2", "%3", "%0", "%1", "quad_perm:[1,0,3,2]")
+        T3_S48("%0", "%1", "%2", "%3", "quad_perm:[2,3,0,1]")
+        T3_S48("%2", "%3", "%0", "%1", "row_half_mirror")
+        T3_S48("%0", "%1", "%2", "%3", "row_mirror")
+        "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_u32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf"
+        : "+v"(lo), "+v"(hi), "=&v"(a), "=&v"(b));
+#undef T3_S48
+    return __builtin_fma((double)(int)hi, 16777216.0, (double)lo);
+}
+
 __device__ __forceinline__ int t3_carr_mult(int lane, int unit, int head) {
     const int sel = lane >> 4, idx = lane & 15;
     return (sel == 3) ? (T3_UNIT * unit - head) : (idx << (4 * sel));
@@ -1172,6 +1198,7 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
             }
         }
         // sum of the units' payloads (integers: exact, order-free); lanes that poll nothing hold 0
+#ifdef T3_SUM64   // (the round-4 form: one 64-bit chain, add + add-with-carry per step)
         unsigned long long q = ((unsigned long long)(unsigned)((int)(short)(unsigned short)(x >> 32) + bias_hi) << 32) | (unsigned)x;
         q = dpp_addl_xor1(q, q);
         q = dpp_addl_xor2(q, q);
@@ -1179,6 +1206,10 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
         q = dpp_addl_mir(q, q);
         q = t3_addl_bc15(q);             // rows 1 and 3: the sums over lanes 0..31 / 32..63
         const double v = __longlong_as_double((long long)q) - T2_MAGIC;   // (in units of the fixed point: the discriminator is a ratio)
+#else
+        (void)bias_hi;
+        const double v = t3_sum48_half(x);   // rows 1 and 3: the sums over lanes 0..31 / 32..63 (in units of the fixed point)
+#endif
         const double I_P = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16),
                                             __builtin_amdgcn_readlane(__double2loint(v), 16));
         const double Q_P = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 48),
