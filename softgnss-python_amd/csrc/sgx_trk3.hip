@@ -222,6 +222,34 @@ __device__ __forceinline__ double t3_sum48_half(unsigned long long x) {
     return __builtin_fma((double)(int)hi, 16777216.0, (double)lo);
 }
 
+// the same for two granules per lane (the DLL wave: I in x1, Q in x2): four independent chains, no wait state to fill
+__device__ __forceinline__ void t3_sum48_half2(unsigned long long x1, unsigned long long x2, double& v1, double& v2) {
+    const unsigned x1l = (unsigned)x1, x1h = (unsigned)(x1 >> 32), x2l = (unsigned)x2, x2h = (unsigned)(x2 >> 32);
+    unsigned l1 = x1l & 0xFFFFFFu, l2 = x2l & 0xFFFFFFu;
+    unsigned h1 = (unsigned)((int)(__builtin_amdgcn_alignbit(x1h, x1l, 24) << 8) >> 8);
+    unsigned h2 = (unsigned)((int)(__builtin_amdgcn_alignbit(x2h, x2l, 24) << 8) >> 8);
+    unsigned a, b, c, d;
+#define T3_S48(d0, d1, d2, d3, s0, s1, s2, s3, ctl)                                               \
+        "v_add_u32_dpp " d0 ", " s0 ", " s0 " " ctl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+        "v_add_u32_dpp " d1 ", " s1 ", " s1 " " ctl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+        "v_add_u32_dpp " d2 ", " s2 ", " s2 " " ctl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+        "v_add_u32_dpp " d3 ", " s3 ", " s3 " " ctl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    asm volatile(
+        "s_nop 1\n\t"
+        T3_S48("%4", "%5", "%6", "%7", "%0", "%1", "%2", "%3", "quad_perm:[1,0,3,2]")
+        T3_S48("%0", "%1", "%2", "%3", "%4", "%5", "%6", "%7", "quad_perm:[2,3,0,1]")
+        T3_S48("%4", "%5", "%6", "%7", "%0", "%1", "%2", "%3", "row_half_mirror")
+        T3_S48("%0", "%1", "%2", "%3", "%4", "%5", "%6", "%7", "row_mirror")
+        "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_u32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_u32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_u32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf"
+        : "+v"(l1), "+v"(h1), "+v"(l2), "+v"(h2), "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d));
+#undef T3_S48
+    v1 = __builtin_fma((double)(int)h1, 16777216.0, (double)l1);
+    v2 = __builtin_fma((double)(int)h2, 16777216.0, (double)l2);
+}
+
 __device__ __forceinline__ int t3_carr_mult(int lane, int unit, int head) {
     const int sel = lane >> 4, idx = lane & 15;
     return (sel == 3) ? (T3_UNIT * unit - head) : (idx << (4 * sel));
@@ -1231,14 +1259,16 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
             const double dw = w_new - w_cur;
             double cs, sn, eps_n, respec_n;
             const double dw2 = dw + d1;              // w_new - w_prev
-            if (__builtin_expect(fabs(dw2) <= dw_lim, 1)) {
+            {   // (the small rotation straight through, the test for it behind: no wait for the compare in front of the arithmetic)
                 double es, ec;
                 sgx_rot_small(__builtin_fma(dw, mf, ang0), rk, es, ec);
                 cs = __builtin_fma(cs_p, ec, -(sn_p * es));
                 sn = __builtin_fma(cs_p, es, sn_p * ec);
                 eps_n = dw2 * inv_fs;
                 respec_n = 0.0;
-            } else {
+                asm volatile("" : "+v"(cs), "+v"(sn));
+            }
+            if (__builtin_expect(!(fabs(dw2) <= dw_lim), 0)) {
                 t2_carr_entry(c_hi, c_lo, inv_2pi, w_new, rc, mi, w3, cs, sn);
                 eps_n = 0.0;
                 respec_n = 1.0;
@@ -1451,11 +1481,17 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
         T2STAMP(prof_on, 12);  // waiting for the sums
         // T8 DLL (tracking.py:238-251).  Integer sums over the units (exact, order-free; lanes that poll nothing hold 0):
         // row 1 then holds the early arm's I (q1) and Q (q2), row 3 the late arm's; the two envelopes are ONE register
+#ifdef T3_SUM64   // (the round-4 form: two 64-bit chains, add + add-with-carry per step)
         unsigned long long q1 = ((unsigned long long)(unsigned)((int)(short)(unsigned short)(x1 >> 32) + bias_hi) << 32) | (unsigned)x1;
         unsigned long long q2 = ((unsigned long long)(unsigned)((int)(short)(unsigned short)(x2 >> 32) + bias_hi) << 32) | (unsigned)x2;
         t3_reduce2_half(q1, q2);
         const double vi = __longlong_as_double((long long)q1) - T2_MAGIC;   // row 1: I_E, row 3: I_L (in units of the fixed
         const double vq = __longlong_as_double((long long)q2) - T2_MAGIC;   // row 1: Q_E, row 3: Q_L  point: the discriminator is a ratio)
+#else
+        (void)bias_hi;
+        double vi, vq;                       // row 1: I_E, Q_E; row 3: I_L, Q_L (in units of the fixed point)
+        t3_sum48_half2(x1, x2, vi, vq);
+#endif
         const double m2 = __builtin_fma(vq, vq, vi * vi);   // row 1: I_E^2 + Q_E^2, row 3: I_L^2 + Q_L^2
         const double mm = sgx_sqrt1_pos(m2);                // (two zero envelopes: NaN, as in the reference)
         const double mE = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mm), 16),

@@ -147,6 +147,9 @@ SGX_HD double sgx_atan_ratio_k(double q, double i, const SgxAtanCoef& k) {
     const double z = sgx_div1(q, i);
     // (the short polynomial unconditionally, libm behind ONE cold branch: the usual path then runs straight through)
     double r = sgx_atan_short_k(z, k);
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(r));   // (the polynomial BEFORE the branch: the compare's result is long there when the branch asks for it)
+#endif
     if (__builtin_expect(!(fabs(z) <= SGX_ATAN_SHORT_MAX), 0)) r = atan(q / i);
     return r;
 }
