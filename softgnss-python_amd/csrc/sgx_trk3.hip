@@ -1505,14 +1505,31 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
         oldCodeErr = codeError;
         T2PROBE(prof_on, 13);  // discriminator + NCO
         // chain part of the next block: its length, the ramps' slope and the slope's reciprocal
-        double step_a, inv_step;
-        const int blk_n = sgx_block_length(a_next, cf_new, D.fs, D.inv_fs, step_a, inv_step);
+        // (sgx_block_length's arithmetic with its guard - the quotient within 6 ulp of an integer, 1e-10 of the blocks - folded
+        // into the ONE rare branch below: a compare in front of a branch costs the wave ~20 cycles of waiting)
+        double step_a = cf_new * D.inv_fs, inv_step;
+        int blk_n;
+        bool near;
+        {
+            double y = SGX_RCP_SEED(step_a);
+            y = __builtin_fma(y, __builtin_fma(-step_a, y, 1.0), y);
+            const double q0 = a_next * y;
+            const double q = __builtin_fma(__builtin_fma(-q0, step_a, a_next), y, q0);
+            inv_step = y;
+            const double c = ceil(q);
+            const double tol = q * 1.4e-15;
+            near = (c - q < tol) | (q - c + 1.0 < tol);
+            blk_n = (int)c;
+        }
         int stop_n = 0;
-        if (__builtin_expect((unsigned)(blk_n - 1) >= lim || gave_up, 0)) {      // (blk <= 0 wraps to a huge number)
-            stop_n = gave_up ? 2 : ((blk_n <= 0 || blk_n > lim1) ? 1 : 3);
-            if (lane == 0 && stop_n == 3) {
-                atomicOr(err, TRK_ERR_RANGE);
-                atomicCAS(err + 1, 0, 1 + ch);
+        if (__builtin_expect(near || (unsigned)(blk_n - 1) >= lim || gave_up, 0)) {      // (blk <= 0 wraps to a huge number)
+            if (near) blk_n = (int)ceil(a_next / sgx_div_rn(cf_new, D.fs, D.inv_fs));
+            if ((unsigned)(blk_n - 1) >= lim || gave_up) {
+                stop_n = gave_up ? 2 : ((blk_n <= 0 || blk_n > lim1) ? 1 : 3);
+                if (lane == 0 && stop_n == 3) {
+                    atomicOr(err, TRK_ERR_RANGE);
+                    atomicCAS(err + 1, 0, 1 + ch);
+                }
             }
         }
         if (lane == 0) {
