@@ -587,14 +587,7 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
         // ======== this set's block: the final pass (on the chain) ========
         __builtin_amdgcn_s_setprio(2);
         double eps = ep.x;
-        // group phasor G' = W1'[tid & 15] * W2'[(tid >> 4) & 7] * W3' (rotated tables)
         double gc, gs;
-        {
-            const double lc = __builtin_fma(w1.x, w2.x, -(w1.y * w2.y));
-            const double ls = __builtin_fma(w1.x, w2.y, w1.y * w2.x);
-            gc = __builtin_fma(lc, w3.x, -(ls * w3.y));
-            gs = __builtin_fma(lc, w3.y, ls * w3.x);
-        }
         bool direct = false;
         double aI0, aQ0, aI1, aQ1, aI2, aQ2;                  // the lane's six sums: arm 0 early, 1 prompt, 2 late
         // (either path below defines them; the statement costs nothing and spares the plain path six initialisations)
@@ -608,6 +601,15 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
         {
             const double a = fabs(r) - 0.5;                   // > 0: the boundary crossed a sample
             plain = !((fabs(a) < 1e-7) | (a > 1.0) | (blk != cut) | ((int)pos != (int)spos) | (step > step_max) | (ep.y != 0.0));
+        }
+        // group phasor G' = W1'[tid & 15] * W2'[(tid >> 4) & 7] * W3' (rotated tables) - HERE, between the compares above and
+        // the branch on them below: a branch right behind its compare waits ~20 cycles for the result (43.16 -> 42.75 ms)
+        {
+            const double lc = __builtin_fma(w1.x, w2.x, -(w1.y * w2.y));
+            const double ls = __builtin_fma(w1.x, w2.y, w1.y * w2.x);
+            gc = __builtin_fma(lc, w3.x, -(ls * w3.y));
+            gs = __builtin_fma(lc, w3.y, ls * w3.x);
+            asm volatile("" : "+v"(gc), "+v"(gs));
         }
 #ifdef T3_CHECK
         bool chk_moved = false;
