@@ -627,12 +627,8 @@ __device__ __forceinline__ int t2_pll_role(T2Shared& S, const TrkConst& K, const
             acc_xch += t_arr - tp;       // this member's publish -> every member's sums visible
         }
         // sum of the units' payloads (integers: exact, order-free), rows of 16 lanes; lanes that poll nothing hold 0
-        unsigned long long q = ((unsigned long long)(unsigned)((int)(short)(unsigned short)(x >> 32) + bias_hi) << 32) | (unsigned)x;
-        q = dpp_addl_xor1(q, q);
-        q = dpp_addl_xor2(q, q);
-        q = dpp_addl_hmir(q, q);
-        q = dpp_addl_mir(q, q);
-        const double v = (__longlong_as_double((long long)q) - T2_MAGIC) * unfix;
+        (void)bias_hi;
+        const double v = t2_sum48_row(x) * unfix;
         const double I_P = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 0),
                                             __builtin_amdgcn_readlane(__double2loint(v), 0));
         const double Q_P = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16),
@@ -833,12 +829,8 @@ __device__ __forceinline__ int t2_dll_role(T2Shared& S, const TrkConst& K, const
         // T8 DLL (tracking.py:238-251).  Row r of the wave holds the units' payloads of I_E | Q_E | I_L | Q_L: integer
         // row sums (exact, order-free; lanes that poll nothing hold 0), every lane of a row then has its row's total.
         // The discriminator runs on the rows as they are: no lane shuffles besides two row broadcasts.
-        unsigned long long q = ((unsigned long long)(unsigned)((int)(short)(unsigned short)(x >> 32) + bias_hi) << 32) | (unsigned)x;
-        q = dpp_addl_xor1(q, q);
-        q = dpp_addl_xor2(q, q);
-        q = dpp_addl_hmir(q, q);
-        q = dpp_addl_mir(q, q);
-        const double v = (__longlong_as_double((long long)q) - T2_MAGIC) * unfix;   // I_E | Q_E | I_L | Q_L by row
+        (void)bias_hi;
+        const double v = t2_sum48_row(x) * unfix;   // I_E | Q_E | I_L | Q_L by row
         const double sq = v * v;
         const double e2 = sq + dpp_bcast<0x142, 0xA>(sq);    // rows 1, 3: I_E^2 + Q_E^2, I_L^2 + Q_L^2
         const double mag = sgx_sqrt1_pos(e2);                // rows 1, 3: E, L (two zero envelopes: NaN, as in the reference)

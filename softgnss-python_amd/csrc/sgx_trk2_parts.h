@@ -148,6 +148,29 @@ T2_DPP_ADDL(dpp_addl_ror8, "row_ror:8")
 T2_DPP_ADDL(dpp_addl_hmir, "row_half_mirror")
 T2_DPP_ADDL(dpp_addl_mir, "row_mirror")
 
+// Sum of the 48-bit payloads (two's complement) of a row's sixteen granules, as a double in every lane of the row: the payload
+// as a low limb of 24 bits and a sign-extended high limb, two INDEPENDENT chains of one DPP add per step - no add-with-carry
+// (an instruction that waits for VCC from the one before it costs a lone wave 10-20 cycles; round 5, sgx_trk3.hip).
+__device__ __forceinline__ double t2_sum48_row(unsigned long long x) {
+    const unsigned xl = (unsigned)x, xh = (unsigned)(x >> 32);
+    unsigned lo = xl & 0xFFFFFFu;
+    unsigned hi = (unsigned)((int)(__builtin_amdgcn_alignbit(xh, xl, 24) << 8) >> 8);   // bits 24..47, sign-extended
+    unsigned a, b;
+#define T2_S48(d0, d1, s0, s1, ctl)                                                               \
+        "v_add_u32_dpp " d0 ", " s0 ", " s0 " " ctl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+        "v_add_u32_dpp " d1 ", " s1 ", " s1 " " ctl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    asm volatile(
+        "s_nop 1\n\t"
+        T2_S48("%2", "%3", "%0", "%1", "quad_perm:[1,0,3,2]") "s_nop 0\n\t"
+        T2_S48("%0", "%1", "%2", "%3", "quad_perm:[2,3,0,1]") "s_nop 0\n\t"
+        T2_S48("%2", "%3", "%0", "%1", "row_half_mirror") "s_nop 0\n\t"
+        "v_add_u32_dpp %0, %2, %2 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_u32_dpp %1, %3, %3 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "+v"(lo), "+v"(hi), "=&v"(a), "=&v"(b));
+#undef T2_S48
+    return __builtin_fma((double)(int)hi, 16777216.0, (double)lo);
+}
+
 // Sign bits of the extended code in LDS: bit k + 1 of the packed table is set where chip k is -1 (k in [-1, 1054]).
 // Two adjacent chips (k, k + 1) from one 8-byte read.
 __device__ __forceinline__ unsigned chip_bits2(const unsigned* cbits, int k) {
