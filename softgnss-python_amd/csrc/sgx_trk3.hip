@@ -117,6 +117,9 @@ struct T3Shared {
     int flag[4];                    // [0] same-XCD placement, [1] abort seen by this workgroup
     int rflag[4];                   // [0] PLL wave, [1] DLL wave: number of blocks whose record values are in rec[]
     long long tpub[2];              // (profiling) time stamp of the member's publish, by block parity
+#ifdef T3_TIMELINE
+    unsigned long long tl[6][2][8]; // (diagnosis) sums of the waves' event stamps [wave][block parity][event]
+#endif
 };
 
 // Two 64-bit values per lane -> sums over lanes 0..31 (rows 1) and 32..63 (rows 3) of either, the two chains interleaved
@@ -194,6 +197,43 @@ __device__ __forceinline__ unsigned long long t3_addl_bc15(unsigned long long v)
 #define T3_WB_DECL
 #define T3_WB(on) wg_barrier()
 #define T3_WB_PRINT(on, name, n)
+#endif
+
+// -DT3_TIMELINE: where a block's period goes.  The waves of channel 0 add s_memtime stamps of their events into LDS
+// counters by block parity over the blocks >= T3_TL_FROM; the means are ABSOLUTE times (one counter per XCD, and a channel
+// lives on one XCD), so that differences between waves and members are mean distances between their events.  A stamp
+// waits for its counter value (~60 cycles on the chain), so a build takes only the events of its masks -DT3_TL_MAP=,
+// -DT3_TL_PLL=, -DT3_TL_DLL= (bit e: event e) plus the PLL wave's release stamp, which every other time is relative to
+// (a barrier releases all waves of the workgroup together).  tools/r6_timeline.sh builds and runs the set of variants.
+#ifdef T3_TIMELINE
+#ifndef T3_TL_FROM
+#define T3_TL_FROM 2000
+#endif
+#ifndef T3_TL_MAP
+#define T3_TL_MAP 0
+#endif
+#ifndef T3_TL_PLL
+#define T3_TL_PLL 0
+#endif
+#ifndef T3_TL_DLL
+#define T3_TL_DLL 0
+#endif
+#define T3_TL_ADD(wave_, e, v)                                                                                      \
+    do {                                                                                                            \
+        const unsigned long long v_ = (unsigned long long)(v);                                                      \
+        if ((threadIdx.x & 63) == 0) atomicAdd(&S.tl[wave_][it & 1][e], v_);                                        \
+    } while (0)
+#define T3_TL(mask, on, wave_, e)                                                                                   \
+    do {                                                                                                            \
+        if ((((mask) >> (e)) & 1) && (on) && it >= T3_TL_FROM) T3_TL_ADD(wave_, e, __builtin_amdgcn_s_memtime());    \
+    } while (0)
+#define T3_TL_SET(mask, on, wave_, e, v)                                                                            \
+    do {                                                                                                            \
+        if ((((mask) >> (e)) & 1) && (on) && it >= T3_TL_FROM) T3_TL_ADD(wave_, e, v);                               \
+    } while (0)
+#else
+#define T3_TL(mask, on, wave_, e) do { } while (0)
+#define T3_TL_SET(mask, on, wave_, e, v) do { } while (0)
 #endif
 
 // Sum of the 48-bit payloads (two's complement) of the granules of lanes 0..31 / 32..63, as a double, in rows 1 / 3 of the
@@ -330,6 +370,8 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
     const long long lane_off = (long long)g * 16;
     T2_FP_DECL
     T3_WB_DECL
+    const bool tl_on = (blockIdx.x & 7) == 0 && blockIdx.x < 8 * T3_MAXP;   // (channel 0 of an 8-channel launch)
+    (void)tl_on;
     (void)wb_on;
     (void)prof_on;
     (void)spacing;
@@ -586,6 +628,7 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
         if ((it & 1) == set) {
         // ======== this set's block: the final pass (on the chain) ========
         __builtin_amdgcn_s_setprio(2);
+        T3_TL(T3_TL_MAP, tl_on, tid >> 6, 1);   // parameters in registers
         double eps = ep.x;
         double gc, gs;
         bool direct = false;
@@ -616,6 +659,7 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
         int chk_dpos = 0;
         const double chk_gc = gc, chk_gs = gs;
 #endif
+        T3_TL(T3_TL_MAP, tl_on, tid >> 6, 2);   // test + group phasor
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(!plain) != 0, 0)) {
             unsigned long long me = 0, mb = 0;
             // The pass ran two blocks back: the block starts `dpos` samples from where it was put and is `blk - cut` samples
@@ -865,6 +909,7 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
         }
 #endif
         T2STAMP(prof_on, 4);   // patch, first-order correction, rotation, three arms
+        T3_TL(T3_TL_MAP, tl_on, tid >> 6, 3);
         // fixed point: the raw bits of fma(a, 2^28, 1.5 2^52) are bias + round(a 2^28); sums of them carry the sum of the
         // integers in their low 48 bits whatever the biases add up to
         const double lane_fix = uns ? T3_FIX * 0.5 : T3_FIX;
@@ -884,6 +929,7 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
         // transposing reduction inside each row of 16 lanes; exchange order I_P Q_P I_E Q_E I_L Q_L
         unsigned long long vpe, vl;
         t3_reduce6(q, odd1, odd2, vpe, vl);
+        T3_TL(T3_TL_MAP, tl_on, tid >> 6, 4);   // reduced inside the rows
         {
             const int rl = lane & 15;
             if (rl < 6) {
@@ -896,11 +942,16 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
                     S.acc[par][word] = 0ull;
                     const unsigned long long gran = ((unsigned long long)((unsigned)(it + 1) & 0xFFFFu) << 48) | (tot & 0xFFFFFFFFFFFFull);
                     granule_store(xbase + ((((par * 3 + (word >> 1)) * T3_XLINE + unit) << 1) | (word & 1)), gran, fast);
+#ifdef T3_TIMELINE
+                    if (word == 0) S.tpub[par] = (long long)__builtin_amdgcn_s_memtime();
+#else
                     if (prof_any && word == 0) S.tpub[par] = (long long)__builtin_amdgcn_s_memtime();
+#endif
                 }
             }
         }
         T2STAMP(prof_on, 5);   // published (or handed to the lanes that publish)
+        T3_TL(T3_TL_MAP, tl_on, tid >> 6, 5);
         __builtin_amdgcn_s_setprio(T3_PRIO_SPEC);
         if (it + 2 < ms) {
             // ======== part A of the pass of this set's NEXT block, it + 2, with this block's rates (in the shadow of this
@@ -933,6 +984,7 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
         pos += blk;
         T2STAMP(prof_on, 6);   // next block's speculative pass
         __builtin_amdgcn_sched_barrier(0);
+        T3_TL(T3_TL_MAP, tl_on, tid >> 6, 6);   // at the barrier
         T3_WB(wb_on);
         __builtin_amdgcn_sched_barrier(0);
         T2STAMP(prof_on, 7);   // waiting for the loop filter
@@ -1129,12 +1181,15 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
 #endif
     T2_FP_DECL
     T3_WB_DECL
+    const bool tl_on = ch == 0;
+    (void)tl_on;
     (void)prof_on;
     __builtin_amdgcn_s_setprio(3);
     int it = 0;
     for (; it < ms; ++it) {
         const int par = it & 1;
         const T3Code& C = S.code[par];
+        T3_TL(1, tl_on, 4, 0);   // released (the reference of every other stamp)
         const int4 hd = *reinterpret_cast<const int4*>(&C.blk);
         const long long pos = C.pos;
         if (owner && it > 0) {
@@ -1186,6 +1241,7 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
         unsigned long long x = 0;
         int budget = T2_POLL_BUDGET;
         bool gave_up = false;
+        T3_TL(T3_TL_PLL, tl_on, 4, 1);   // poll entered
 #if defined(T3_POLL2) && (T3_POLL2 & 1)
         for (;;) {
             int left = 1;
@@ -1216,6 +1272,8 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
         }
 #endif
         T2STAMP(prof_on, 8);   // waiting for the sums
+        T3_TL(T3_TL_PLL, tl_on, 4, 2);   // sums found
+        T3_TL_SET(T3_TL_PLL, tl_on, 4, 6, lds_peek64(&S.tpub[par]));   // (this member's publish)
         if (prof) {
             t_arr = (long long)__builtin_amdgcn_s_memtime();
             const long long tp = lds_peek64(&S.tpub[par]);
@@ -1255,6 +1313,7 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
         oldCarrNco = carrNco;
         oldCarrErr = carrError;
         T2PROBE(prof_on, 9);   // discriminator + NCO
+        T3_TL(T3_TL_PLL, tl_on, 4, 3);
         // carrier tables of the next block: the prepared entry turned by the rate step (exact: w_new - w_cur is)
         double eps_next = 0.0;
         if (it + 1 < ms) {
@@ -1288,6 +1347,7 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
             __hip_atomic_store(xabort, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         T2STAMP(prof_on, 10);  // carrier tables
+        T3_TL(T3_TL_PLL, tl_on, 4, 4);   // at the barrier
         T3_WB(wb_on);
         __builtin_amdgcn_s_setprio(T3_PRIO_PRE);   // what follows until the next poll is off the chain: the final pass (2) issues first,
                                          // the speculative pass (0) after it
@@ -1373,6 +1433,8 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
     double r_ve = 0.0, r_vl = 0.0, r_cf = 0.0, r_err = 0.0, r_nco = 0.0;
     T2_FP_DECL
     T3_WB_DECL
+    const bool tl_on = ch == 0;
+    (void)tl_on;
     (void)prof_on;
 #ifdef T3_PROF_DLL   // (diagnosis, SGX_TRK_PROFILE=1) the three phase times of the profile are the DLL wave's: release -> poll
     long long dp_in = 0, dp_wait = 0, dp_post = 0, dp_t0 = 0, dp_t1 = 0, dp_t2 = 0;   // entered -> sums found -> at the barrier
@@ -1450,6 +1512,7 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
 #ifdef T3_PROF_DLL
         if (prof) dp_t1 = (long long)__builtin_amdgcn_s_memtime();
 #endif
+        T3_TL(T3_TL_DLL, tl_on, 5, 1);   // poll entered
 #if defined(T3_POLL2) && (T3_POLL2 & 2)
         for (;;) {
             int left = 1;
@@ -1481,6 +1544,7 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
         if (prof) dp_t2 = (long long)__builtin_amdgcn_s_memtime();
 #endif
         T2STAMP(prof_on, 12);  // waiting for the sums
+        T3_TL(T3_TL_DLL, tl_on, 5, 2);   // sums found
         // T8 DLL (tracking.py:238-251).  Integer sums over the units (exact, order-free; lanes that poll nothing hold 0):
         // row 1 then holds the early arm's I (q1) and Q (q2), row 3 the late arm's; the two envelopes are ONE register
 #ifdef T3_SUM64   // (the round-4 form: two 64-bit chains, add + add-with-carry per step)
@@ -1506,6 +1570,7 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
         oldCodeNco = codeNco;
         oldCodeErr = codeError;
         T2PROBE(prof_on, 13);  // discriminator + NCO
+        T3_TL(T3_TL_DLL, tl_on, 5, 3);
         // chain part of the next block: its length, the ramps' slope and the slope's reciprocal
         // (sgx_block_length's arithmetic with its guard - the quotient within 6 ulp of an integer, 1e-10 of the blocks - folded
         // into the ONE rare branch below: a compare in front of a branch costs the wave ~20 cycles of waiting)
@@ -1563,6 +1628,7 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
             }
         }
 #endif
+        T3_TL(T3_TL_DLL, tl_on, 5, 4);   // at the barrier
         T3_WB(wb_on);
         __builtin_amdgcn_s_setprio(T3_PRIO_PRE);
         __builtin_amdgcn_sched_barrier(0);
@@ -1694,6 +1760,9 @@ __global__ __launch_bounds__(T3_THREADS) void trk3_kernel(const int8_t* __restri
     }
 
     if (tid < 16) S.acc[tid >> 3][tid & 7] = 0ull;
+#ifdef T3_TIMELINE
+    if (tid < 96) S.tl[tid >> 4][(tid >> 3) & 1][tid & 7] = 0ull;
+#endif
     if (tid < 2) {
         S.code[tid].xflag = 0;
         S.carr[tid].eps = 0.0;
@@ -1797,6 +1866,12 @@ __global__ __launch_bounds__(T3_THREADS) void trk3_kernel(const int8_t* __restri
     else
         done = t3_rec_role(S, K, rec, unit, ch, owner, lane, o, err, mark_seen, wb_on);
 
+#ifdef T3_TIMELINE
+    __syncthreads();
+    if (ch == 0 && tid < 96 && done > T3_TL_FROM + 2 && S.tl[tid >> 4][(tid >> 3) & 1][tid & 7] != 0ull)
+        printf("[t3 tl] unit %d wave %d par %d ev %d mean %.1f\n", unit, tid >> 4, (tid >> 3) & 1, tid & 7,
+               (double)S.tl[tid >> 4][(tid >> 3) & 1][tid & 7] / (0.5 * (double)(done - T3_TL_FROM)));
+#endif
     // a channel that was given up reports the blocks completed before the abort
     const bool aborted = S.code[done & 1].stop == 2;
     if (wave == 6 && owner && done > 0 && !aborted) t3_rec_store(S, done - 1, (long long)K.ms, lane, o, err, ch);
