@@ -35,6 +35,10 @@ extern "C" {
 #define SGX_E_RCCL     -5   /* RCCL error / library not loadable */
 #define SGX_E_RANGE    -6   /* record too short for the request; also where the reference's numpy code raises on
                                out-of-range data (the error text then starts with the exception's name) */
+#define SGX_E_DEFER    -7   /* sgx_track_chained: the queued (deferred) sequence does not apply to this call - no
+                               acquisition pending, a kernel other than the cooperative int8 / uint8 ones, a streaming
+                               record, a launch that had to be repeated; the caller runs sgx_acquire_end, preRun and
+                               sgx_track_ex instead (nothing has been lost: the search's results are still pending) */
 
 #define SGX_NUM_SERIES 13   /* per-ms tracking series, in this order (tracking.py:255-275):
                                absoluteSample codeFreq carrFreq I_P I_E I_L Q_E Q_P Q_L
@@ -182,6 +186,31 @@ int sgx_acquire(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n_samples,
 int sgx_acquire_f64(sgx_ctx* c, const double* signal, size_t n_samples, const int32_t* prn0, int32_t n_prn,
                     int32_t n_blocks, int32_t noncoh, double* carrFreq, double* codePhase, double* peakMetric,
                     int32_t* freqBin, int32_t* fineIdx);
+
+/* ---- the same path without host round trips between its stages (round 6) --------------------
+ * The reference's caller looks at every stage's result before it starts the next (initialize.py:484-506: acquire, preRun,
+ * TrackingResult.track).  A caller that wants the tracking results can queue all three and wait once:
+ *   sgx_acquire_begin    sgx_acquire's arguments without the outputs: the search is queued (acquisition.py:27-204), the
+ *                        call returns without looking at it.  One acquisition may be pending per context.
+ *   sgx_track_chained    preRun (acquisition.py:259-306: stable descending sort of the 32 peak metrics, the first
+ *                        min(n_ch, #detected) become channels) runs ON THE DEVICE behind the pending search and the tracking
+ *                        kernel (tracking.py:13-295) behind it, reading the channel table where preRun left it; the call
+ *                        waits once, for everything.  out = [n_ch][13][ms] (pinned memory from sgx_host_alloc), ms_done =
+ *                        [n_ch]; the channel table as preRun made it comes back in prn / acquiredFreq / codePhase [n_ch]
+ *                        (prn 0 = off; the first *n_active channels are on, in order of descending metric).  Returns
+ *                        SGX_E_DEFER when the queued sequence does not apply (see the code's comment) - then nothing has
+ *                        been tracked and the eager calls do the work; SGX_E_INDEX / SGX_E_RANGE where the SEARCH failed
+ *                        the way the reference's acquire() raises (no channel was tracked).
+ *   sgx_acquire_end      the pending search's outputs (sgx_acquire's), without waiting if sgx_track_chained has run.
+ * Results are those of sgx_acquire + preRun + sgx_track_ex, bit for bit: the same kernels in the same order, and the
+ * device-side preRun repeats the host's arithmetic (tests/test_gpu_parity.py). */
+int sgx_acquire_begin(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n_samples,
+                      const int32_t* prn0, int32_t n_prn, int32_t n_blocks, int32_t noncoh);
+int sgx_acquire_end(sgx_ctx* c, double* carrFreq, double* codePhase, double* peakMetric,
+                    int32_t* freqBin, int32_t* fineIdx);
+int sgx_track_chained(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, int32_t n_ch, int32_t ms,
+                      double* out, int32_t* ms_done, int32_t data_type,
+                      int32_t* prn, double* acquiredFreq, double* codePhase, int32_t* n_active);
 
 /* ---- TrackingResult.track (tracking.py:13-295) ----------------------------------------------
  * Tracks n_ch channels for `ms` code periods on the record.  rec_file_offset is the byte offset

@@ -89,6 +89,10 @@ _PROTOS = {
     "sgx_acquire": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, C.c_int32, C.c_int32, C.c_int32,
                               _P, _P, _P, _P, _P]),
     "sgx_acquire_f64": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
+    "sgx_acquire_begin": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, C.c_int32, C.c_int32, C.c_int32]),
+    "sgx_acquire_end": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "sgx_track_chained": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int32, _P, _P, _P,
+                                    C.POINTER(C.c_int32)]),
     "sgx_track": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, C.c_int32, _P, _P]),
     "sgx_track_ex": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32]),
     "sgx_track_plan": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
@@ -366,6 +370,41 @@ class Context(object):
         check(lib().sgx_acquire(self._h, rec._h, int(offset), int(n_samples), _ptr(prn), n, int(n_blocks),
                                 1 if noncoh else 0, _ptr(carr), _ptr(cph), _ptr(met), _ptr(fb), _ptr(fi)))
         return dict(carrFreq=carr, codePhase=cph, peakMetric=met, freqBin=fb, fineIdx=fi)
+
+    # ---- the same without host round trips between the stages (include/sgx.h, "round 6") ----
+    def acquire_begin(self, rec, offset, n_samples, prn0, n_blocks=2, noncoh=False):
+        """Queue the search of acquire(); nothing is looked at.  acquire_end() returns what acquire() would have."""
+        prn = np.ascontiguousarray(prn0, dtype=np.int32)
+        check(lib().sgx_acquire_begin(self._h, rec._h, int(offset), int(n_samples), _ptr(prn), prn.size, int(n_blocks),
+                                      1 if noncoh else 0))
+        self._acq_token = getattr(self, "_acq_token", 0) + 1   # (one search may be pending per context)
+        return self._acq_token
+
+    def acquire_end(self, n):
+        carr = np.zeros(n)
+        cph = np.zeros(n)
+        met = np.zeros(n)
+        fb = np.zeros(n, dtype=np.int32)
+        fi = np.zeros(n, dtype=np.int32)
+        check(lib().sgx_acquire_end(self._h, _ptr(carr), _ptr(cph), _ptr(met), _ptr(fb), _ptr(fi)))
+        return dict(carrFreq=carr, codePhase=cph, peakMetric=met, freqBin=fb, fineIdx=fi)
+
+    def track_chained(self, rec, n_ch, ms, rec_file_offset=0, data_type=DT_INT8):
+        """preRun on the device behind the pending acquisition + the tracking kernel behind it, one wait.
+        Returns None where the queued sequence does not apply (SGX_E_DEFER: run acquire_end, preRun and track instead),
+        else (series[n_ch, 13, ms], ms_done[n_ch], PRN[n_ch], acquiredFreq[n_ch], codePhase[n_ch], n_active)."""
+        out = pinned_empty((int(n_ch), NUM_SERIES, int(ms)))
+        done = np.zeros(n_ch, dtype=np.int32)
+        prn = np.zeros(n_ch, dtype=np.int32)
+        freq = np.zeros(n_ch)
+        cph = np.zeros(n_ch)
+        n_act = C.c_int32(0)
+        rc = lib().sgx_track_chained(self._h, rec._h, int(rec_file_offset), int(n_ch), int(ms), _ptr(out), _ptr(done),
+                                     int(data_type), _ptr(prn), _ptr(freq), _ptr(cph), C.byref(n_act))
+        if rc == SGX_E_DEFER:
+            return None
+        check(rc)
+        return out, done, prn, freq, cph, n_act.value
 
     def acquire_f64(self, signal, prn0, n_blocks=2, noncoh=False):
         """acquire() on a host signal of any real dtype (copied to HBM as fp64)."""

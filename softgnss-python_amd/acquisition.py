@@ -15,26 +15,54 @@ from .record import DeviceSignal
 
 
 class AcquisitionResult(Result):
-    def __init__(self, settings, verbose=False, device=None):
+    def __init__(self, settings, verbose=False, device=None, deferred=False):
+        """deferred (extension; the reference and the default are eager): acquire() of a DeviceSignal only QUEUES the
+        search and preRun() only notes that it was asked for; TrackingResult.track() of a DeviceFile then runs preRun on
+        the device and the tracking kernel behind it and the host waits ONCE for all three (include/sgx.h,
+        sgx_acquire_begin / sgx_track_chained).  Anything that looks at .results / .channels / .peakMetric ... earlier
+        simply waits for the search then.  Results are the eager ones, bit for bit; the reference's IndexError
+        (acquisition.py:152-162) is raised by whichever call looks first instead of by acquire()."""
         Result.__init__(self, settings)
         self._verbose = verbose
         self._device = device
-        self.internals = None      # frequencyBinIndex / fftMaxIndex per PRN, for parity checks
+        self._deferred = bool(deferred)
+        self._pending = None           # (context, PRN indices) of a queued search nobody has looked at
+        self._prerun_pending = False   # preRun() was called while the search was still queued
+        self._internals = None
+
+    @property
+    def internals(self):
+        """frequencyBinIndex / fftMaxIndex per PRN, for parity checks"""
+        self._materialize()
+        return self._internals
+
+    @internals.setter
+    def internals(self, value):
+        self._internals = value
+
+    def _materialize(self):
+        if self._pending is not None:
+            ctx, prn_indices, token = self._pending
+            self._pending = None
+            if getattr(ctx, "_acq_token", None) != token:
+                raise RuntimeError("this deferred acquisition was superseded by a later one on the same context before "
+                                   "anybody looked at it (one search may be pending per context)")
+            self._fill(prn_indices, ctx.acquire_end(len(prn_indices)))
+        if self._prerun_pending:
+            self._prerun_pending = False
+            self._prerun_host()
 
     @property
     def peakMetric(self):
-        assert isinstance(self._results, np.recarray)
-        return self._results.peakMetric
+        return self.results.peakMetric
 
     @property
     def carrFreq(self):
-        assert isinstance(self._results, np.recarray)
-        return self._results.carrFreq
+        return self.results.carrFreq
 
     @property
     def codePhase(self):
-        assert isinstance(self._results, np.recarray)
-        return self._results.codePhase
+        return self.results.codePhase
 
     def acquire(self, longSignal, n_blocks=2, noncoh=False, prn_indices=None):
         """Cold-start acquisition (reference acquisition.py:27-204).
@@ -67,6 +95,14 @@ class AcquisitionResult(Result):
                 if not np.isrealobj(arr):
                     raise TypeError("longSignal must be real-valued")
                 f64 = arr.astype(np.float64)
+        self._prerun_pending = False
+        if self._deferred and f64 is None and own is None and not self._verbose:
+            token = ctx.acquire_begin(rec, off, n, prn_indices, n_blocks=n_blocks, noncoh=noncoh)
+            self._pending = (ctx, prn_indices, token)
+            self._results = None
+            self._channels = None
+            return
+        self._pending = None
         if self._verbose:
             print('(')
         try:
@@ -77,22 +113,27 @@ class AcquisitionResult(Result):
         finally:
             if own is not None:
                 own.free()
+        self._fill(prn_indices, r)
+        return
+
+    def _fill(self, prn_indices, r):
+        """The reference's three 32-entry result arrays (acquisition.py:201-203) from the library's per-PRN outputs."""
         carrFreq = np.zeros(32)
         codePhase_ = np.zeros(32)
         peakMetric = np.zeros(32)
         freqBin = np.full(32, -1, dtype=np.int64)
         fineIdx = np.full(32, -1, dtype=np.int64)
-        for j, p in enumerate(prn_indices):
-            carrFreq[p] = r["carrFreq"][j]
-            codePhase_[p] = r["codePhase"][j]
-            peakMetric[p] = r["peakMetric"][j]
-            freqBin[p] = r["freqBin"][j]
-            fineIdx[p] = r["fineIdx"][j]
-            if self._verbose:
-                print('%02d ' % (p + 1) if carrFreq[p] > 0 else '. ')
+        idx = np.asarray(prn_indices, dtype=np.int64)
+        carrFreq[idx] = r["carrFreq"]
+        codePhase_[idx] = r["codePhase"]
+        peakMetric[idx] = r["peakMetric"]
+        freqBin[idx] = r["freqBin"]
+        fineIdx[idx] = r["fineIdx"]
         if self._verbose:
+            for p in prn_indices:
+                print('%02d ' % (p + 1) if carrFreq[p] > 0 else '. ')
             print(')\n')
-        self.internals = dict(freqBin=freqBin, fineIdx=fineIdx)
+        self._internals = dict(freqBin=freqBin, fineIdx=fineIdx)
         self._results = np.rec.fromarrays([carrFreq, codePhase_, peakMetric],
                                           names='carrFreq,codePhase,peakMetric')
         return
@@ -119,6 +160,24 @@ class AcquisitionResult(Result):
     def preRun(self):
         """Channel table from the acquisition results (reference acquisition.py:259-306): stable
         descending sort on peakMetric, first min(numberOfChannels, #detected) become channels."""
+        if self._pending is not None:
+            # deferred: the same table is made on the device when TrackingResult.track() queues the tracking kernel
+            # (csrc/sgx_acq.hip: acq_prerun_kernel), or here on the host by the first look at .channels
+            self._prerun_pending = True
+            self._channels = None
+            return
+        self._prerun_host()
+
+    def _channels_from_table(self, prn, freq, cph, n_active):
+        """The channel table as the device-side preRun left it (sgx_track_chained)."""
+        nch = len(prn)
+        status = ['T' if i < n_active else '-' for i in range(nch)]
+        self._prerun_pending = False
+        self._channels = np.rec.fromarrays([np.asarray(prn, dtype='int64'), np.asarray(freq, dtype=float),
+                                            np.asarray(cph, dtype=float), status],
+                                           names='PRN,acquiredFreq,codePhase,status')
+
+    def _prerun_host(self):
         assert isinstance(self._results, np.recarray)
         settings = self._settings
         nch = int(settings.numberOfChannels)

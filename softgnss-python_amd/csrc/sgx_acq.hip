@@ -443,7 +443,7 @@ static int ensure_buf(void** p, size_t* cap_bytes, size_t need) {
 
 static int acquire_four_step(sgx_ctx* c, SgxSig x, size_t n_samples, const int32_t* prn0,
                              int32_t n_prn, int32_t n_blocks, int32_t noncoh, double* carrFreq, double* codePhase,
-                             double* peakMetric, int32_t* freqBin, int32_t* fineIdx, bool* handled);
+                             double* peakMetric, int32_t* freqBin, int32_t* fineIdx, bool* handled, bool defer = false);
 static int acquire_passes(sgx_ctx* c, SgxSig x, size_t n_samples, const int32_t* prn0, int32_t n_prn, int32_t n_blocks,
                           int32_t noncoh, double* carrFreq, double* codePhase, double* peakMetric, int32_t* freqBin,
                           int32_t* fineIdx);
@@ -1289,7 +1289,7 @@ extern "C" int sgx_acquire_plan(int32_t n_prn, int32_t n_bins, int32_t n_blocks,
 // number of PRN chunks.
 static int acquire_four_step(sgx_ctx* c, SgxSig x, size_t n_samples, const int32_t* prn0,
                              int32_t n_prn, int32_t n_blocks, int32_t noncoh, double* carrFreq, double* codePhase,
-                             double* peakMetric, int32_t* freqBin, int32_t* fineIdx, bool* handled) {
+                             double* peakMetric, int32_t* freqBin, int32_t* fineIdx, bool* handled, bool defer) {
     *handled = false;
     const long long N = c->n_code;
     const sgx_settings& S = c->s;
@@ -1549,7 +1549,8 @@ static int acquire_four_step(sgx_ctx* c, SgxSig x, size_t n_samples, const int32
         acq_publish_kernel<<<1, 64, 0, st>>>(d_po, d_second, n_prn, device_led ? d_stage : (CoarseLook*)c->d_look, seq, d_prn,
                                              S.acqThreshold, fine_len, (long long)n_samples, device_led ? d_det : nullptr);
     // (an event between the coarse and the fine kernels holds the fine search back by 6-8 us: recorded on request only)
-    static const bool split_event = getenv("SGX_ACQ_SPLIT_EVENT") && getenv("SGX_ACQ_SPLIT_EVENT")[0] == '1';
+    const char* sev = getenv("SGX_ACQ_SPLIT_EVENT");   // (read per call, like every other SGX_ACQ_* knob)
+    const bool split_event = sev && sev[0] == '1';
     if (split_event || !device_led) hipEventRecord(c->ev[1], st);
     SGX_HIP(hipGetLastError());
     if (device_led) {
@@ -1561,10 +1562,20 @@ static int acquire_four_step(sgx_ctx* c, SgxSig x, size_t n_samples, const int32
         if (rc != SGX_OK) return rc;
         hipEventRecord(c->ev[2], st);
         SGX_HIP(hipGetLastError());
-        rc = coarse_look_wait(c, seq, true);
-    } else {
-        rc = coarse_look_wait(c, seq);
+        // everything is queued; what the look needs to be decoded later (sgx_acquire_finish)
+        AcqPending& P = c->acq_pending;
+        P.mode = 1;
+        P.seq = seq;
+        P.n_prn = n_prn;
+        for (int i = 0; i < n_prn; ++i) P.prn0[i] = prn0[i];
+        P.N = N;
+        P.npts = npts;
+        P.fine_len = fine_len;
+        P.n_samples = n_samples;
+        if (defer) return SGX_OK;
+        return sgx_acquire_finish(c, carrFreq, codePhase, peakMetric, freqBin, fineIdx);
     }
+    rc = coarse_look_wait(c, seq);
     if (rc != SGX_OK) return rc;
     const CoarseLook* look = (const CoarseLook*)c->h_look;
     const PeakOut* h_po = &look->po;
@@ -1591,37 +1602,242 @@ static int acquire_four_step(sgx_ctx* c, SgxSig x, size_t n_samples, const int32
             det_slot.push_back(pi);
         }
     }
-    if (device_led) {
-        if (look->range_error) {
-            const int o = look->range_error - 1;
-            sgx_set_error("fine search needs codePhase + 10 ms = %lld samples, record window has %zu "
-                          "(reference acquisition.py:177 would fail to broadcast)", (long long)cph[o] + fine_len, n_samples);
-            return SGX_E_RANGE;
-        }
-        if (look->n_det != (int)det_prn.size()) {   // (the same comparison on the same doubles: cannot differ)
-            sgx_set_error("acquisition: device found %d detections, host %zu", look->n_det, det_prn.size());
-            return SGX_E_HIP;
-        }
-        for (int d = 0; d < look->n_det; ++d) {
-            const long long m = look->fine_bi[d] - 4;   // index inside the [4:uniq-5] slice (acquisition.py:187)
-            const int o = look->det_slot[d];
-            carrFreq[o] = ((double)m * S.samplingFreq) / (double)npts;   // acquisition.py:189-191 (Q3)
-            codePhase[o] = (double)look->det_phase[d];
-            fineIdx[o] = (int)m;
-        }
-        // (the result word is stored a moment before the last kernel retires: the device times below need its event)
-        SGX_HIP(hipEventSynchronize(c->ev[2]));
-    } else {
-        rc = acquire_fine(c, x, n_samples, det_prn, det_phase, det_slot, d_sum, carrFreq, codePhase, fineIdx);
-        if (rc != SGX_OK) return rc;
-    }
+    rc = acquire_fine(c, x, n_samples, det_prn, det_phase, det_slot, d_sum, carrFreq, codePhase, fineIdx);
+    if (rc != SGX_OK) return rc;
     hipEventElapsedTime(&c->timing.acquire_ms, c->ev[0], c->ev[2]);
-    if (split_event || !device_led) {
+    hipEventElapsedTime(&c->timing.acq_coarse_ms, c->ev[0], c->ev[1]);
+    hipEventElapsedTime(&c->timing.acq_fine_ms, c->ev[1], c->ev[2]);
+    return SGX_OK;
+}
+
+// The host's ONE look at a device-led acquisition (queued by acquire_four_step; c->acq_pending says what was asked): waits
+// for the result page's second word, then decodes peaks, detections and fine frequencies exactly as the eager call did.
+int sgx_acquire_finish(sgx_ctx* c, double* carrFreq, double* codePhase, double* peakMetric, int32_t* freqBin, int32_t* fineIdx) {
+    AcqPending& P = c->acq_pending;
+    if (P.mode == 2) {   // (the search could not be deferred and ran eagerly: its outputs were kept)
+        P.mode = 0;
+        for (int i = 0; i < P.n_prn; ++i) {
+            carrFreq[i] = P.res_carr[i];
+            codePhase[i] = P.res_cph[i];
+            peakMetric[i] = P.res_met[i];
+            freqBin[i] = P.res_fb[i];
+            fineIdx[i] = P.res_fi[i];
+        }
+        return P.rc;
+    }
+    if (P.mode != 1) {
+        sgx_set_error("sgx_acquire_end: no acquisition is pending on this context");
+        return SGX_E_ARG;
+    }
+    P.mode = 0;
+    const sgx_settings& S = c->s;
+    const int n_prn = P.n_prn;
+    const long long N = P.N, npts = P.npts, fine_len = P.fine_len;
+    const size_t n_samples = P.n_samples;
+    const int* prn0 = P.prn0;
+    for (int i = 0; i < n_prn; ++i) {
+        carrFreq[i] = 0.0;
+        codePhase[i] = 0.0;
+        peakMetric[i] = 0.0;
+        freqBin[i] = -1;
+        fineIdx[i] = -1;
+    }
+    int rc = coarse_look_wait(c, P.seq, true);
+    if (rc != SGX_OK) return rc;
+    const CoarseLook* look = (const CoarseLook*)c->h_look;
+    const PeakOut* h_po = &look->po;
+    const double* h_second = look->second;
+    const double* peak = h_po->peak;
+    const int* cph = h_po->cph;
+    const int* fbi = h_po->fbi;
+    for (int pi = 0; pi < n_prn; ++pi) {
+        if (h_po->index_error[pi]) {
+            sgx_set_error("IndexError: index %lld is out of bounds for axis 1 with size %lld "
+                          "(PRN index %d, codePhase %d; reference acquisition.py:152-162)",
+                          N, N, prn0[pi], cph[pi]);
+            return SGX_E_INDEX;
+        }
+    }
+    int n_det_host = 0;
+    for (int pi = 0; pi < n_prn; ++pi) {
+        const double ratio = peak[pi] / h_second[pi];
+        peakMetric[pi] = ratio;
+        freqBin[pi] = fbi[pi];
+        if (ratio > S.acqThreshold) ++n_det_host;
+    }
+    if (look->range_error) {
+        const int o = look->range_error - 1;
+        sgx_set_error("fine search needs codePhase + 10 ms = %lld samples, record window has %zu "
+                      "(reference acquisition.py:177 would fail to broadcast)", (long long)cph[o] + fine_len, n_samples);
+        return SGX_E_RANGE;
+    }
+    if (look->n_det != n_det_host) {   // (the same comparison on the same doubles: cannot differ)
+        sgx_set_error("acquisition: device found %d detections, host %d", look->n_det, n_det_host);
+        return SGX_E_HIP;
+    }
+    for (int d = 0; d < look->n_det; ++d) {
+        const long long m = look->fine_bi[d] - 4;   // index inside the [4:uniq-5] slice (acquisition.py:187)
+        const int o = look->det_slot[d];
+        carrFreq[o] = ((double)m * S.samplingFreq) / (double)npts;   // acquisition.py:189-191 (Q3)
+        codePhase[o] = (double)look->det_phase[d];
+        fineIdx[o] = (int)m;
+    }
+    // (the result word is stored a moment before the last kernel retires: the device times below need its event)
+    SGX_HIP(hipEventSynchronize(c->ev[2]));
+    hipEventElapsedTime(&c->timing.acquire_ms, c->ev[0], c->ev[2]);
+    // (SGX_ACQ_SPLIT_EVENT=1 records an event between the coarse and the fine kernels, which holds the fine search back by
+    // 6-8 us; without it the split is NOT measured: NaN, not total / 0)
+    const char* sev = getenv("SGX_ACQ_SPLIT_EVENT");
+    if (sev && sev[0] == '1') {
         hipEventElapsedTime(&c->timing.acq_coarse_ms, c->ev[0], c->ev[1]);
         hipEventElapsedTime(&c->timing.acq_fine_ms, c->ev[1], c->ev[2]);
     } else {
-        c->timing.acq_coarse_ms = c->timing.acquire_ms;
-        c->timing.acq_fine_ms = 0.0f;
+        c->timing.acq_coarse_ms = __builtin_nanf("");
+        c->timing.acq_fine_ms = __builtin_nanf("");
     }
     return SGX_OK;
+}
+
+
+// ================================ round 6: deferred acquisition, preRun on the device ================================
+// The reference's caller (initialize.py:484-506) runs acquire -> preRun -> track and looks at each result in between.  A
+// caller that only wants the tracking results can queue all three: sgx_acquire_begin queues the search and returns,
+// sgx_track_chained (sgx_trk.hip) queues preRun - the kernel below - and the tracking kernel behind it and waits ONCE;
+// sgx_acquire_end then decodes the search's page (no waiting left).  Outputs are those of the eager calls, bit for bit:
+// the same kernels in the same order, and the kernel below repeats the host's arithmetic (one IEEE multiplication and
+// division for carrFreq, one division for peakMetric, a stable descending sort).
+// acquisition.py:259-306 on the device.  One wave; lane p = PRN index p of the 32-entry result arrays.
+__global__ __launch_bounds__(64) void acq_prerun_kernel(const CoarseLook* __restrict__ stage, const long long* __restrict__ fine_bi,
+                                                        const int* __restrict__ prn_list, int n_prn, double fs, double npts,
+                                                        TrkChan* __restrict__ d_ch, int n_ch, long long skip_bytes,
+                                                        long long rec_file_offset, int sample_bytes,
+                                                        StepLook* __restrict__ look) {
+    __shared__ double s_met[32], s_carr[32], s_cph[32];
+    __shared__ int s_err;
+    const int t = threadIdx.x;
+    if (t < 32) {
+        s_met[t] = 0.0;
+        s_carr[t] = 0.0;
+        s_cph[t] = 0.0;
+    }
+    if (t == 0) s_err = 0;
+    __syncthreads();
+    if (t < n_prn) {
+        s_met[prn_list[t]] = stage->po.peak[t] / stage->second[t];   // acquisition.py:164
+        if (stage->po.index_error[t]) atomicOr(&s_err, 2);
+    }
+    if (t == 0 && stage->range_error) atomicOr(&s_err, 2);
+    __syncthreads();
+    const int n_det = stage->n_det;
+    if (t < n_det && s_err == 0) {
+        const long long m = fine_bi[t] - 4;                          // acquisition.py:187-191 (Q3)
+        const int p = prn_list[stage->det_slot[t]];
+        s_carr[p] = ((double)m * fs) / npts;
+        s_cph[p] = (double)stage->det_phase[t];
+    }
+    __syncthreads();
+    // sorted(enumerate(peakMetric), key = metric, reverse = True): stable, descending (acquisition.py:289-290)
+    int rank = 0, nan = 0;
+    if (t < 32) {
+        const double mine = s_met[t];
+        nan = (mine != mine) ? 1 : 0;
+        for (int q = 0; q < 32; ++q) {
+            const double o = s_met[q];
+            rank += (o > mine || (o == mine && q < t)) ? 1 : 0;
+        }
+    }
+    const unsigned long long any_nan = __builtin_amdgcn_ballot_w64(nan != 0);
+    const int count = __builtin_popcountll(__builtin_amdgcn_ballot_w64(t < 32 && s_carr[t] > 0.0));   // sum(carrFreq > 0)
+    int flags = s_err | (any_nan ? 1 : 0);
+    const int n_act = flags ? 0 : (count < n_ch ? count : n_ch);
+    // channels that are off (acquisition.py:281-284); the lanes holding ranks < n_act then fill theirs
+    if (t < n_ch) {
+        d_ch[t].acquiredFreq = 0.0;
+        d_ch[t].pos0 = 0;
+        d_ch[t].prn = 0;
+        d_ch[t].pad = 0;
+        if (t < 32) {
+            look->prn[t] = 0;
+            look->acquiredFreq[t] = 0.0;
+            look->codePhase[t] = 0.0;
+        }
+    }
+    __syncthreads();
+    int before = 0;
+    if (t < 32 && rank < n_act) {
+        const long long p0 = skip_bytes + (long long)s_cph[t] - rec_file_offset;   // tracking.py:107
+        if (p0 < 0) before = 1;
+        d_ch[rank].acquiredFreq = s_carr[t];
+        d_ch[rank].pos0 = p0 / sample_bytes;
+        d_ch[rank].prn = t + 1;
+        d_ch[rank].pad = (int)(p0 % sample_bytes);
+        look->prn[rank] = t + 1;
+        look->acquiredFreq[rank] = s_carr[t];
+        look->codePhase[rank] = s_cph[t];
+    }
+    if (__builtin_amdgcn_ballot_w64(before != 0)) {
+        flags |= 4;
+        __syncthreads();
+        if (t < n_ch) d_ch[t].prn = 0;      // (nothing is tracked; the host reports the channel)
+    }
+    if (t == 0) {
+        look->n_ch = n_ch;
+        look->n_active = n_act;
+        look->flags = flags;
+    }
+}
+
+int sgx_prerun_enqueue(sgx_ctx* c, TrkChan* d_ch, int n_ch, long long skip_bytes, long long rec_file_offset, int sample_bytes) {
+    const AcqPending& P = c->acq_pending;
+    if (P.mode != 1 || n_ch < 1 || n_ch > 32) return SGX_E_DEFER;
+    char* dsm = (char*)c->d_small;
+    const CoarseLook* d_stage = (const CoarseLook*)(dsm + 700000);
+    const int* d_prn = (const int*)(dsm + 64);
+    StepLook* look = (StepLook*)((char*)c->d_look + SGX_STEP_LOOK_OFFSET);
+    acq_prerun_kernel<<<1, 64, 0, c->stream>>>(d_stage, ((const CoarseLook*)c->d_look)->fine_bi, d_prn, P.n_prn,
+                                               c->s.samplingFreq, (double)P.npts, d_ch, n_ch, skip_bytes, rec_file_offset,
+                                               sample_bytes, look);
+    SGX_HIP(hipGetLastError());
+    return SGX_OK;
+}
+
+extern "C" int sgx_acquire_begin(sgx_ctx* c, const sgx_if* r, size_t offset, size_t n_samples, const int32_t* prn0,
+                                 int32_t n_prn, int32_t n_blocks, int32_t noncoh) {
+    SGX_CHECK_ARG(c && r && prn0);
+    SGX_CHECK_ARG(n_prn >= 1 && n_prn <= 32 && n_blocks >= 1 && n_blocks <= 64);
+    for (int i = 0; i < n_prn; ++i) SGX_CHECK_ARG(prn0[i] >= 0 && prn0[i] < 32);
+    const long long N = c->n_code;
+    if (offset > r->n || n_samples > r->n - offset || (long long)n_samples < (long long)n_blocks * N) {
+        sgx_set_error("record window too short: %zu samples at offset %zu, %lld needed for the coarse search",
+                      n_samples, offset, (long long)n_blocks * N);
+        return SGX_E_RANGE;
+    }
+    {
+        const int rq = sgx_if_require(r, offset + n_samples);
+        if (rq != SGX_OK) return rq;
+    }
+    SGX_HIP(hipSetDevice(c->device));
+    SgxSig x;
+    x.i8 = r->d + offset;
+    x.f64 = nullptr;
+    AcqPending& P = c->acq_pending;
+    P.mode = 0;
+    bool handled = false;
+    int rc = acquire_four_step(c, x, n_samples, prn0, n_prn, n_blocks, noncoh, P.res_carr, P.res_cph, P.res_met, P.res_fb,
+                               P.res_fi, &handled, true);
+    if (handled && P.mode == 1) return rc;          // queued; nothing has been looked at
+    if (!handled)
+        rc = acquire_passes(c, x, n_samples, prn0, n_prn, n_blocks, noncoh, P.res_carr, P.res_cph, P.res_met, P.res_fb, P.res_fi);
+    // (a path without the device-led sequence: it ran eagerly; sgx_acquire_end hands its outputs over)
+    P.mode = 2;
+    P.n_prn = n_prn;
+    P.rc = rc;
+    return SGX_OK;
+}
+
+extern "C" int sgx_acquire_end(sgx_ctx* c, double* carrFreq, double* codePhase, double* peakMetric, int32_t* freqBin,
+                               int32_t* fineIdx) {
+    SGX_CHECK_ARG(c && carrFreq && codePhase && peakMetric && freqBin && fineIdx);
+    SGX_HIP(hipSetDevice(c->device));
+    return sgx_acquire_finish(c, carrFreq, codePhase, peakMetric, freqBin, fineIdx);
 }

@@ -78,8 +78,36 @@ int sgx_track_float64(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, cons
                       double* out, int32_t* ms_done);
 #define SGX_IF_PAD 256
 
+// A DEFERRED acquisition (sgx_acquire_begin, round 6): every kernel of the search is queued, the host has not looked.
+// mode 1: the device-led sequence is in flight (the result page's seq2 will equal `seq`); mode 2: the path could not be
+// deferred, the search ran eagerly and its outputs wait in res_* for sgx_acquire_end.
+struct AcqPending {
+    int mode = 0;
+    unsigned long long seq = 0;
+    int n_prn = 0;
+    int prn0[32];
+    long long N = 0, npts = 0, fine_len = 0;
+    size_t n_samples = 0;
+    int rc = 0;                 // mode 2: the eager search's return code
+    double res_carr[32], res_cph[32], res_met[32];
+    int res_fb[32], res_fi[32];
+};
+
+// What the device-side preRun + a chained tracking launch leave in the upper half of the result page (offset 2048)
+struct StepLook {
+    int n_ch, n_active;         // channels of the table, channels that are on (acquisition.py:289)
+    int flags;                  // 1 a NaN among the metrics (the host sorts); 2 IndexError / range error of the search (no
+                                // channel is on); 4 a channel starts before the record
+    int pad;
+    int prn[32];
+    double acquiredFreq[32], codePhase[32];
+};
+static_assert(sizeof(StepLook) <= 2048, "upper half of the result page");
+#define SGX_STEP_LOOK_OFFSET 2048
+
 struct sgx_ctx {
     sgx_settings s;
+    AcqPending acq_pending;
     int device = 0;
     int priority = 0;            // stream priority class of the context: -1 high, 0 normal, +1 low
     hipStream_t stream = nullptr;
@@ -196,5 +224,17 @@ int sgx_fft4_row_blocks(void);
 int sgx_fft4_residues(void);
 int sgx_fft4_forward(const FftPlan* p, const cplx* in, cplx* work, cplx* out, int64_t rows, hipStream_t st,
                      const Fft4Fuse* fuse);
+
+// sgx_acq.hip: preRun (acquisition.py:259-306) on the device, behind a deferred acquisition: channel table -> d_ch (what the
+// tracking kernels read) and the result page's StepLook.  d_ch: TrkChan[n_ch] in device memory.
+struct TrkChan {      // one channel as the tracking kernels read it
+    double acquiredFreq;
+    long long pos0;   // record index of the channel's first sample
+    int prn;          // 1-based, 0 = off
+    int pad;          // two-byte samples: byte shift (0 / 1) of the channel's sample grid in the record; else 0
+};
+int sgx_prerun_enqueue(sgx_ctx* c, TrkChan* d_ch, int n_ch, long long skip_bytes, long long rec_file_offset, int sample_bytes);
+// Wait for a deferred acquisition and decode it (the tail of the eager call); clears c->acq_pending.
+int sgx_acquire_finish(sgx_ctx* c, double* carrFreq, double* codePhase, double* peakMetric, int32_t* freqBin, int32_t* fineIdx);
 
 // sgx_synth.hip / sgx_acq.hip / sgx_trk.hip provide the C-ABI entry points directly.

@@ -156,9 +156,12 @@ extern "C" int sgx_track_plan(const sgx_settings* s, int32_t data_type, int32_t 
 // fscale > 0 (float32 / float64 only): every sample the channels can reach is finite and at most 128 / fscale in magnitude
 // (sgx_trk_f32.hip has scanned the window; fscale is a power of two) - the record then runs the latency-mode kernel, which
 // scales the samples by it on conversion; the correlator series are scaled back here.  0: the per-sample kernel.
-int sgx_track_kind(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const sgx_chan_init* ch, int32_t n_ch,
-                   int32_t ms, double* out, int32_t* ms_done, int kind, long long skip_bytes, double fscale) {
-    SGX_CHECK_ARG(c && r && ch && out && ms_done);
+// chained (round 6, sgx_track_chained): `ch` is null - the channel table is made ON THE DEVICE by the preRun kernel queued
+// in front of the first launch (sgx_prerun_enqueue, sgx_acq.hip) from the acquisition that is pending on this context.
+static int track_kind_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const sgx_chan_init* ch, int32_t n_ch,
+                           int32_t ms, double* out, int32_t* ms_done, int kind, long long skip_bytes, double fscale,
+                           bool chained) {
+    SGX_CHECK_ARG(c && r && (ch || chained) && out && ms_done);
     const int sample_bytes = sgx_dt_bytes(kind);
     SGX_CHECK_ARG(sample_bytes >= 1);
     const bool sample_uns = kind == SGX_DT_UINT8;
@@ -196,7 +199,7 @@ int sgx_track_kind(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const s
     K.mark = nullptr;
     // (a float record the typed kernel can take: in range, no channel starting inside a sample, not switched off)
     bool floaty = (kind == SGX_DT_FLOAT32 || kind == SGX_DT_FLOAT64) && fscale > 0.0;
-    for (int i = 0; i < n_ch && floaty; ++i) {
+    for (int i = 0; i < n_ch && floaty && !chained; ++i) {
         // (a channel that starts inside a sample reads other values than the ones that were scanned)
         const long long p0 = skip_bytes + (long long)ch[i].codePhase - rec_file_offset;
         if (ch[i].prn != 0 && p0 >= 0 && p0 % sample_bytes != 0) floaty = false;
@@ -245,7 +248,7 @@ int sgx_track_kind(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const s
     }
 
     std::vector<TrkChan> hc((size_t)n_ch);
-    for (int i = 0; i < n_ch; ++i) {
+    for (int i = 0; i < n_ch && !chained; ++i) {
         hc[(size_t)i].acquiredFreq = ch[i].acquiredFreq;
         hc[(size_t)i].prn = ch[i].prn;
         hc[(size_t)i].pad = 0;
@@ -340,16 +343,26 @@ int sgx_track_kind(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const s
     bool used_v2 = false;
     // what the launches so far have established: the record's streaming has been tried (and stalled), a member of a
     // cooperative layout timed out (the next launch runs with one workgroup per channel)
-    bool stream_tried = false, fallback_one = false, v3_off = false;
+    bool stream_tried = false, fallback_one = false;
+    const bool v3_off = false;
     int used_members = 0;
     hipError_t e = hipSuccess;
     int h_err = 0;
     // The cooperating workgroups of a channel wait for each other, so all of them must be resident at once.  If
     // something else occupies the CUs a member times out (bounded spins) and flags the channel: the launch is
     // then repeated once with one workgroup per channel, which needs no co-residency.  A streaming record whose
-    // watermark stalls is repeated on the resident record first, with the same decomposition: at most three launches.
+    // watermark stalls is repeated on the resident record first, with the same decomposition: at most three launches, each
+    // repeat said on stderr.  (Rounds 4-5 also repeated a record too strong for the speculative kernel's 48-bit granules
+    // with the round-3 kernel; since round 6 its granules hold any record's sums, sgx_trk3.hip.)
+    if (chained && r->loader && !r->load_done.load()) return SGX_E_DEFER;   // (a record that is still streaming in)
     for (int launches = 0; launches < 4; ++launches) {
-        SGX_HIP(hipMemcpyAsync(d_ch, hc.data(), sizeof(TrkChan) * (size_t)n_ch, hipMemcpyHostToDevice, st));
+        if (!chained) {
+            SGX_HIP(hipMemcpyAsync(d_ch, hc.data(), sizeof(TrkChan) * (size_t)n_ch, hipMemcpyHostToDevice, st));
+        } else if (launches == 0) {
+            // preRun on the device: the table lands in d_ch (a repeated launch finds it there)
+            const int rp = sgx_prerun_enqueue(c, d_ch, n_ch, skip_bytes, rec_file_offset, sample_bytes);
+            if (rp != SGX_OK) return rp;
+        }
         SGX_HIP(hipMemsetAsync(aux + sz_ch, 0, sz_done + sz_xch + 256, st));   // done, every polled word, err
         if (!direct) trk_fill_kernel<<<(unsigned)((elems + 255) / 256), 256, 0, st>>>(d_out, ms, (long long)elems);
         // a record that is still streaming in is followed by the latency-mode kernel (its record wave watches the
@@ -448,13 +461,6 @@ int sgx_track_kind(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const s
             continue;
         }
         h_err &= ~TRK_ERR_STREAM;
-        if (e == hipSuccess && (h_err & TRK_ERR_SCALE) && !v3_off) {
-            // sums beyond the room of the speculative kernel's 2^30 fixed point (a record far stronger than any front end
-            // delivers): the round-3 kernel, whose 2^28 holds full-scale samples that all line up, tracks it
-            v3_off = true;
-            continue;
-        }
-        h_err &= ~TRK_ERR_SCALE;
         if (e == hipSuccess && (h_err & TRK_ERR_RANGE) == 0) h_err &= 0xFFFF;
         if (e == hipSuccess && (h_err & TRK_ERR_RANGE)) {
             sgx_set_error("tracking: channel %d reached a block longer than the %d units of %d samples the kernel "
@@ -522,6 +528,34 @@ int sgx_track_kind(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const s
             for (int sidx = 3; sidx <= 8; ++sidx)
                 for (int t = 0; t < dn; ++t) o[(size_t)sidx * ms + t] *= un;
         }
+    }
+    return SGX_OK;
+}
+
+int sgx_track_kind(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, const sgx_chan_init* ch, int32_t n_ch,
+                   int32_t ms, double* out, int32_t* ms_done, int kind, long long skip_bytes, double fscale) {
+    return track_kind_impl(c, r, rec_file_offset, ch, n_ch, ms, out, ms_done, kind, skip_bytes, fscale, false);
+}
+
+// include/sgx.h: preRun on the device behind the pending acquisition, the tracking kernel behind it, ONE wait.
+extern "C" int sgx_track_chained(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset, int32_t n_ch, int32_t ms, double* out,
+                                 int32_t* ms_done, int32_t data_type, int32_t* prn, double* acquiredFreq, double* codePhase,
+                                 int32_t* n_active) {
+    SGX_CHECK_ARG(c && r && out && ms_done && prn && acquiredFreq && codePhase && n_active);
+    if (c->acq_pending.mode != 1 || n_ch < 1 || n_ch > 32) return SGX_E_DEFER;
+    if (data_type != SGX_DT_INT8 && data_type != SGX_DT_UINT8) return SGX_E_DEFER;
+    const int rc = track_kind_impl(c, r, rec_file_offset, nullptr, n_ch, ms, out, ms_done, data_type,
+                                   (long long)c->s.skipNumberOfBytes, 0.0, true);
+    if (rc != SGX_OK) return rc;
+    // (the stream has been synchronised: the page is complete)
+    const StepLook* look = (const StepLook*)((const char*)c->h_look + SGX_STEP_LOOK_OFFSET);
+    if (look->n_ch != n_ch || look->flags != 0) return SGX_E_DEFER;   // a NaN metric, a failed search, a channel in front of
+                                                                       // the record: nothing was tracked, the eager calls report it
+    *n_active = look->n_active;
+    for (int i = 0; i < n_ch; ++i) {
+        prn[i] = look->prn[i];
+        acquiredFreq[i] = look->acquiredFreq[i];
+        codePhase[i] = look->codePhase[i];
     }
     return SGX_OK;
 }

@@ -46,7 +46,8 @@
 // factor, and steps beyond 20 Hz (the pull-in) are evaluated exactly - tables in full, accumulate again - because the
 // residue of those first blocks sat in the code NCO's integrator for the rest of the run (code phase 1e-11 chips from the
 // reference's after 10 000 blocks: enough to put a sample 3e-12 chips from a chip boundary on the other side).
-// Exchange: granules {16-bit epoch | 48-bit fixed point, 2^30}, order-free integer sums, redundant filters in every member;
+// Exchange: granules {52-bit fixed point, 2^30 | 4 zero bits | 8-bit epoch} (round 6: a unit's total cannot leave 52 bits,
+// whatever the record), order-free integer sums, redundant filters in every member;
 // an arm's I and Q of a unit side by side; the filter waves keep THREE looks in flight (the PLL wave 8-byte loads, the DLL
 // wave one 16-byte load per look; reserved registers v[244:255]).  Record path and abort protocol are those of
 // sgx_trk2.hip.
@@ -75,9 +76,12 @@
 // difference between this kernel's sums and the reference's own (9e-13 relative against 4e-13 from the reference's carrier
 // argument; the code NCO disagrees by an ulp in 3 % of the blocks because of it, and the code phases of two
 // implementations then drift apart until a sample within 1e-11 chips of a chip boundary falls on different sides).
-// A unit's total must stay below 2^17 (the default scene's prompt sums: 7 500 per unit): the PLL wave looks at the units'
-// prompt granules behind the barrier and a record whose sums pass HALF the room is tracked by sgx_trk2.hip instead
-// (TRK_ERR_SCALE, the host repeats the launch).
+// Rounds 4-5 kept a 48-bit payload under a 16-bit epoch: a unit's total had to stay below 2^17, a guard on the PLL wave sent
+// stronger records to sgx_trk2.hip (TRK_ERR_SCALE) - and looked at payloads that had already wrapped (totals of 1.5 x 2^17
+// and more passed it).  Round 6: the payload is the double's whole 52-bit mantissa field, above an epoch of 8 bits (a slot
+// is rewritten every second block: consecutive epochs of a slot differ by 2).  A unit holds 2 048 samples of at most 255
+// in magnitude: |total| 2^30 <= 2^49 < 2^51 - no record can wrap it, there is no guard and no repeated launch.  The filter
+// waves add the payloads as two 26-bit limbs (32 lanes: 31 bits).
 #ifndef T3_FIX
 #define T3_FIX 1073741824.0
 #endif
@@ -121,53 +125,6 @@ struct T3Shared {
     unsigned long long tl[6][2][8]; // (diagnosis) sums of the waves' event stamps [wave][block parity][event]
 #endif
 };
-
-// Two 64-bit values per lane -> sums over lanes 0..31 (rows 1) and 32..63 (rows 3) of either, the two chains interleaved
-// so that no DPP source was written by either of the two instructions before it (no wait states, no s_nop)
-__device__ __forceinline__ void t3_reduce2_half(unsigned long long& a, unsigned long long& b) {
-    unsigned a0 = (unsigned)a, a1 = (unsigned)(a >> 32), b0 = (unsigned)b, b1 = (unsigned)(b >> 32);
-    unsigned c0, c1, d0, d1;
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_add_co_u32_dpp %4, vcc, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_addc_co_u32_dpp %5, vcc, %1, %1, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_co_u32_dpp %6, vcc, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_addc_co_u32_dpp %7, vcc, %3, %3, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_co_u32_dpp %0, vcc, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_addc_co_u32_dpp %1, vcc, %5, %5, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_co_u32_dpp %2, vcc, %6, %6 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_addc_co_u32_dpp %3, vcc, %7, %7, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_co_u32_dpp %4, vcc, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_addc_co_u32_dpp %5, vcc, %1, %1, vcc row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_co_u32_dpp %6, vcc, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_addc_co_u32_dpp %7, vcc, %3, %3, vcc row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_co_u32_dpp %0, vcc, %4, %4 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_addc_co_u32_dpp %1, vcc, %5, %5, vcc row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_co_u32_dpp %2, vcc, %6, %6 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_addc_co_u32_dpp %3, vcc, %7, %7, vcc row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_co_u32_dpp %4, vcc, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "v_addc_co_u32_dpp %5, vcc, %1, %1, vcc row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "v_add_co_u32_dpp %6, vcc, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "v_addc_co_u32_dpp %7, vcc, %3, %3, vcc row_bcast:15 row_mask:0xa bank_mask:0xf"
-        : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "=&v"(c0), "=&v"(c1), "=&v"(d0), "=&v"(d1)
-        :
-        : "vcc");
-    a = ((unsigned long long)c1 << 32) | c0;
-    b = ((unsigned long long)d1 << 32) | d0;
-}
-
-// rows 1 and 3 of the wave: v + (lane 15 of the row before) - joins two 16-lane row sums into a 32-lane sum
-__device__ __forceinline__ unsigned long long t3_addl_bc15(unsigned long long v) {
-    const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-    unsigned olo, ohi;
-    asm volatile("s_nop 1\n\t"
-                 "v_add_co_u32_dpp %0, vcc, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-                 "v_addc_co_u32_dpp %1, vcc, %3, %3, vcc row_bcast:15 row_mask:0xa bank_mask:0xf"
-                 : "=&v"(olo), "=&v"(ohi)
-                 : "v"(lo), "v"(hi)
-                 : "vcc");
-    return ((unsigned long long)ohi << 32) | olo;
-}
 
 // -DTRK_WAVEPROF: how long after the barrier's release each wave of (channel 0, member 0) arrives at the next one
 #ifdef TRK_WAVEPROF
@@ -236,14 +193,14 @@ __device__ __forceinline__ unsigned long long t3_addl_bc15(unsigned long long v)
 #define T3_TL_SET(mask, on, wave_, e, v) do { } while (0)
 #endif
 
-// Sum of the 48-bit payloads (two's complement) of the granules of lanes 0..31 / 32..63, as a double, in rows 1 / 3 of the
-// wave: the payload is split into a low limb of 24 bits and a sign-extended high limb, whose sums over 32 lanes fit 32 bits -
+// Sum of the 52-bit payloads (two's complement) of the granules of lanes 0..31 / 32..63, as a double, in rows 1 / 3 of the
+// wave: the payload is split into a low limb of 26 bits and a sign-extended high limb, whose sums over 32 lanes fit 32 bits -
 // two INDEPENDENT chains of one DPP add per step instead of one chain of add + add-with-carry (the carry is a second
-// dependent instruction in each of the five steps of the PLL wave's chain behind its poll); hi 2^24 + lo is exact.
+// dependent instruction in each of the five steps of the PLL wave's chain behind its poll); hi 2^26 + lo is exact.
 __device__ __forceinline__ double t3_sum48_half(unsigned long long x) {
     const unsigned xl = (unsigned)x, xh = (unsigned)(x >> 32);
-    unsigned lo = xl & 0xFFFFFFu;
-    unsigned hi = (unsigned)((int)(__builtin_amdgcn_alignbit(xh, xl, 24) << 8) >> 8);   // bits 24..47, sign-extended
+    unsigned lo = __builtin_amdgcn_alignbit(xh, xl, 12) & 0x3FFFFFFu;   // payload bits 0..25 (granule bits 12..37)
+    unsigned hi = (unsigned)((int)xh >> 6);                             // payload bits 26..51, sign-extended
     unsigned a, b;
 #define T3_S48(d0, d1, s0, s1, ctl)                                                               \
         "v_add_u32_dpp " d0 ", " s0 ", " s0 " " ctl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
@@ -259,15 +216,15 @@ __device__ __forceinline__ double t3_sum48_half(unsigned long long x) {
         "v_add_u32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf"
         : "+v"(lo), "+v"(hi), "=&v"(a), "=&v"(b));
 #undef T3_S48
-    return __builtin_fma((double)(int)hi, 16777216.0, (double)lo);
+    return __builtin_fma((double)(int)hi, 67108864.0, (double)lo);
 }
 
 // the same for two granules per lane (the DLL wave: I in x1, Q in x2): four independent chains, no wait state to fill
 __device__ __forceinline__ void t3_sum48_half2(unsigned long long x1, unsigned long long x2, double& v1, double& v2) {
     const unsigned x1l = (unsigned)x1, x1h = (unsigned)(x1 >> 32), x2l = (unsigned)x2, x2h = (unsigned)(x2 >> 32);
-    unsigned l1 = x1l & 0xFFFFFFu, l2 = x2l & 0xFFFFFFu;
-    unsigned h1 = (unsigned)((int)(__builtin_amdgcn_alignbit(x1h, x1l, 24) << 8) >> 8);
-    unsigned h2 = (unsigned)((int)(__builtin_amdgcn_alignbit(x2h, x2l, 24) << 8) >> 8);
+    unsigned l1 = __builtin_amdgcn_alignbit(x1h, x1l, 12) & 0x3FFFFFFu, l2 = __builtin_amdgcn_alignbit(x2h, x2l, 12) & 0x3FFFFFFu;
+    unsigned h1 = (unsigned)((int)x1h >> 6);
+    unsigned h2 = (unsigned)((int)x2h >> 6);
     unsigned a, b, c, d;
 #define T3_S48(d0, d1, d2, d3, s0, s1, s2, s3, ctl)                                               \
         "v_add_u32_dpp " d0 ", " s0 ", " s0 " " ctl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
@@ -286,8 +243,8 @@ __device__ __forceinline__ void t3_sum48_half2(unsigned long long x1, unsigned l
         "v_add_u32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf"
         : "+v"(l1), "+v"(h1), "+v"(l2), "+v"(h2), "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d));
 #undef T3_S48
-    v1 = __builtin_fma((double)(int)h1, 16777216.0, (double)l1);
-    v2 = __builtin_fma((double)(int)h2, 16777216.0, (double)l2);
+    v1 = __builtin_fma((double)(int)h1, 67108864.0, (double)l1);
+    v2 = __builtin_fma((double)(int)h2, 67108864.0, (double)l2);
 }
 
 __device__ __forceinline__ int t3_carr_mult(int lane, int unit, int head) {
@@ -913,7 +870,7 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
         // fixed point: the raw bits of fma(a, 2^28, 1.5 2^52) are bias + round(a 2^28); sums of them carry the sum of the
         // integers in their low 48 bits whatever the biases add up to
         const double lane_fix = uns ? T3_FIX * 0.5 : T3_FIX;
-        constexpr unsigned long long res_mask = 0xFFFFFFFFFFFFull;
+        constexpr unsigned long long res_mask = 0xFFFFFFFFFFFFFull;   // the 52 mantissa bits
         unsigned long long q[6];
         {
             double t_[6];
@@ -940,7 +897,8 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
                     // the eighth arrival (2 waves x 4 rows): this lane holds the member's total of its word
                     const unsigned long long tot = prev + mine;
                     S.acc[par][word] = 0ull;
-                    const unsigned long long gran = ((unsigned long long)((unsigned)(it + 1) & 0xFFFFu) << 48) | (tot & 0xFFFFFFFFFFFFull);
+                    // (the shift drops the arrival count and what the eight mantissas carried into bits 52 ..)
+                    const unsigned long long gran = (tot << 12) | (unsigned long long)((unsigned)(it + 1) & 0xFFu);
                     granule_store(xbase + ((((par * 3 + (word >> 1)) * T3_XLINE + unit) << 1) | (word & 1)), gran, fast);
 #ifdef T3_TIMELINE
                     if (word == 0) S.tpub[par] = (long long)__builtin_amdgcn_s_memtime();
@@ -1017,8 +975,8 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
 #endif
 #define T3_STR2(x) #x
 #define T3_STR(x) T3_STR2(x)
-__device__ __forceinline__ int t3_poll1(unsigned long long& x, const unsigned long long* p, unsigned long long tag, int rounds) {
-    unsigned long long t;
+__device__ __forceinline__ int t3_poll1(unsigned long long& x, const unsigned long long* p, unsigned tag, int rounds) {
+    unsigned t;
     int left;
     // (THREE loads in flight here: the PLL wave's chain is the longer of the two filter waves')
     asm volatile(
@@ -1031,20 +989,20 @@ __device__ __forceinline__ int t3_poll1(unsigned long long& x, const unsigned lo
         "s_mov_b32 %[n], %[r]\n"
         "1:\n\t"
         "s_waitcnt vmcnt(2)\n\t"
-        "v_lshrrev_b64 %[t], 48, v[250:251]\n\t"
-        "v_cmp_eq_u64_e32 vcc, %[tag], %[t]\n\t"
+        "v_and_b32 %[t], 0xff, v250\n\t"
+        "v_cmp_eq_u32_e32 vcc, %[tag], %[t]\n\t"
         "s_cmp_eq_u64 vcc, exec\n\t"
         "s_cbranch_scc1 2f\n\t"
         "global_load_dwordx2 v[250:251], %[p], off sc1\n\t"
         "s_waitcnt vmcnt(2)\n\t"
-        "v_lshrrev_b64 %[t], 48, v[252:253]\n\t"
-        "v_cmp_eq_u64_e32 vcc, %[tag], %[t]\n\t"
+        "v_and_b32 %[t], 0xff, v252\n\t"
+        "v_cmp_eq_u32_e32 vcc, %[tag], %[t]\n\t"
         "s_cmp_eq_u64 vcc, exec\n\t"
         "s_cbranch_scc1 3f\n\t"
         "global_load_dwordx2 v[252:253], %[p], off sc1\n\t"
         "s_waitcnt vmcnt(2)\n\t"
-        "v_lshrrev_b64 %[t], 48, v[254:255]\n\t"
-        "v_cmp_eq_u64_e32 vcc, %[tag], %[t]\n\t"
+        "v_and_b32 %[t], 0xff, v254\n\t"
+        "v_cmp_eq_u32_e32 vcc, %[tag], %[t]\n\t"
         "s_cmp_eq_u64 vcc, exec\n\t"
         "s_cbranch_scc1 5f\n\t"
         "global_load_dwordx2 v[254:255], %[p], off sc1\n\t"
@@ -1073,16 +1031,16 @@ __device__ __forceinline__ int t3_poll1(unsigned long long& x, const unsigned lo
 #ifndef T3_POLL_GAPD
 #define T3_POLL_GAPD T3_POLL_GAP3    // s_sleep units between the DLL wave's three loads
 #endif
-#define T3_TAGSEL 0x07060302u      // v_perm_b32: {upper half of the first source, upper half of the second}
+#define T3_TAGSEL 0x0c0c0400u      // v_perm_b32: {0, 0, lowest byte of the first source, lowest byte of the second}
 __device__ __forceinline__ int t3_poll2(unsigned long long& x1, unsigned long long& x2, const unsigned long long* p1,
-                                        const unsigned long long* p2, unsigned long long tag, int rounds) {
+                                        const unsigned long long* p2, unsigned tag, int rounds) {
     (void)p2;
     unsigned t;
     int left;
-    const unsigned tag2 = (unsigned)tag | ((unsigned)tag << 16);
-#define T3_P2_CHECK(r0, r1, r3, lbl)                                   \
+    const unsigned tag2 = tag | (tag << 8);
+#define T3_P2_CHECK(r0, r2, r3, lbl)                                   \
         "s_waitcnt vmcnt(2)\n\t"                                        \
-        "v_perm_b32 %[t], v" #r3 ", v" #r1 ", %[sel]\n\t"               \
+        "v_perm_b32 %[t], v" #r2 ", v" #r0 ", %[sel]\n\t"               \
         "v_cmp_eq_u32_e32 vcc, %[tag2], %[t]\n\t"                       \
         "s_cmp_eq_u64 vcc, exec\n\t"                                    \
         "s_cbranch_scc1 " lbl "\n\t"                                    \
@@ -1096,9 +1054,9 @@ __device__ __forceinline__ int t3_poll2(unsigned long long& x1, unsigned long lo
         "global_load_dwordx4 v[252:255], %[p], off sc1\n\t"
         "s_mov_b32 %[n], %[r]\n"
         "1:\n\t"
-        T3_P2_CHECK(244, 245, 247, "2f")
-        T3_P2_CHECK(248, 249, 251, "3f")
-        T3_P2_CHECK(252, 253, 255, "5f")
+        T3_P2_CHECK(244, 246, 247, "2f")
+        T3_P2_CHECK(248, 250, 251, "3f")
+        T3_P2_CHECK(252, 254, 255, "5f")
         "s_sub_u32 %[n], %[n], 1\n\t"
         "s_cmp_lg_u32 %[n], 0\n\t"
         "s_cbranch_scc1 1b\n\t"
@@ -1164,8 +1122,6 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
     T2_PIN(ak.c0); T2_PIN(ak.c1); T2_PIN(ak.c2); T2_PIN(ak.c3); T2_PIN(ak.c4); T2_PIN(ak.c5); T2_PIN(ak.c6); T2_PIN(ak.c7); T2_PIN(ak.c8);
     T2_PIN(rk.s0); T2_PIN(rk.s1); T2_PIN(rk.s2); T2_PIN(rk.s3); T2_PIN(rk.s4); T2_PIN(rk.s5);
     T2_PIN(rk.c0); T2_PIN(rk.c1); T2_PIN(rk.c2); T2_PIN(rk.c3); T2_PIN(rk.c4); T2_PIN(rk.c5);
-    // lane 0 of a 32-lane half adds the bits of 1.5 2^52 to its payload: the half's integer sum then IS the double
-    const int bias_hi = ((lane & 31) == 0) ? 0x43380000 : 0;
     double unfix = 1.0 / (K.uns != 0 ? T3_FIX * 0.5 : T3_FIX);
     T2_PIN(unfix);
     const bool w3 = lane >= 48;
@@ -1237,7 +1193,7 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
         T2_PIN(cs_p); T2_PIN(sn_p); T2_PIN(mf); T2_PIN(rc);   // (keeps all of this ahead of the wait)
         __builtin_amdgcn_s_setprio(3);
         const unsigned long long* gp = xbase + ((((par * 3 + 0) * T3_XLINE + (lane & 31)) << 1) | (lane >> 5));   // (I_P, Q_P of a unit lie side by side)
-        const unsigned long long tag = (unsigned long long)((unsigned)(it + 1) & 0xFFFFu);
+        const unsigned tag = (unsigned)(it + 1) & 0xFFu;
         unsigned long long x = 0;
         int budget = T2_POLL_BUDGET;
         bool gave_up = false;
@@ -1262,7 +1218,7 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
 #else
         for (;;) {
             if (mine) x = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__all(!mine || (x >> 48) == tag)) break;
+            if (__all(!mine || ((unsigned)x & 0xFFu) == tag)) break;
             if ((--budget & 31) == 0) {
                 if (budget == 0 || lds_peek(&S.flag[1]) != 0) {
                     gave_up = true;
@@ -1286,18 +1242,7 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
             }
         }
         // sum of the units' payloads (integers: exact, order-free); lanes that poll nothing hold 0
-#ifdef T3_SUM64   // (the round-4 form: one 64-bit chain, add + add-with-carry per step)
-        unsigned long long q = ((unsigned long long)(unsigned)((int)(short)(unsigned short)(x >> 32) + bias_hi) << 32) | (unsigned)x;
-        q = dpp_addl_xor1(q, q);
-        q = dpp_addl_xor2(q, q);
-        q = dpp_addl_hmir(q, q);
-        q = dpp_addl_mir(q, q);
-        q = t3_addl_bc15(q);             // rows 1 and 3: the sums over lanes 0..31 / 32..63
-        const double v = __longlong_as_double((long long)q) - T2_MAGIC;   // (in units of the fixed point: the discriminator is a ratio)
-#else
-        (void)bias_hi;
         const double v = t3_sum48_half(x);   // rows 1 and 3: the sums over lanes 0..31 / 32..63 (in units of the fixed point)
-#endif
         const double I_P = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16),
                                             __builtin_amdgcn_readlane(__double2loint(v), 16));
         const double Q_P = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 48),
@@ -1352,10 +1297,6 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
         __builtin_amdgcn_s_setprio(T3_PRIO_PRE);   // what follows until the next poll is off the chain: the final pass (2) issues first,
                                          // the speculative pass (0) after it
         __builtin_amdgcn_sched_barrier(0);
-        // (a unit's prompt sum beyond half the room of the 48-bit payload: see T3_FIX)
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(mine && (unsigned)((int)(short)(unsigned short)(x >> 32) + 0x4000) > 0x7FFFu) != 0, 0)) {
-            if (lane == 0) atomicOr(err, TRK_ERR_SCALE);
-        }
         r_cf = carrFreq;                 // (the block's record values: nobody waits for these)
         r_ip = I_P * (s2_blk * unfix);
         r_qp = Q_P * (s2_blk * unfix);
@@ -1424,7 +1365,6 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
     const int l4 = lane & 3;
     const double off = (l4 == 0) ? -D.spacing : ((l4 == 2) ? D.spacing : 0.0);   // rem - spc == rem + (-spc) exactly
     const int lim3 = K.n_units * T3_UNIT - 15;             // the longest block the units of the launch hold
-    const int bias_hi = ((lane & 31) == 0) ? 0x43380000 : 0;   // (see the PLL wave)
     double unfix = 1.0 / (K.uns != 0 ? T3_FIX * 0.5 : T3_FIX);
     T2_PIN(unfix);
     const bool mine = (lane & 31) < P;
@@ -1505,7 +1445,7 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
         // lanes 0..31 follow the early arm, lanes 32..63 the late one: gp1 the I sums (words 2 | 4), gp2 the Q sums (3 | 5)
         const unsigned long long* gp1 = xbase + (((par * 3 + 1 + (lane >> 5)) * T3_XLINE + (lane & 31)) << 1);   // 16 bytes: I and Q
         const unsigned long long* gp2 = gp1 + 1;
-        const unsigned long long tag = (unsigned long long)((unsigned)(it + 1) & 0xFFFFu);
+        const unsigned tag = (unsigned)(it + 1) & 0xFFu;
         unsigned long long x1 = 0, x2 = 0, xa = 0;
         int budget = T2_POLL_BUDGET;
         bool gave_up = false;
@@ -1530,7 +1470,7 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
                 x1 = __hip_atomic_load(gp1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 x2 = __hip_atomic_load(gp2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (__all(!mine || ((x1 >> 48) == tag && (x2 >> 48) == tag))) break;
+            if (__all(!mine || (((unsigned)x1 & 0xFFu) == tag && ((unsigned)x2 & 0xFFu) == tag))) break;
             if ((--budget & 15) == 0) {
                 xa = __hip_atomic_load(xabort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (xa != 0 || budget == 0) {
@@ -1547,17 +1487,8 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
         T3_TL(T3_TL_DLL, tl_on, 5, 2);   // sums found
         // T8 DLL (tracking.py:238-251).  Integer sums over the units (exact, order-free; lanes that poll nothing hold 0):
         // row 1 then holds the early arm's I (q1) and Q (q2), row 3 the late arm's; the two envelopes are ONE register
-#ifdef T3_SUM64   // (the round-4 form: two 64-bit chains, add + add-with-carry per step)
-        unsigned long long q1 = ((unsigned long long)(unsigned)((int)(short)(unsigned short)(x1 >> 32) + bias_hi) << 32) | (unsigned)x1;
-        unsigned long long q2 = ((unsigned long long)(unsigned)((int)(short)(unsigned short)(x2 >> 32) + bias_hi) << 32) | (unsigned)x2;
-        t3_reduce2_half(q1, q2);
-        const double vi = __longlong_as_double((long long)q1) - T2_MAGIC;   // row 1: I_E, row 3: I_L (in units of the fixed
-        const double vq = __longlong_as_double((long long)q2) - T2_MAGIC;   // row 1: Q_E, row 3: Q_L  point: the discriminator is a ratio)
-#else
-        (void)bias_hi;
         double vi, vq;                       // row 1: I_E, Q_E; row 3: I_L, Q_L (in units of the fixed point)
         t3_sum48_half2(x1, x2, vi, vq);
-#endif
         const double m2 = __builtin_fma(vq, vq, vi * vi);   // row 1: I_E^2 + Q_E^2, row 3: I_L^2 + Q_L^2
         const double mm = sgx_sqrt1_pos(m2);                // (two zero envelopes: NaN, as in the reference)
         const double mE = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mm), 16),

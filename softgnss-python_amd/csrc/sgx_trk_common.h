@@ -59,12 +59,7 @@ struct TrkConst {
     double fscale;        // float records on the typed kernel (sgx_trk2.hip): the power of two the samples are scaled by
 };
 
-struct TrkChan {
-    double acquiredFreq;
-    long long pos0;   // record index of the channel's first sample
-    int prn;          // 1-based, 0 = off
-    int pad;          // two-byte samples: byte shift (0 / 1) of the channel's sample grid in the record; else 0
-};
+// (struct TrkChan: sgx_internal.h - the device-side preRun of sgx_acq.hip fills it too)
 
 // Per-block parameters: code part written by wave 1, carrier part by wave 0, read by everybody.
 struct TrkBlock {
@@ -267,7 +262,6 @@ __device__ __forceinline__ void granule_store(unsigned long long* p, unsigned lo
 // once per several hundred blocks and not once per block.
 #define TRK_ERR_STREAM 0x40000000   // error word: the watermark of a streaming record did not advance in time
 #define TRK_ERR_RANGE 0x20000000    // error word: a block is longer than the units the launch provides
-#define TRK_ERR_SCALE 0x10000000    // error word: sums beyond the room of the speculative kernel's finer fixed point (sgx_trk3.hip)
 
 __device__ __forceinline__ void wait_mark(const unsigned long long* mark, long long need, unsigned long long& seen,
                                           int* err, int ch) {

@@ -23,13 +23,19 @@ class Result(object):
     def settings(self):
         return self._settings
 
+    def _materialize(self):
+        """Hook of the subclasses: results that are still queued on the GPU, or not yet packed into record arrays, are
+        brought in before anybody looks (the reference computes everything eagerly; so does this class by default)."""
+
     @property
     def channels(self):
+        self._materialize()
         assert isinstance(self._channels, np.recarray)
         return self._channels
 
     @property
     def results(self):
+        self._materialize()
         assert isinstance(self._results, np.recarray)
         return self._results
 
@@ -210,7 +216,7 @@ class Settings(object):
             trackResults.track(fid)
             self.lastTrackingSeconds = (datetime.datetime.now() - start).total_seconds()
             print('   Tracking is over (elapsed time %s s)' % self.lastTrackingSeconds)
-        if trackResults._results is None:
+        if not trackResults.has_results():   # (the reference's short-read exit: results were not set, tracking.py:159-163)
             return acqResults, trackResults, None
         print('   Calculating navigation solutions...')
         navResults = postNavigation.NavigationResult(trackResults)

@@ -97,6 +97,10 @@ def acquire_sharded(acq, long_signal, rank, world, gather, n_prn=None, n_blocks=
         n_prn = len(settings.acqSatelliteList)
     mine = list(plan_shards(n_prn, world)[rank])
     slots = -(-n_prn // world)
+    if world == 1:
+        # nothing to gather: the single-GPU call itself (a deferred AcquisitionResult stays queued)
+        acq.acquire(long_signal, n_blocks=n_blocks, noncoh=noncoh, prn_indices=mine)
+        return acq
     if mine:
         acq.acquire(long_signal, n_blocks=n_blocks, noncoh=noncoh, prn_indices=mine)
         res = dict(carrFreq=acq.carrFreq[mine], codePhase=acq.codePhase[mine], peakMetric=acq.peakMetric[mine],

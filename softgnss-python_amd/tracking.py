@@ -27,11 +27,35 @@ class TrackingResult(Result):
         kernel has finished; the GPU is never synchronised every 50 ms to print."""
         self._verbose = verbose
         self._results = None
-        self._channels = acqResult.channels
+        self._acq = acqResult
+        # (a deferred acquisition whose preRun is still to run on the device: the table arrives with the tracking results)
+        self._channels = None if getattr(acqResult, "_prerun_pending", False) else acqResult.channels
         self._settings = acqResult.settings
         self._device = device
+        self._lazy = None           # (series, active channel numbers): .results is packed on first access
+        self.chained = False        # the last track() ran preRun on the device behind a deferred acquisition
         self.series = None          # float64[n_active, 13, ms] in _native.SERIES order
         self.kernel_ms = None       # HIP-event duration of the tracking kernel
+
+    def has_results(self):
+        """False after the reference's short-read exit (tracking.py:159-163 leaves the results unset) and before track()."""
+        return self._results is not None or self._lazy is not None
+
+    def _materialize(self):
+        if self._channels is None and self._acq is not None:
+            self._channels = self._acq.channels
+        if self._lazy is not None:
+            series, active = self._lazy
+            self._lazy = None
+            channel = self._channels
+            # reference tracking.py:280-294: one record per ACTIVE channel, each series an object field
+            res = np.recarray((len(active),), dtype=RESULT_DTYPE)
+            for j, i in enumerate(active):
+                res[j].status = channel[i].status
+                res[j].PRN = int(channel[i].PRN)
+                for k, name in enumerate(_native.SERIES):
+                    res[j][name] = series[j, k]
+            self._results = res
 
     def _data_type(self):
         """Settings.dataType -> (sgx_track_ex data_type, bytes per sample).  The reference reads np.fromfile(fid,
@@ -77,11 +101,19 @@ class TrackingResult(Result):
         On a short record the reference prints a message, closes fid and returns None without
         setting results (tracking.py:159-163); so does this method.
         """
-        channel = self._channels
         settings = self._settings
         ctx = engine.get_context(settings, self._device)
         ms = int(settings.msToProcess)            # float in the reference (Q9)
         nch = int(settings.numberOfChannels)
+        self._lazy = None
+        self._results = None
+        self.series = None
+        self.chained = False
+        if self._channels is None and self._try_chained(fid, ctx, nch, ms):
+            return
+        if self._channels is None:
+            self._channels = self._acq.channels   # (the queued sequence did not apply: the search is looked at, preRun runs here)
+        channel = self._channels
         active = [i for i in range(nch) if channel[i].PRN != 0]
         if not active:
             self._results = np.recarray((0,), dtype=RESULT_DTYPE)
@@ -122,14 +154,43 @@ class TrackingResult(Result):
                           '; Completed %d' % k + ' of %d' % ms + ' msec')
         fid.seek(int(series[-1, 0, ms - 1]), 0)    # where the reference's last read left the file
         self.series = series
-        res = np.recarray((len(active),), dtype=RESULT_DTYPE)
-        for j, i in enumerate(active):
-            res[j].status = channel[i].status
-            res[j].PRN = int(channel[i].PRN)
-            for k, name in enumerate(_native.SERIES):
-                res[j][name] = series[j, k]
-        self._results = res
+        self._lazy = (series, active)              # the record array of object fields is packed on first access of .results
         return
+
+    def _try_chained(self, fid, ctx, nch, ms):
+        """A deferred acquisition + preRun are pending on this context and the record is resident: preRun runs on the
+        device, the tracking kernel behind it, and the host waits once (sgx_track_chained).  False: not applicable -
+        the eager sequence follows."""
+        acq = self._acq
+        pend = getattr(acq, "_pending", None)
+        if not (isinstance(fid, DeviceFile) and pend is not None and pend[0] is ctx and getattr(acq, "_prerun_pending", False)
+                and getattr(ctx, "_acq_token", None) == pend[2] and not self._verbose and 1 <= nch <= 32):
+            return False
+        try:
+            dtype_code, isz = self._data_type()
+        except TypeError:
+            return False
+        got = ctx.track_chained(fid.record, nch, ms, rec_file_offset=fid.file_offset, data_type=dtype_code)
+        if got is None:
+            return False
+        out, done, prn, freq, cph, n_act = got
+        self.chained = True
+        self.kernel_ms = ctx.timing()["track_ms"]
+        acq._channels_from_table(prn, freq, cph, n_act)   # what preRun made, on the device
+        self._channels = acq._channels
+        if n_act == 0:
+            self._results = np.recarray((0,), dtype=RESULT_DTYPE)
+            self.series = np.empty((0, _native.NUM_SERIES, ms))
+            return True
+        if np.any(done[:n_act] != ms):
+            print('Not able to read the specified number of samples for tracking, exiting!')
+            fid.close()
+            return True
+        series = out[:n_act]
+        fid.seek(int(series[-1, 0, ms - 1]), 0)
+        self.series = series
+        self._lazy = (series, list(range(n_act)))
+        return True
 
     def plot(self):
         """One figure per tracked channel: discrete-time scatter, navigation bits, raw and filtered discriminators,

@@ -1907,3 +1907,100 @@ def test_acquire_accepts_any_real_valued_signal(default_record):
         assert np.allclose(b.peakMetric[:12], want["peakMetric"][:12], rtol=1e-9, atol=0)
     with pytest.raises(TypeError):
         m.AcquisitionResult(s, device=0).acquire(x8.astype(np.complex128))
+
+
+def _step(m, s, rec, ms, deferred):
+    n = s.samplesPerCode
+    a = m.AcquisitionResult(s, device=0, deferred=deferred)
+    a.acquire(m.DeviceSignal(rec, 0, 11 * n))
+    a.preRun()
+    t = m.TrackingResult(a, device=0)
+    fid = m.DeviceFile(rec)
+    t.track(fid)
+    return a, t, fid
+
+
+def test_deferred_step_equals_the_eager_one(default_record):
+    """acquire -> preRun -> track queued without a look in between (sgx_acquire_begin / sgx_track_chained: preRun on the
+    device, one wait) against the eager calls: every result bit for bit, 8 channels and a table with channels off."""
+    m = pkg()
+    for nch, ms in ((8, 300), (12, 120)):
+        s = m.Settings()
+        s.numberOfChannels = nch
+        s.msToProcess = float(ms)
+        ctx = m.engine.get_context(s, 0)
+        rec = ctx.upload(default_record)
+        ae, te, fe = _step(m, s, rec, ms, False)
+        ad, td, fd = _step(m, s, rec, ms, True)
+        assert td.chained and not te.chained
+        assert ad._pending is not None           # tracking is done and nobody has looked at the search yet
+        assert np.array_equal(td.series, te.series)
+        assert fd.tell() == fe.tell()
+        for f in ("carrFreq", "codePhase", "peakMetric"):
+            assert np.array_equal(ad.results[f], ae.results[f]), f
+        assert ad._pending is None
+        for f in ("freqBin", "fineIdx"):
+            assert np.array_equal(ad.internals[f], ae.internals[f]), f
+        for f in ("PRN", "acquiredFreq", "codePhase", "status"):
+            assert np.array_equal(ad.channels[f], ae.channels[f]), f
+        assert ad.channels.PRN.dtype == ae.channels.PRN.dtype
+        assert len(td.results) == len(te.results) == int(np.sum(ae.channels.PRN != 0))
+        for name in td.results.dtype.names:
+            for j in range(len(te.results)):
+                assert np.array_equal(td.results[j][name], te.results[j][name]), name
+        rec.free()
+
+
+def test_deferred_results_looked_at_early_and_superseded(default_record):
+    """A deferred search somebody looks at before tracking simply becomes an eager one; one search is pending per context."""
+    m = pkg()
+    s = m.Settings()
+    s.msToProcess = 60.0
+    ctx = m.engine.get_context(s, 0)
+    rec = ctx.upload(default_record)
+    n = s.samplesPerCode
+    want = m.AcquisitionResult(s, device=0)
+    want.acquire(m.DeviceSignal(rec, 0, 11 * n))
+    want.preRun()
+    a = m.AcquisitionResult(s, device=0, deferred=True)
+    a.acquire(m.DeviceSignal(rec, 0, 11 * n))
+    assert np.array_equal(a.peakMetric, want.peakMetric) and a._pending is None     # the look
+    a.preRun()
+    assert np.array_equal(a.channels.PRN, want.channels.PRN)
+    t = m.TrackingResult(a, device=0)
+    t.track(m.DeviceFile(rec))
+    assert not t.chained and len(t.results) == 8
+    # preRun() asked for while queued, channels looked at before tracking: the host's preRun
+    b = m.AcquisitionResult(s, device=0, deferred=True)
+    b.acquire(m.DeviceSignal(rec, 0, 11 * n))
+    b.preRun()
+    assert b._prerun_pending
+    assert np.array_equal(b.channels.acquiredFreq, want.channels.acquiredFreq) and not b._prerun_pending
+    # two deferred searches on one context: the first one's owner is told
+    c1 = m.AcquisitionResult(s, device=0, deferred=True)
+    c1.acquire(m.DeviceSignal(rec, 0, 11 * n))
+    c2 = m.AcquisitionResult(s, device=0, deferred=True)
+    c2.acquire(m.DeviceSignal(rec, 0, 11 * n))
+    with pytest.raises(RuntimeError):
+        c1.results
+    assert np.array_equal(c2.carrFreq, want.carrFreq)
+    rec.free()
+
+
+def test_deferred_search_raises_the_references_index_error_at_the_first_look():
+    g = load_golden("acq_edges.npz")
+    m = pkg()
+    s = m.Settings()
+    s.acqSatelliteList = [1]
+    s.msToProcess = 20.0
+    ctx = m.engine.get_context(s, 0)
+    i = [k for k in range(len(g["phases"])) if str(g["err"][k]) == "IndexError"][0]
+    x = m.synth.generate(scene_from_json(g["scenes"][i]), 40 * s.samplesPerCode)
+    rec = ctx.upload(x)
+    a = m.AcquisitionResult(s, device=0, deferred=True)
+    a.acquire(m.DeviceSignal(rec, 0, 11 * s.samplesPerCode))      # queued: nothing raised yet
+    a.preRun()
+    t = m.TrackingResult(a, device=0)
+    with pytest.raises(IndexError):
+        t.track(m.DeviceFile(rec))                                 # the device found no channel table to make: the look raises
+    rec.free()

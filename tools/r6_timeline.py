@@ -17,6 +17,8 @@ for e in range(1, 7):
         continue
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "step_profile.py"), "37000"], env=dict(os.environ, SGX_LIB=lib),
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode()
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    open(os.path.join(ROOT, "gpurun_out", "r06_timeline_raw_tl%d.txt" % e), "w").write(out)
     T = {}
     for m in pat.finditer(out):
         T[(int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(4)))] = float(m.group(5))
@@ -52,6 +54,7 @@ for par in (0, 1):
                 v = res.get((role, ev, par, kind))
                 if not v:
                     continue
+                v = [x for x in v if abs(x[2]) < 1e5]   # (a printf line cut short by another workgroup's)
                 a = np.array([x[2] for x in v if x[0] != 0])
                 a0 = np.array([x[2] for x in v if x[0] == 0])
                 label = ("map waves, final pass" if kind == "final" else "map waves, the other set") if role == "map" else role + " wave"
