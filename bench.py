@@ -476,7 +476,24 @@ def main():
                         ae.acquire(sig4, n_blocks=10, noncoh=True, prn_indices=prns)
                         ts.append(ctx.timing()["acquire_ms"])
                     worst = max(worst, min(ts))
+                # ... and the same shards END TO END through shard.acquire_sharded as a rank calls it (sgx_acquire_sharded
+                # without a communicator: search, device-side pack, publish, one look, merge), wall clock, mean of 5 calls
+                worst_wall = 0.0
+                lg = shard.LocalGather()
+                for rk in range(8):
+                    acq4(rk, 8, lg)
+                    device_sync()
+                    t0 = time.perf_counter()
+                    for _ in range(5):
+                        acq4(rk, 8, lg)
+                    device_sync()
+                    worst_wall = max(worst_wall, (time.perf_counter() - t0) / 5 * 1e3)
                 emu = {"emulated_8rank_ms": worst, "emulated_speedup": dev_one / worst,
+                       "emulated_wall_ms": worst_wall, "emulated_wall_speedup": t_one / (worst_wall + 0.03),
+                       "emulated_wall_note": "wall clock of the slowest 4-PRN shard through shard.acquire_sharded (one library "
+                                             "call: search, pack on the device, one look, merge) against ms_n1, the wall clock "
+                                             "of the whole search on this GPU; + 0.03 ms for the ncclAllGather of 160 bytes "
+                                             "per rank, which no single GPU can run",
                        # what a rank spends beyond an eighth of the one-GPU search: the part that does not shard
                        "emulated_remainder_us": (worst - dev_one / 8.0) * 1e3,
                        "emulated_note": "device time of the slowest 4-PRN shard of an 8-rank run, timed on this one GPU, against "

@@ -373,6 +373,18 @@ int sgx_post_navigate(const double* absoluteSample, int32_t n_rows, int32_t ms, 
 int sgx_comm_unique_id(uint8_t id[128]);
 int sgx_comm_create(sgx_ctx* c, int32_t n_ranks, int32_t rank, const uint8_t id[128], sgx_comm** out);
 int sgx_comm_allgather(sgx_comm* m, const void* send, void* recv, size_t bytes);
+
+/* The sharded search as ONE call (round 6; BASELINE configs[3]: acquisition.py:92 is the loop that shards, :135-193 do not
+ * shrink).  Rank `rank` of `world` searches its contiguous, balanced share of PRN indices 0 .. n_prn_total-1 (the partition
+ * of softgnss-python_amd/shard.py: plan_shards); its peaks are packed into 40-byte records on the device behind the search,
+ * ONE ncclAllGather on the context's stream gathers every rank's, a small kernel copies them to a pinned page and the host
+ * looks once.  Outputs: the merged 32-entry arrays of acquisition.py:201-203 plus frequencyBinIndex / fftMaxIndex (-1 where
+ * not detected), identical on every rank.  comm NULL: no collective - world 1, or one rank's shard run alone (what one
+ * rank of an N-GPU run executes, for timing; only its own PRNs are filled in).  A rank whose search fails the way the
+ * reference's acquire() raises (SGX_E_INDEX / SGX_E_RANGE) marks its record and EVERY rank returns that error. */
+int sgx_acquire_sharded(sgx_ctx* c, sgx_comm* comm, int32_t rank, int32_t world, const sgx_if* r, size_t offset,
+                        size_t n_samples, int32_t n_prn_total, int32_t n_blocks, int32_t noncoh,
+                        double* carrFreq, double* codePhase, double* peakMetric, int32_t* freqBin, int32_t* fineIdx);
 int sgx_comm_destroy(sgx_comm* m);
 
 #ifdef __cplusplus

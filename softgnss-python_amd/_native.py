@@ -122,6 +122,8 @@ _PROTOS = {
     "sgx_comm_create": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.POINTER(_P)]),
     "sgx_comm_allgather": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "sgx_comm_destroy": (C.c_int, [_P]),
+    "sgx_acquire_sharded": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_size_t, C.c_size_t, C.c_int32, C.c_int32,
+                                      C.c_int32, _P, _P, _P, _P, _P]),
 }
 SYMBOLS = tuple(sorted(_PROTOS))
 
@@ -405,6 +407,19 @@ class Context(object):
             return None
         check(rc)
         return out, done, prn, freq, cph, n_act.value
+
+    def acquire_sharded(self, comm, rank, world, rec, offset, n_samples, n_prn_total=32, n_blocks=2, noncoh=False):
+        """This rank's share of the PRN search + the peak gather as ONE library call (sgx_acquire_sharded): packed on the
+        device, one ncclAllGather (comm: a Comm, or None for no collective), one look.  Returns the merged 32-entry arrays."""
+        carr = np.zeros(32)
+        cph = np.zeros(32)
+        met = np.zeros(32)
+        fb = np.zeros(32, dtype=np.int32)
+        fi = np.zeros(32, dtype=np.int32)
+        check(lib().sgx_acquire_sharded(self._h, comm._h if comm is not None else None, int(rank), int(world), rec._h,
+                                        int(offset), int(n_samples), int(n_prn_total), int(n_blocks), 1 if noncoh else 0,
+                                        _ptr(carr), _ptr(cph), _ptr(met), _ptr(fb), _ptr(fi)))
+        return dict(carrFreq=carr, codePhase=cph, peakMetric=met, freqBin=fb.astype(np.int64), fineIdx=fi.astype(np.int64))
 
     def acquire_f64(self, signal, prn0, n_blocks=2, noncoh=False):
         """acquire() on a host signal of any real dtype (copied to HBM as fp64)."""

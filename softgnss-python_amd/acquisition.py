@@ -116,6 +116,14 @@ class AcquisitionResult(Result):
         self._fill(prn_indices, r)
         return
 
+    def _fill32(self, r):
+        """The merged 32-entry arrays of a sharded search (sgx_acquire_sharded) as this object's results."""
+        self._pending = None
+        self._prerun_pending = False
+        self._internals = dict(freqBin=r["freqBin"], fineIdx=r["fineIdx"])
+        self._results = np.rec.fromarrays([r["carrFreq"], r["codePhase"], r["peakMetric"]],
+                                          names='carrFreq,codePhase,peakMetric')
+
     def _fill(self, prn_indices, r):
         """The reference's three 32-entry result arrays (acquisition.py:201-203) from the library's per-PRN outputs."""
         carrFreq = np.zeros(32)

@@ -1841,3 +1841,177 @@ extern "C" int sgx_acquire_end(sgx_ctx* c, double* carrFreq, double* codePhase, 
     SGX_HIP(hipSetDevice(c->device));
     return sgx_acquire_finish(c, carrFreq, codePhase, peakMetric, freqBin, fineIdx);
 }
+
+
+// ================================ round 6: the sharded search as ONE call ================================
+// BASELINE configs[3]: the PRN loop (acquisition.py:92) shards over the ranks, the peaks are gathered.  Rounds 1-5 did the
+// pack, the gather and the merge in Python around sgx_acquire (softgnss-python_amd/shard.py): 0.17-0.28 ms of host time per
+// call next to a 0.45 ms shard.  Here the rank's search is queued, its peaks are packed into 40-byte records ON THE DEVICE
+// behind it, one ncclAllGather follows on the same stream, a small kernel copies the gathered records to the result page and
+// the host looks ONCE; the merge into the 32-entry arrays is a loop over at most 32 records.
+struct PeakRec {      // = shard.PEAK_DTYPE, 40 bytes
+    int prn0, freqBin;
+    double carrFreq, codePhase, peakMetric;
+    int fineIdx, valid;   // valid 1; 0 unused slot; -1 the reference's IndexError at this PRN; -2 its fine window leaves the record
+};
+static_assert(sizeof(PeakRec) == 40, "shard.PEAK_DTYPE");
+
+__global__ __launch_bounds__(64) void acq_pack_kernel(const CoarseLook* __restrict__ stage, const long long* __restrict__ fine_bi,
+                                                      const int* __restrict__ prn_list, int n_prn, double fs, double npts,
+                                                      PeakRec* __restrict__ out, int slots) {
+    const int t = threadIdx.x;
+    if (t >= slots) return;
+    PeakRec r;
+    r.prn0 = 0; r.freqBin = -1; r.carrFreq = 0.0; r.codePhase = 0.0; r.peakMetric = 0.0; r.fineIdx = -1; r.valid = 0;
+    if (t < n_prn) {
+        r.prn0 = prn_list[t];
+        r.freqBin = stage->po.fbi[t];
+        r.peakMetric = stage->po.peak[t] / stage->second[t];
+        r.valid = stage->po.index_error[t] ? -1 : 1;
+        if (stage->range_error == 1 + t) r.valid = -2;
+        if (r.valid < 0) r.codePhase = (double)stage->po.cph[t];   // (for the error text)
+        const int n_det = stage->n_det;
+        for (int d = 0; d < n_det; ++d)
+            if (stage->det_slot[d] == t && r.valid == 1 && stage->range_error == 0) {
+                const long long m = fine_bi[d] - 4;
+                r.carrFreq = ((double)m * fs) / npts;
+                r.codePhase = (double)stage->det_phase[d];
+                r.fineIdx = (int)m;
+            }
+    }
+    out[t] = r;
+}
+
+// gathered records -> the result page (its upper half), then the word the host spins on
+__global__ __launch_bounds__(256) void acq_gather_publish_kernel(const int* __restrict__ src, int n_words, int* __restrict__ dst,
+                                                                 unsigned long long* __restrict__ word, unsigned long long seq) {
+    for (int i = threadIdx.x; i < n_words; i += 256) dst[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+extern "C" int sgx_acquire_sharded(sgx_ctx* c, sgx_comm* comm, int32_t rank, int32_t world, const sgx_if* r, size_t offset,
+                                   size_t n_samples, int32_t n_prn_total, int32_t n_blocks, int32_t noncoh, double* carrFreq,
+                                   double* codePhase, double* peakMetric, int32_t* freqBin, int32_t* fineIdx) {
+    SGX_CHECK_ARG(c && r && carrFreq && codePhase && peakMetric && freqBin && fineIdx);
+    SGX_CHECK_ARG(world >= 1 && rank >= 0 && rank < world && n_prn_total >= 1 && n_prn_total <= 32);
+    SGX_CHECK_ARG(!comm || (comm->n_ranks == world && comm->rank == rank && comm->ctx == c));
+    for (int i = 0; i < 32; ++i) {
+        carrFreq[i] = 0.0;
+        codePhase[i] = 0.0;
+        peakMetric[i] = 0.0;
+        freqBin[i] = -1;
+        fineIdx[i] = -1;
+    }
+    // contiguous balanced partition (shard.plan_shards)
+    const int base = n_prn_total / world, extra = n_prn_total % world;
+    const int first = rank * base + (rank < extra ? rank : extra);
+    const int n_mine = base + (rank < extra ? 1 : 0);
+    const int slots = (n_prn_total + world - 1) / world;
+    int32_t prn0[32];
+    for (int i = 0; i < n_mine; ++i) prn0[i] = first + i;
+    SGX_HIP(hipSetDevice(c->device));
+    const size_t rec_bytes = sizeof(PeakRec) * (size_t)slots;
+    // where the packed records go: the communicator's send buffer, or (no communicator: one rank, or a shard run alone)
+    // the context's small device area
+    char* dsm = (char*)c->d_small;
+    PeakRec* d_send = comm ? (PeakRec*)comm->d_send : (PeakRec*)(dsm + 720000);
+    const PeakRec* d_all = comm ? (const PeakRec*)comm->d_recv : d_send;
+    const int n_ranks_seen = comm ? world : 1;
+    std::vector<PeakRec> host_pack;      // a search that could not be queued: packed on the host
+    bool queued = false;
+    if (n_mine > 0) {
+        const int rb = sgx_acquire_begin(c, r, offset, n_samples, prn0, n_mine, n_blocks, noncoh);
+        if (rb != SGX_OK) return rb;
+        queued = c->acq_pending.mode == 1;
+        if (!queued) {
+            double cf[32], cp[32], pm[32];
+            int fb[32], fi[32];
+            const int re = sgx_acquire_finish(c, cf, cp, pm, fb, fi);
+            if (re != SGX_OK && re != SGX_E_INDEX && re != SGX_E_RANGE) return re;
+            host_pack.resize((size_t)slots);
+            memset(host_pack.data(), 0, rec_bytes);
+            for (int i = 0; i < n_mine; ++i) {
+                PeakRec& q = host_pack[(size_t)i];
+                q.prn0 = prn0[i]; q.freqBin = fb[i]; q.carrFreq = cf[i]; q.codePhase = cp[i]; q.peakMetric = pm[i];
+                q.fineIdx = fi[i]; q.valid = 1;
+            }
+            if (re != SGX_OK) host_pack[0].valid = re == SGX_E_INDEX ? -1 : -2;   // (every rank learns of it)
+        }
+    }
+    hipStream_t st = c->stream;
+    if (queued) {
+        const AcqPending& P = c->acq_pending;
+        acq_pack_kernel<<<1, 64, 0, st>>>((const CoarseLook*)(dsm + 700000), ((const CoarseLook*)c->d_look)->fine_bi,
+                                          (const int*)(dsm + 64), P.n_prn, c->s.samplingFreq, (double)P.npts, d_send, slots);
+    } else {
+        if (host_pack.empty()) {
+            host_pack.resize((size_t)slots);
+            memset(host_pack.data(), 0, rec_bytes);
+        }
+        SGX_HIP(hipMemcpyAsync(d_send, host_pack.data(), rec_bytes, hipMemcpyHostToDevice, st));
+    }
+    if (comm) {
+        const int rg = sgx_comm_allgather_device(comm, rec_bytes);
+        if (rg != SGX_OK) return rg;
+    }
+    const size_t all_bytes = rec_bytes * (size_t)n_ranks_seen;
+    if (all_bytes > SGX_LOOK_BYTES - SGX_GATHER_LOOK_OFFSET - 16) {
+        sgx_set_error("sgx_acquire_sharded: %d ranks x %d slots do not fit the result page", world, slots);
+        return SGX_E_ARG;
+    }
+    const unsigned long long seq = ++c->look_seq;
+    char* page_d = (char*)c->d_look + SGX_GATHER_LOOK_OFFSET;
+    const char* page_h = (const char*)c->h_look + SGX_GATHER_LOOK_OFFSET;
+    acq_gather_publish_kernel<<<1, 256, 0, st>>>((const int*)d_all, (int)(all_bytes / 4), (int*)(page_d + 16),
+                                                 (unsigned long long*)page_d, seq);
+    SGX_HIP(hipGetLastError());
+    {   // the one look
+        const unsigned long long* word = (const unsigned long long*)page_h;
+        const auto t0 = std::chrono::steady_clock::now();
+        bool seen = false;
+        for (unsigned it = 0; !seen; ++it) {
+            if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) seen = true;
+            else if ((it & 1023u) == 1023u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.05) break;
+        }
+        if (!seen) {
+            SGX_HIP(hipStreamSynchronize(st));
+            if (__atomic_load_n(word, __ATOMIC_ACQUIRE) != seq) {
+                sgx_set_error("sharded acquisition: the gathered peaks were not written");
+                return SGX_E_HIP;
+            }
+        }
+    }
+    if (queued) {   // (device time of this rank's search; the search's own page is complete: the gather came behind it)
+        c->acq_pending.mode = 0;
+        SGX_HIP(hipEventSynchronize(c->ev[2]));
+        hipEventElapsedTime(&c->timing.acquire_ms, c->ev[0], c->ev[2]);
+        c->timing.acq_coarse_ms = __builtin_nanf("");
+        c->timing.acq_fine_ms = __builtin_nanf("");
+    }
+    const PeakRec* all = (const PeakRec*)(page_h + 16);
+    const int n_rec = slots * n_ranks_seen;
+    for (int i = 0; i < n_rec; ++i) {
+        const PeakRec& q = all[i];
+        if (q.valid == 0) continue;
+        if (q.valid == -1) {
+            sgx_set_error("IndexError: index %lld is out of bounds for axis 1 with size %lld "
+                          "(PRN index %d, codePhase %d; reference acquisition.py:152-162)",
+                          (long long)c->n_code, (long long)c->n_code, q.prn0, (int)q.codePhase);
+            return SGX_E_INDEX;
+        }
+        if (q.valid == -2) {
+            sgx_set_error("fine search needs codePhase + 10 ms = %lld samples, record window has %zu "
+                          "(reference acquisition.py:177 would fail to broadcast)", (long long)q.codePhase + 10 * c->n_code, n_samples);
+            return SGX_E_RANGE;
+        }
+        if (q.prn0 < 0 || q.prn0 >= 32) continue;
+        carrFreq[q.prn0] = q.carrFreq;
+        codePhase[q.prn0] = q.codePhase;
+        peakMetric[q.prn0] = q.peakMetric;
+        freqBin[q.prn0] = q.freqBin;
+        fineIdx[q.prn0] = q.fineIdx;
+    }
+    return SGX_OK;
+}

@@ -157,8 +157,8 @@ static int ctx_build(sgx_ctx* c, int priority) {
     SGX_HIP(hipMemcpy(c->d_codes, codes.data(), codes.size(), hipMemcpyHostToDevice));
     SGX_HIP(hipMalloc(&c->d_small, 1 << 20));
     SGX_HIP(hipHostMalloc(&c->h_small, 1 << 20, hipHostMallocDefault));
-    SGX_HIP(hipHostMalloc(&c->h_look, 4096, hipHostMallocCoherent | hipHostMallocMapped));
-    memset(c->h_look, 0, 4096);
+    SGX_HIP(hipHostMalloc(&c->h_look, SGX_LOOK_BYTES, hipHostMallocCoherent | hipHostMallocMapped));
+    memset(c->h_look, 0, SGX_LOOK_BYTES);
     SGX_HIP(hipHostGetDevicePointer(&c->d_look, c->h_look, 0));
     return SGX_OK;
 }
@@ -795,14 +795,7 @@ static int rccl_load() {
     return SGX_OK;
 }
 
-struct sgx_comm {
-    sgx_ctx* ctx;
-    void* comm;
-    int n_ranks, rank;
-    void* d_send;
-    void* d_recv;
-    size_t cap;
-};
+// (struct sgx_comm: sgx_internal.h)
 
 static int rccl_fail(const char* what, int code) {
     sgx_set_error("%s failed: %s", what, g_rccl.errstr ? g_rccl.errstr(code) : "rccl error");
@@ -852,6 +845,18 @@ extern "C" int sgx_comm_allgather(sgx_comm* m, const void* send, void* recv, siz
     if (e != 0) return rccl_fail("ncclAllGather", e);
     SGX_HIP(hipMemcpyAsync(recv, m->d_recv, bytes * (size_t)m->n_ranks, hipMemcpyDeviceToHost, c->stream));
     SGX_HIP(hipStreamSynchronize(c->stream));
+    return SGX_OK;
+}
+
+// ncclAllGather of `bytes` per rank from m->d_send into m->d_recv on the context's stream; nothing is copied or waited for
+// (sgx_acquire_sharded packs and unpacks on the device)
+int sgx_comm_allgather_device(sgx_comm* m, size_t bytes) {
+    if (!m || bytes == 0 || bytes > m->cap) {
+        sgx_set_error("sgx_comm_allgather_device: %zu bytes per rank, room for %zu", bytes, m ? m->cap : (size_t)0);
+        return SGX_E_ARG;
+    }
+    int e = g_rccl.allgather(m->d_send, m->d_recv, bytes, /*ncclInt8*/ 0, m->comm, m->ctx->stream);
+    if (e != 0) return rccl_fail("ncclAllGather", e);
     return SGX_OK;
 }
 

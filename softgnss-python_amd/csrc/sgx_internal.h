@@ -104,6 +104,10 @@ struct StepLook {
 };
 static_assert(sizeof(StepLook) <= 2048, "upper half of the result page");
 #define SGX_STEP_LOOK_OFFSET 2048
+// the result "page" is two pages: [0, 2048) the search's CoarseLook, [2048, 4096) StepLook, [4096, 8192) the gathered peak
+// records of sgx_acquire_sharded behind the word the host spins on
+#define SGX_GATHER_LOOK_OFFSET 4096
+#define SGX_LOOK_BYTES 8192
 
 struct sgx_ctx {
     sgx_settings s;
@@ -236,5 +240,16 @@ struct TrkChan {      // one channel as the tracking kernels read it
 int sgx_prerun_enqueue(sgx_ctx* c, TrkChan* d_ch, int n_ch, long long skip_bytes, long long rec_file_offset, int sample_bytes);
 // Wait for a deferred acquisition and decode it (the tail of the eager call); clears c->acq_pending.
 int sgx_acquire_finish(sgx_ctx* c, double* carrFreq, double* codePhase, double* peakMetric, int32_t* freqBin, int32_t* fineIdx);
+
+// sgx_host.cpp: the RCCL communicator of a context (librccl.so by dlopen)
+struct sgx_comm {
+    sgx_ctx* ctx;
+    void* comm;
+    int n_ranks, rank;
+    void* d_send;
+    void* d_recv;
+    size_t cap;
+};
+int sgx_comm_allgather_device(sgx_comm* m, size_t bytes);
 
 // sgx_synth.hip / sgx_acq.hip / sgx_trk.hip provide the C-ABI entry points directly.

@@ -73,14 +73,22 @@ class RcclGather(object):
     def __init__(self, comm):
         self.comm = comm
 
+    def native(self):
+        """The communicator sgx_acquire_sharded gathers with, on the device and on the search's own stream."""
+        return self.comm
+
     def allgather(self, buf):
         out = self.comm.allgather(np.ascontiguousarray(buf).view(np.uint8))
         return out.view(PEAK_DTYPE).reshape(self.comm.n_ranks, -1)
 
 
 class LocalGather(object):
-    """world == 1."""
+    """world == 1 - or ONE rank's shard of a larger world run alone (what a rank of an N-GPU run executes, without the
+    collective): only its own PRNs come back."""
     name = "local"
+
+    def native(self):
+        return None      # sgx_acquire_sharded without a communicator
 
     def allgather(self, buf):
         return np.asarray(buf).reshape(1, -1)
@@ -97,9 +105,18 @@ def acquire_sharded(acq, long_signal, rank, world, gather, n_prn=None, n_blocks=
         n_prn = len(settings.acqSatelliteList)
     mine = list(plan_shards(n_prn, world)[rank])
     slots = -(-n_prn // world)
-    if world == 1:
+    if world == 1 and not isinstance(gather, RcclGather):
         # nothing to gather: the single-GPU call itself (a deferred AcquisitionResult stays queued)
         acq.acquire(long_signal, n_blocks=n_blocks, noncoh=noncoh, prn_indices=mine)
+        return acq
+    native = getattr(gather, "native", None)
+    if native is not None and hasattr(long_signal, "record") and n_prn <= 32:
+        # ONE library call: the search queued, the peaks packed on the device, one ncclAllGather on the same stream (or none:
+        # a shard run alone), one look, the merge in C (sgx_acquire_sharded) - no Python between the kernels and the gather
+        from . import engine
+        ctx = engine.get_context(settings, acq._device)
+        acq._fill32(ctx.acquire_sharded(native(), rank, world, long_signal.record, long_signal.offset, long_signal.length,
+                                        n_prn_total=n_prn, n_blocks=n_blocks, noncoh=noncoh))
         return acq
     if mine:
         acq.acquire(long_signal, n_blocks=n_blocks, noncoh=noncoh, prn_indices=mine)

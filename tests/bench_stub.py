@@ -29,7 +29,7 @@ class _Record(object):
 
 class _Ctx(object):
     def __init__(self):
-        self._t = dict(acquire_ms=1.0, acq_coarse_ms=0.7, acq_fine_ms=0.3, track_ms=50.0, synth_ms=1.0)
+        self._t = dict(acquire_ms=1.0, acq_coarse_ms=float('nan'), acq_fine_ms=float('nan'), track_ms=50.0, synth_ms=1.0)
 
     def synth(self, scene, n):
         return _Record(n)
@@ -67,8 +67,9 @@ def DeviceFile(rec):
 
 
 class AcquisitionResult(object):
-    def __init__(self, settings, device=0):
+    def __init__(self, settings, device=0, deferred=False):
         self.settings = settings
+        self._device = device
         self.internals = None
         self.results = None
         self.searched = []
@@ -79,6 +80,9 @@ class AcquisitionResult(object):
         self.codePhase = _G["codePhase"].copy()
         self.peakMetric = _G["peakMetric"].copy()
         self.internals = dict(freqBin=_G["freqBin"].copy(), fineIdx=_G["fineIdx"].copy())
+        if prn_indices is None or len(self.searched) == 32:   # (the whole search: the real class fills in its results)
+            self.results = np.rec.fromarrays([self.carrFreq, self.codePhase, self.peakMetric],
+                                             names="carrFreq,codePhase,peakMetric")
 
     def __getattr__(self, name):
         if name in ("carrFreq", "codePhase", "peakMetric") and self.__dict__.get("results") is not None:
@@ -94,6 +98,8 @@ class AcquisitionResult(object):
 
 
 class TrackingResult(object):
+    chained = False
+
     def __init__(self, acq, device=0):
         self.acq = acq
         self.kernel_ms = 50.0

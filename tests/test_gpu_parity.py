@@ -1856,10 +1856,23 @@ def test_rccl_communicator_single_rank_roundtrip():
         a = m.AcquisitionResult(s, device=0)
         rec = ctx.synth(m.synth.Scene.default(), 11 * s.samplesPerCode)
         sig = m.DeviceSignal(rec, 0, 11 * s.samplesPerCode)
-        sh.acquire_sharded(a, sig, 0, 1, gather)
+        sh.acquire_sharded(a, sig, 0, 1, gather)      # (sgx_acquire_sharded: packed on the device, ncclAllGather, one look)
         b = m.AcquisitionResult(s, device=0)
         b.acquire(sig)
-        assert np.array_equal(a.codePhase, b.codePhase) and np.array_equal(a.carrFreq, b.carrFreq)
+        for f in ("codePhase", "carrFreq", "peakMetric"):
+            assert np.array_equal(a.results[f], b.results[f]), f
+        for f in ("freqBin", "fineIdx"):
+            assert np.array_equal(a.internals[f], b.internals[f]), f
+        # one rank's shard of a world of eight, run alone (no communicator): its own PRNs, the plain call's values
+        for rk in (0, 3, 7):
+            c = m.AcquisitionResult(s, device=0)
+            sh.acquire_sharded(c, sig, rk, 8, sh.LocalGather())
+            mine = list(sh.plan_shards(32, 8)[rk])
+            other = [p for p in range(32) if p not in mine]
+            for f in ("codePhase", "carrFreq", "peakMetric"):
+                assert np.array_equal(c.results[f][mine], b.results[f][mine]), (rk, f)
+                assert not np.any(c.results[f][other])
+            assert np.array_equal(c.internals["fineIdx"][mine], b.internals["fineIdx"][mine])
         rec.free()
     finally:
         comm.close()
