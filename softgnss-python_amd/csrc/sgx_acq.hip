@@ -1440,11 +1440,24 @@ static int acquire_four_step(sgx_ctx* c, SgxSig x, size_t n_samples, const int32
     hipStream_t st2 = st;
     if (two_q) {
         if (!c->acq_stream2) {
+            // (into locals; the context gets them only when ALL exist - a half-made second queue would fail every later call)
             int least = 0, greatest = 0;
             SGX_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            if (c->priority == 0) SGX_HIP(hipStreamCreateWithFlags(&c->acq_stream2, hipStreamNonBlocking));
-            else SGX_HIP(hipStreamCreateWithPriority(&c->acq_stream2, hipStreamNonBlocking, c->priority < 0 ? greatest : least));
-            for (int i = 0; i < 2; ++i) SGX_HIP(hipEventCreateWithFlags(&c->acq_ev2[i], hipEventDisableTiming));
+            hipStream_t ns = nullptr;
+            hipEvent_t ne[2] = {nullptr, nullptr};
+            hipError_t ce = (c->priority == 0) ? hipStreamCreateWithFlags(&ns, hipStreamNonBlocking)
+                                               : hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, c->priority < 0 ? greatest : least);
+            for (int i = 0; i < 2 && ce == hipSuccess; ++i) ce = hipEventCreateWithFlags(&ne[i], hipEventDisableTiming);
+            if (ce != hipSuccess) {
+                for (int i = 0; i < 2; ++i)
+                    if (ne[i]) hipEventDestroy(ne[i]);
+                if (ns) hipStreamDestroy(ns);
+                sgx_set_error("acquisition: the second queue could not be created: %s", hipGetErrorString(ce));
+                return SGX_E_HIP;
+            }
+            c->acq_stream2 = ns;
+            c->acq_ev2[0] = ne[0];
+            c->acq_ev2[1] = ne[1];
         }
         st2 = c->acq_stream2;
         // (the second queue's intermediate is the buffer the forward transforms read: they are queued in front)
@@ -1480,7 +1493,11 @@ static int acquire_four_step(sgx_ctx* c, SgxSig x, size_t n_samples, const int32
             fu.sum_blocks = noncoh ? n_blocks : 1;
             const int q = two_q ? (chunk_no & 1) : 0;
             rc = sgx_fft4_forward(&c->plan_code, nullptr, c->d_work[q], nullptr, (int64_t)np * fu.rows_per_prn, q ? st2 : st, &fu);
-            if (rc != SGX_OK) return rc;
+            if (rc != SGX_OK) {
+                // (the second queue may still hold chunks that write d_work[1]: nothing of the next call may overtake them)
+                if (two_q) hipStreamSynchronize(st2);
+                return rc;
+            }
         }
     if (two_q) {
         SGX_HIP(hipEventRecord(c->acq_ev2[1], st2));

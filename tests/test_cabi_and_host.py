@@ -572,45 +572,18 @@ def test_tracking_kernel_selection_table(built):
     assert not bad, bad
 
 
-def test_reserved_poll_registers_are_touched_by_nothing_else(tmp_path):
-    """csrc/sgx_trk3.hip keeps two poll loads in flight while the loop filter runs; the load that lands late writes v[244:255],
-    which therefore must appear in the speculative kernel's code ONLY inside the poll's asm statements."""
+def test_reserved_poll_registers_are_touched_by_nothing_else():
+    """csrc/sgx_trk3.hip keeps poll loads in flight while the loop filter runs; the loads that land late write v[244:255],
+    which therefore must appear in the speculative kernel's code ONLY inside the polls' asm statements.  The same gate runs
+    inside build() and tools/build_variant.sh (softgnss-python_amd/build.py: check_trk3_registers)."""
     import shutil
-    import subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = str(tmp_path / "trk3.s")
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip",
-                        "-I", os.path.join(root, "include"), "-I", os.path.join(root, "softgnss-python_amd", "csrc"),
-                        "-S", "--cuda-device-only", "-o", out, os.path.join(root, "softgnss-python_amd", "csrc", "sgx_trk3.hip")],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    assert r.returncode == 0, r.stderr.decode()[-2000:]
-    import re
-    reserved = re.compile(r"\bv(24[4-9]|25[0-5])\b|\bv\[(\d+):(\d+)\]")
-    in_asm, hits_in, hits_out, spills = False, 0, [], None
-    for line in open(out):
-        t = line.strip()
-        if t.startswith(";;#ASMSTART"):
-            in_asm = True
-        elif t.startswith(";;#ASMEND"):
-            in_asm = False
-        elif t.startswith(".vgpr_spill_count:"):
-            spills = int(t.split(":")[1])
-        elif t and not t.startswith((";", ".")):
-            touched = False
-            for mm in reserved.finditer(t):
-                if mm.group(1) or (int(mm.group(3)) >= 244 and int(mm.group(2)) <= 255):
-                    touched = True
-            if touched:
-                if in_asm:
-                    hits_in += 1
-                else:
-                    hits_out.append(t)
-    assert hits_in >= 10                       # the poll is there
-    assert not hits_out, hits_out[:5]
-    assert spills == 0
+    ok, msg = pkg("build").check_trk3_registers((), hipcc)
+    assert ok, msg
+    ok, msg = pkg("build").check_trk3_registers(("-DT3_POLL2=0",), hipcc)   # (polls written in C++: no asm statements)
+    assert not ok and "not found" in msg, msg       # the gate can fail
 
 
 def test_throughput_kernel_spills_nothing_among_its_dot_products(tmp_path):

@@ -754,7 +754,14 @@ def test_probe_statistics_golden():
 def _oracle_vs_gpu(m, s, os_, rec_host, ms, split_env=None):
     n = s.samplesPerCode
     a = m.AcquisitionResult(s, device=0)
-    a.acquire(rec_host[:11 * n])
+    try:
+        a.acquire(rec_host[:11 * n])
+    except IndexError:
+        # the reference's own failure (coarse code phase == samples per chip, acquisition.py:152-162; round 6: wide-fuzz
+        # seed 1401, 5 samples per chip and a code phase of 5): the oracle must raise it too, and nothing is tracked
+        with pytest.raises(IndexError):
+            orc.acquire(os_, rec_host[:11 * n])
+        return a, None
     ref = orc.acquire(os_, rec_host[:11 * n])
     assert np.array_equal(a.codePhase, ref["codePhase"])
     assert np.array_equal(a.carrFreq, ref["carrFreq"])

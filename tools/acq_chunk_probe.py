@@ -1,5 +1,6 @@
 """Acquisition time against the PRN chunk size of the correlation batch (SGX_ACQ_CHUNK_ROWS): GPU box."""
 import importlib, os, sys
+os.environ["SGX_ACQ_SPLIT_EVENT"] = "1"   # (the coarse / fine split is measured only with the event between them)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 m = importlib.import_module("softgnss-python_amd")
 s = m.Settings(); ctx = m.engine.get_context(s, 0); n = s.samplesPerCode

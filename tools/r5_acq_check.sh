@@ -1,7 +1,7 @@
 #!/bin/bash
 # (round 5) acquisition after a change: every acquisition test of the GPU suite, the two-rank test, the 4-PRN shard's
 # timeline and the config-4 figures of the bench line.  GPU box: bash tools/r5_acq_check.sh
-cd "$GRAFT_REPO_ROOT"
+cd "$(dirname "$0")/.."
 python -m pytest tests -q -m gpu -x -k "acqui or acquire or front_end or two_ranks or config4 or smoke" 2>&1 | tail -4
 bash tools/acq_shard_trace.sh 0 2>&1 | tail -24
 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --concurrent 0 --many-channels 0 2>/dev/null | python3 -c "
