@@ -198,7 +198,7 @@ int sgx_acquire_f64(sgx_ctx* c, const double* signal, size_t n_samples, const in
  *                        waits once, for everything.  out = [n_ch][13][ms] (pinned memory from sgx_host_alloc), ms_done =
  *                        [n_ch]; the channel table as preRun made it comes back in prn / acquiredFreq / codePhase [n_ch]
  *                        (prn 0 = off; the first *n_active channels are on, in order of descending metric).  Returns
- *                        SGX_E_DEFER when the queued sequence does not apply (see the code's comment) - then nothing has
+ *                        SGX_E_DEFER when the queued sequence does not apply (see the code's comment; n_ch > 8) - then nothing has
  *                        been tracked and the eager calls do the work; SGX_E_INDEX / SGX_E_RANGE where the SEARCH failed
  *                        the way the reference's acquire() raises (no channel was tracked).
  *   sgx_acquire_end      the pending search's outputs (sgx_acquire's), without waiting if sgx_track_chained has run.

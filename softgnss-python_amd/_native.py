@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SGX_LIB") or os.path.join(HERE, "lib", "libsgx.so")   # SGX_LIB: another build of the same library (kernel variants side by side)
 
 SGX_OK = 0
-SGX_E_ARG, SGX_E_HIP, SGX_E_NOMEM, SGX_E_INDEX, SGX_E_RCCL, SGX_E_RANGE = -1, -2, -3, -4, -5, -6
+SGX_E_ARG, SGX_E_HIP, SGX_E_NOMEM, SGX_E_INDEX, SGX_E_RCCL, SGX_E_RANGE, SGX_E_DEFER = -1, -2, -3, -4, -5, -6, -7
 NUM_SERIES = 13
 DT_INT8, DT_INT16, DT_UINT8, DT_FLOAT32 = 0, 1, 2, 3   # sgx_track_ex data_type (include/sgx.h)
 DT_FLOAT64, DT_UINT16, DT_INT32, DT_UINT32, DT_INT64, DT_UINT64, DT_FLOAT16 = 4, 5, 6, 7, 8, 9, 10
@@ -362,6 +362,7 @@ class Context(object):
 
     # ---- hot path ----
     def acquire(self, rec, offset, n_samples, prn0, n_blocks=2, noncoh=False):
+        self._acq_token = getattr(self, "_acq_token", 0) + 1   # (any search supersedes a deferred one nobody has looked at)
         prn = np.ascontiguousarray(prn0, dtype=np.int32)
         n = prn.size
         carr = np.zeros(n)
@@ -411,6 +412,7 @@ class Context(object):
     def acquire_sharded(self, comm, rank, world, rec, offset, n_samples, n_prn_total=32, n_blocks=2, noncoh=False):
         """This rank's share of the PRN search + the peak gather as ONE library call (sgx_acquire_sharded): packed on the
         device, one ncclAllGather (comm: a Comm, or None for no collective), one look.  Returns the merged 32-entry arrays."""
+        self._acq_token = getattr(self, "_acq_token", 0) + 1
         carr = np.zeros(32)
         cph = np.zeros(32)
         met = np.zeros(32)
@@ -423,6 +425,7 @@ class Context(object):
 
     def acquire_f64(self, signal, prn0, n_blocks=2, noncoh=False):
         """acquire() on a host signal of any real dtype (copied to HBM as fp64)."""
+        self._acq_token = getattr(self, "_acq_token", 0) + 1
         sig = np.ascontiguousarray(signal, dtype=np.float64)
         prn = np.ascontiguousarray(prn0, dtype=np.int32)
         n = prn.size

@@ -498,8 +498,10 @@ static int track_kind_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset,
     }
     if (direct) {
         // entries never reached keep the reference's initial values (tracking.py:65-94): zeros or +Inf
+        const StepLook* slook = (const StepLook*)((const char*)c->h_look + SGX_STEP_LOOK_OFFSET);   // (chained: preRun's table)
         for (int i = 0; i < n_ch; ++i) {
-            const int dn = (ch[i].prn == 0) ? 0 : ms_done[i];
+            if (chained && slook->prn[i] == 0) continue;      // (a channel that is off: the caller gets the first n_active rows)
+            const int dn = chained ? ms_done[i] : ((ch[i].prn == 0) ? 0 : ms_done[i]);
             if (dn >= ms) continue;
             for (int sidx = 0; sidx < SGX_NUM_SERIES; ++sidx) {
                 const bool zero = (sidx == 0) || (sidx >= 3 && sidx <= 8);
@@ -521,7 +523,7 @@ static int track_kind_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset,
         // the kernel tracked fscale x the record: the six correlator series carry the factor (a power of two: exact),
         // everything the discriminators made of them (ratios) does not
         const double un = 1.0 / K.fscale;
-        for (int i = 0; i < n_ch; ++i) {
+        for (int i = 0; i < n_ch && !chained; ++i) {
             if (ch[i].prn == 0) continue;
             double* o = out + (size_t)i * SGX_NUM_SERIES * (size_t)ms;
             const int dn = ms_done[i] < ms ? ms_done[i] : ms;
@@ -542,7 +544,9 @@ extern "C" int sgx_track_chained(sgx_ctx* c, const sgx_if* r, int64_t rec_file_o
                                  int32_t* ms_done, int32_t data_type, int32_t* prn, double* acquiredFreq, double* codePhase,
                                  int32_t* n_active) {
     SGX_CHECK_ARG(c && r && out && ms_done && prn && acquiredFreq && codePhase && n_active);
-    if (c->acq_pending.mode != 1 || n_ch < 1 || n_ch > 32) return SGX_E_DEFER;
+    // (n_ch <= 8: the eager sequence launches the ACTIVE channels only, and which kernel runs depends on their number
+    // rounded up to 8 - with at most 8 configured channels that is the same launch whatever preRun finds)
+    if (c->acq_pending.mode != 1 || n_ch < 1 || n_ch > 8) return SGX_E_DEFER;
     if (data_type != SGX_DT_INT8 && data_type != SGX_DT_UINT8) return SGX_E_DEFER;
     const int rc = track_kind_impl(c, r, rec_file_offset, nullptr, n_ch, ms, out, ms_done, data_type,
                                    (long long)c->s.skipNumberOfBytes, 0.0, true);

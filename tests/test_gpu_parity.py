@@ -1944,16 +1944,19 @@ def test_deferred_step_equals_the_eager_one(default_record):
     """acquire -> preRun -> track queued without a look in between (sgx_acquire_begin / sgx_track_chained: preRun on the
     device, one wait) against the eager calls: every result bit for bit, 8 channels and a table with channels off."""
     m = pkg()
-    for nch, ms in ((8, 300), (12, 120)):
+    # 8 channels, all on; 5 channels for 8 detections; 8 channels for the 4 detections among PRN indices 0..10 (channels
+    # off); 12 channels (more than 8: the queued sequence does not apply, the same objects run the eager calls)
+    for nch, ms, n_search, chained in ((8, 300, 32, True), (5, 150, 32, True), (8, 150, 11, True), (12, 120, 32, False)):
         s = m.Settings()
         s.numberOfChannels = nch
         s.msToProcess = float(ms)
+        s.acqSatelliteList = list(range(1, n_search + 1))
         ctx = m.engine.get_context(s, 0)
         rec = ctx.upload(default_record)
         ae, te, fe = _step(m, s, rec, ms, False)
         ad, td, fd = _step(m, s, rec, ms, True)
-        assert td.chained and not te.chained
-        assert ad._pending is not None           # tracking is done and nobody has looked at the search yet
+        assert td.chained == chained and not te.chained
+        assert (ad._pending is not None) == chained   # chained: tracking is done and nobody has looked at the search yet
         assert np.array_equal(td.series, te.series)
         assert fd.tell() == fe.tell()
         for f in ("carrFreq", "codePhase", "peakMetric"):
