@@ -65,6 +65,8 @@ struct sgx_if {
     std::atomic<size_t> host_mark{0};        // bytes whose copy has completed, as the host knows it
     std::atomic<int> load_rc{0};             // SGX_OK while running / after success, an error code otherwise
     std::atomic<bool> load_done{false};
+    std::atomic<long long> mag_max{-1};      // largest sum of magnitudes (bytes read as int8) over 17 consecutive 128-byte
+                                             // blocks = a bound for every 2 048-byte window; -1: not scanned yet (sgx_trk.hip)
     unsigned long long* d_mark = nullptr;    // the same watermark in device memory, advanced in copy-stream order
     hipStream_t copy_stream = nullptr;
     char load_err[256] = {0};

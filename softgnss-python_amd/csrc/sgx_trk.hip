@@ -15,6 +15,7 @@
 //                   several chip switches of one ramp (per-sample replica lookup; the round-1 cooperative body).
 // fp64 everywhere: 1e-7 errors in the sums move the code NCO enough to flip a chip-boundary sample somewhere in a 37 s
 // run, which is a 1e-3 relative blip.
+#include <chrono>
 #include "sgx_trk_common.h"
 
 // sgx_trk_tp.hip: throughput-mode kernel (one lane per prompt chip, two workgroups per CU) for split == 1, > 128 channels
@@ -59,6 +60,60 @@ __global__ __launch_bounds__(256) void trk_fill_kernel(double* __restrict__ out,
     const int series = (int)((i / ms) % SGX_NUM_SERIES);
     const bool zero = (series == 0) || (series >= 3 && series <= 8);
     out[i] = zero ? 0.0 : __longlong_as_double(0x7FF0000000000000ll);
+}
+
+// THE SPECULATIVE KERNEL'S SCALE GUARD for resident int8 records (sgx_trk3.hip: a unit's total must stay below 2^17, and no
+// arm's total can exceed the sum of the unit's magnitudes).  One pass over the record, once per record (cached in the
+// handle): the largest sum of |x| over 17 consecutive 128-byte blocks - any 2 048-byte window of the kernel lies inside
+// such a run - by workgroups of 256 blocks with a halo of 16.  1.4 GB in ~0.4 ms; a streaming record that is not resident
+// yet is guarded inside the kernel instead (its record wave adds up the magnitudes of every block's window).
+__global__ __launch_bounds__(256) void if_mag_kernel(const int8_t* __restrict__ x, long long n_bytes, int* __restrict__ out_max) {
+    __shared__ int s_m[256 + 16];
+    const long long blk0 = (long long)blockIdx.x * 256;
+    auto block_mag = [&](long long j) -> int {
+        const long long a = j * 128;
+        if (a >= n_bytes) return 0;                      // (the allocation is padded with zero bytes: SGX_IF_PAD)
+        int m = 0;
+        const uint4* p = reinterpret_cast<const uint4*>(x + a);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint4 w = p[k];
+            const unsigned b = 0x80808080u;
+            m = (int)__builtin_amdgcn_sad_u8(w.x ^ b, b, (unsigned)m);
+            m = (int)__builtin_amdgcn_sad_u8(w.y ^ b, b, (unsigned)m);
+            m = (int)__builtin_amdgcn_sad_u8(w.z ^ b, b, (unsigned)m);
+            m = (int)__builtin_amdgcn_sad_u8(w.w ^ b, b, (unsigned)m);
+        }
+        return m;
+    };
+    s_m[threadIdx.x] = block_mag(blk0 + threadIdx.x);
+    if (threadIdx.x < 16) s_m[256 + threadIdx.x] = block_mag(blk0 + 256 + threadIdx.x);
+    __syncthreads();
+    int w = 0;
+#pragma unroll
+    for (int k = 0; k < 17; ++k) w += s_m[threadIdx.x + k];
+    for (int o = 32; o > 0; o >>= 1) {
+        const int v = __shfl_down(w, o);
+        w = v > w ? v : w;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out_max, w);
+}
+
+// -> the bound (cached in the handle), or -1 when the record is not fully resident yet / on an error
+static long long if_mag_bound(sgx_ctx* c, const sgx_if* r) {
+    long long known = r->mag_max.load();
+    if (known >= 0) return known;
+    if (r->loader && !r->load_done.load()) return -1;
+    int* d_max = (int*)((char*)c->d_small + 730000);
+    if (hipMemsetAsync(d_max, 0, sizeof(int), c->stream) != hipSuccess) return -1;
+    const long long n_blocks128 = ((long long)r->n + 127) / 128;
+    const unsigned grid = (unsigned)((n_blocks128 + 255) / 256);
+    if_mag_kernel<<<grid ? grid : 1u, 256, 0, c->stream>>>(r->d, (long long)r->n + SGX_IF_PAD - 128, d_max);
+    int h = 0;
+    if (hipMemcpyAsync(&h, d_max, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+    const_cast<sgx_if*>(r)->mag_max.store((long long)h);
+    return (long long)h;
 }
 
 // ---- WHICH KERNEL, HOW MANY MEMBERS: the one rule (include/sgx.h: sgx_track_plan; tests/test_cabi_and_host.py holds the table)
@@ -174,6 +229,14 @@ static int track_kind_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset,
     SGX_HIP(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const sgx_settings& S = c->s;
+    // (diagnosis) SGX_STEP_TRACE=1: host-side time stamps of this call on stderr, microseconds since its entry
+    const char* tre = getenv("SGX_STEP_TRACE");
+    const bool trace = tre && tre[0] == '1';
+    const auto tr0 = std::chrono::steady_clock::now();
+    auto stamp = [&](const char* what) {
+        if (trace) fprintf(stderr, "[sgx step trace] %-28s %8.1f us\n", what,
+                           std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr0).count());
+    };
 
     TrkConst K;
     K.fs = S.samplingFreq;
@@ -343,17 +406,24 @@ static int track_kind_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset,
     bool used_v2 = false;
     // what the launches so far have established: the record's streaming has been tried (and stalled), a member of a
     // cooperative layout timed out (the next launch runs with one workgroup per channel)
-    bool stream_tried = false, fallback_one = false;
-    const bool v3_off = false;
+    bool stream_tried = false, fallback_one = false, v3_off = false;
+    if (use_v3 && kind == SGX_DT_INT8 && !(r->loader && !r->load_done.load())) {
+        // (resident int8 record: the scale guard is a bound computed once per record; sgx_trk3.hip says why 2^17)
+        const long long mag = if_mag_bound(c, r);
+        if (mag >= 131072) {
+            fprintf(stderr, "[sgx] tracking: samples too strong for the speculative kernel's fixed point (2 048 samples add up "
+                            "to 131 072 or more in magnitude); the round-3 kernel tracks this record\n");
+            v3_off = true;
+        }
+    }
     int used_members = 0;
     hipError_t e = hipSuccess;
     int h_err = 0;
     // The cooperating workgroups of a channel wait for each other, so all of them must be resident at once.  If
     // something else occupies the CUs a member times out (bounded spins) and flags the channel: the launch is
     // then repeated once with one workgroup per channel, which needs no co-residency.  A streaming record whose
-    // watermark stalls is repeated on the resident record first, with the same decomposition: at most three launches, each
-    // repeat said on stderr.  (Rounds 4-5 also repeated a record too strong for the speculative kernel's 48-bit granules
-    // with the round-3 kernel; since round 6 its granules hold any record's sums, sgx_trk3.hip.)
+    // watermark stalls is repeated on the resident record first, with the same decomposition; a record too strong for the
+    // speculative kernel's fixed point is repeated with the round-3 kernel: at most four launches, each repeat said on stderr.
     if (chained && r->loader && !r->load_done.load()) return SGX_E_DEFER;   // (a record that is still streaming in)
     for (int launches = 0; launches < 4; ++launches) {
         if (!chained) {
@@ -363,7 +433,9 @@ static int track_kind_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset,
             const int rp = sgx_prerun_enqueue(c, d_ch, n_ch, skip_bytes, rec_file_offset, sample_bytes);
             if (rp != SGX_OK) return rp;
         }
+        stamp("channel table queued");
         SGX_HIP(hipMemsetAsync(aux + sz_ch, 0, sz_done + sz_xch + 256, st));   // done, every polled word, err
+        stamp("memset queued");
         if (!direct) trk_fill_kernel<<<(unsigned)((elems + 255) / 256), 256, 0, st>>>(d_out, ms, (long long)elems);
         // a record that is still streaming in is followed by the latency-mode kernel (its record wave watches the
         // device watermark); the other kernels, and a launch repeated on the resident record, first wait for all of it
@@ -436,12 +508,15 @@ static int track_kind_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset,
             c->timing.track_kernel = 4.f;
         }
         hipEventRecord(c->ev[4], st);
+        stamp("kernel queued");
         c->timing.track_members = (float)members_now;
         c->timing.track_streamed = streaming ? 1.f : 0.f;
         e = hipGetLastError();
         int h_err2[2] = {0, 0};   // [0] flags | 1 + channel of a timeout; [1] 1 + channel of a block beyond the units
         if (e == hipSuccess) e = hipMemcpyAsync(h_err2, d_err, 2 * sizeof(int), hipMemcpyDeviceToHost, st);
+        stamp("error word copy queued");
         if (e == hipSuccess) e = hipStreamSynchronize(st);
+        stamp("stream synchronised");
         h_err = h_err2[0];
         reserved.drop();
         // test hooks: treat the first launch as timed out ('1'), or the one that follows a stalled stream ('2'); treat
@@ -461,6 +536,15 @@ static int track_kind_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset,
             continue;
         }
         h_err &= ~TRK_ERR_STREAM;
+        if (e == hipSuccess && (h_err & TRK_ERR_SCALE) && !v3_off) {
+            // samples beyond what the speculative kernel's 2^30 fixed point holds in 48 bits (a record that clips all the
+            // time): the round-3 kernel, whose 2^28 holds full-scale samples that all line up, tracks it
+            fprintf(stderr, "[sgx] tracking: samples too strong for the speculative kernel's fixed point (2 048 samples add up "
+                            "to 131 072 or more in magnitude); repeating the launch with the round-3 kernel\n");
+            v3_off = true;
+            continue;
+        }
+        h_err &= ~TRK_ERR_SCALE;
         if (e == hipSuccess && (h_err & TRK_ERR_RANGE) == 0) h_err &= 0xFFFF;
         if (e == hipSuccess && (h_err & TRK_ERR_RANGE)) {
             sgx_set_error("tracking: channel %d reached a block longer than the %d units of %d samples the kernel "
@@ -477,6 +561,7 @@ static int track_kind_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset,
     if (e == hipSuccess && !direct) e = hipMemcpyAsync(out, d_out, elems * sizeof(double), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(ms_done, d_done, sizeof(int) * (size_t)n_ch, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
+    stamp("ms_done copied");
     if (want_prof && e == hipSuccess) {
         std::vector<long long> hp(T2_PROF_STRIDE * (size_t)n_ch);
         hipMemcpy(hp.data(), d_prof, sizeof(long long) * hp.size(), hipMemcpyDeviceToHost);
@@ -519,6 +604,7 @@ static int track_kind_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset,
         if (rq != SGX_OK) return sgx_if_require(r, r->n);
     }
     hipEventElapsedTime(&c->timing.track_ms, c->ev[3], c->ev[4]);
+    stamp("done");
     if (floaty && K.fscale != 1.0) {
         // the kernel tracked fscale x the record: the six correlator series carry the factor (a power of two: exact),
         // everything the discriminators made of them (ratios) does not

@@ -46,8 +46,7 @@
 // factor, and steps beyond 20 Hz (the pull-in) are evaluated exactly - tables in full, accumulate again - because the
 // residue of those first blocks sat in the code NCO's integrator for the rest of the run (code phase 1e-11 chips from the
 // reference's after 10 000 blocks: enough to put a sample 3e-12 chips from a chip boundary on the other side).
-// Exchange: granules {52-bit fixed point, 2^30 | 4 zero bits | 8-bit epoch} (round 6: a unit's total cannot leave 52 bits,
-// whatever the record), order-free integer sums, redundant filters in every member;
+// Exchange: granules {16-bit epoch | 48-bit fixed point, 2^30}, order-free integer sums, redundant filters in every member;
 // an arm's I and Q of a unit side by side; the filter waves keep THREE looks in flight (the PLL wave 8-byte loads, the DLL
 // wave one 16-byte load per look; reserved registers v[244:255]).  Record path and abort protocol are those of
 // sgx_trk2.hip.
@@ -76,12 +75,17 @@
 // difference between this kernel's sums and the reference's own (9e-13 relative against 4e-13 from the reference's carrier
 // argument; the code NCO disagrees by an ulp in 3 % of the blocks because of it, and the code phases of two
 // implementations then drift apart until a sample within 1e-11 chips of a chip boundary falls on different sides).
-// Rounds 4-5 kept a 48-bit payload under a 16-bit epoch: a unit's total had to stay below 2^17, a guard on the PLL wave sent
-// stronger records to sgx_trk2.hip (TRK_ERR_SCALE) - and looked at payloads that had already wrapped (totals of 1.5 x 2^17
-// and more passed it).  Round 6: the payload is the double's whole 52-bit mantissa field, above an epoch of 8 bits (a slot
-// is rewritten every second block: consecutive epochs of a slot differ by 2).  A unit holds 2 048 samples of at most 255
-// in magnitude: |total| 2^30 <= 2^49 < 2^51 - no record can wrap it, there is no guard and no repeated launch.  The filter
-// waves add the payloads as two 26-bit limbs (32 lanes: 31 bits).
+// A unit's total must stay below 2^17 (the default scene's prompt sums: 7 500 per unit).  The guard (round 6; round 5's
+// looked at the units' prompt payloads only, which have already WRAPPED when a total passes 1.5 x 2^17): any arm's sum over
+// samples is at most the sum of their magnitudes - every sample enters once, with a chip of +-1 and a phasor of modulus 1 -
+// so while the 2 048 bytes of a unit's window add up to less than 2^17 in magnitude (a mean of 64 of the 127 an int8 sample
+// can reach: a record that clips all the time), no arm of the unit can reach 2^17.  A resident record is scanned ONCE by the
+// host side (sgx_trk.hip: if_mag_bound, cached in the record's handle; a record beyond the bound goes to sgx_trk2.hip, said
+// on stderr); a record that is still streaming in is watched by the RECORD wave, block by block (v_sad_u8 on two 16-byte
+// loads per lane, a DPP reduction: it has the time; the map waves have none), and flags TRK_ERR_SCALE: the host repeats the
+// launch with sgx_trk2.hip and says so.  Offset-binary records (uint8, read as they lie: a DC of 128 that the correlation
+// cancels but a magnitude bound cannot) keep the round-5 guard: the units' prompt payloads beyond HALF the room, seen by the
+// PLL wave behind the barrier.
 #ifndef T3_FIX
 #define T3_FIX 1073741824.0
 #endif
@@ -193,14 +197,14 @@ struct T3Shared {
 #define T3_TL_SET(mask, on, wave_, e, v) do { } while (0)
 #endif
 
-// Sum of the 52-bit payloads (two's complement) of the granules of lanes 0..31 / 32..63, as a double, in rows 1 / 3 of the
-// wave: the payload is split into a low limb of 26 bits and a sign-extended high limb, whose sums over 32 lanes fit 32 bits -
+// Sum of the 48-bit payloads (two's complement) of the granules of lanes 0..31 / 32..63, as a double, in rows 1 / 3 of the
+// wave: the payload is split into a low limb of 24 bits and a sign-extended high limb, whose sums over 32 lanes fit 32 bits -
 // two INDEPENDENT chains of one DPP add per step instead of one chain of add + add-with-carry (the carry is a second
-// dependent instruction in each of the five steps of the PLL wave's chain behind its poll); hi 2^26 + lo is exact.
+// dependent instruction in each of the five steps of the PLL wave's chain behind its poll); hi 2^24 + lo is exact.
 __device__ __forceinline__ double t3_sum48_half(unsigned long long x) {
     const unsigned xl = (unsigned)x, xh = (unsigned)(x >> 32);
-    unsigned lo = __builtin_amdgcn_alignbit(xh, xl, 12) & 0x3FFFFFFu;   // payload bits 0..25 (granule bits 12..37)
-    unsigned hi = (unsigned)((int)xh >> 6);                             // payload bits 26..51, sign-extended
+    unsigned lo = xl & 0xFFFFFFu;
+    unsigned hi = (unsigned)((int)(__builtin_amdgcn_alignbit(xh, xl, 24) << 8) >> 8);   // bits 24..47, sign-extended
     unsigned a, b;
 #define T3_S48(d0, d1, s0, s1, ctl)                                                               \
         "v_add_u32_dpp " d0 ", " s0 ", " s0 " " ctl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
@@ -216,15 +220,15 @@ __device__ __forceinline__ double t3_sum48_half(unsigned long long x) {
         "v_add_u32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf"
         : "+v"(lo), "+v"(hi), "=&v"(a), "=&v"(b));
 #undef T3_S48
-    return __builtin_fma((double)(int)hi, 67108864.0, (double)lo);
+    return __builtin_fma((double)(int)hi, 16777216.0, (double)lo);
 }
 
 // the same for two granules per lane (the DLL wave: I in x1, Q in x2): four independent chains, no wait state to fill
 __device__ __forceinline__ void t3_sum48_half2(unsigned long long x1, unsigned long long x2, double& v1, double& v2) {
     const unsigned x1l = (unsigned)x1, x1h = (unsigned)(x1 >> 32), x2l = (unsigned)x2, x2h = (unsigned)(x2 >> 32);
-    unsigned l1 = __builtin_amdgcn_alignbit(x1h, x1l, 12) & 0x3FFFFFFu, l2 = __builtin_amdgcn_alignbit(x2h, x2l, 12) & 0x3FFFFFFu;
-    unsigned h1 = (unsigned)((int)x1h >> 6);
-    unsigned h2 = (unsigned)((int)x2h >> 6);
+    unsigned l1 = x1l & 0xFFFFFFu, l2 = x2l & 0xFFFFFFu;
+    unsigned h1 = (unsigned)((int)(__builtin_amdgcn_alignbit(x1h, x1l, 24) << 8) >> 8);
+    unsigned h2 = (unsigned)((int)(__builtin_amdgcn_alignbit(x2h, x2l, 24) << 8) >> 8);
     unsigned a, b, c, d;
 #define T3_S48(d0, d1, d2, d3, s0, s1, s2, s3, ctl)                                               \
         "v_add_u32_dpp " d0 ", " s0 ", " s0 " " ctl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
@@ -243,8 +247,8 @@ __device__ __forceinline__ void t3_sum48_half2(unsigned long long x1, unsigned l
         "v_add_u32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf"
         : "+v"(l1), "+v"(h1), "+v"(l2), "+v"(h2), "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d));
 #undef T3_S48
-    v1 = __builtin_fma((double)(int)h1, 67108864.0, (double)l1);
-    v2 = __builtin_fma((double)(int)h2, 67108864.0, (double)l2);
+    v1 = __builtin_fma((double)(int)h1, 16777216.0, (double)l1);
+    v2 = __builtin_fma((double)(int)h2, 16777216.0, (double)l2);
 }
 
 __device__ __forceinline__ int t3_carr_mult(int lane, int unit, int head) {
@@ -870,7 +874,7 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
         // fixed point: the raw bits of fma(a, 2^28, 1.5 2^52) are bias + round(a 2^28); sums of them carry the sum of the
         // integers in their low 48 bits whatever the biases add up to
         const double lane_fix = uns ? T3_FIX * 0.5 : T3_FIX;
-        constexpr unsigned long long res_mask = 0xFFFFFFFFFFFFFull;   // the 52 mantissa bits
+        constexpr unsigned long long res_mask = 0xFFFFFFFFFFFFull;
         unsigned long long q[6];
         {
             double t_[6];
@@ -897,8 +901,7 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
                     // the eighth arrival (2 waves x 4 rows): this lane holds the member's total of its word
                     const unsigned long long tot = prev + mine;
                     S.acc[par][word] = 0ull;
-                    // (the shift drops the arrival count and what the eight mantissas carried into bits 52 ..)
-                    const unsigned long long gran = (tot << 12) | (unsigned long long)((unsigned)(it + 1) & 0xFFu);
+                    const unsigned long long gran = ((unsigned long long)((unsigned)(it + 1) & 0xFFFFu) << 48) | (tot & 0xFFFFFFFFFFFFull);
                     granule_store(xbase + ((((par * 3 + (word >> 1)) * T3_XLINE + unit) << 1) | (word & 1)), gran, fast);
 #ifdef T3_TIMELINE
                     if (word == 0) S.tpub[par] = (long long)__builtin_amdgcn_s_memtime();
@@ -973,10 +976,22 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
 #ifndef T3_POLL2
 #define T3_POLL2 3                 // bit 0: the PLL wave, bit 1: the DLL wave (0: one load at a time, for comparison)
 #endif
+// s_sleep units (64 cycles) the filter waves rest behind the barrier before their off-chain work
+#ifndef T3_SLEEP_PLL
+#define T3_SLEEP_PLL 0
+#endif
+#ifndef T3_SLEEP_DLL
+#define T3_SLEEP_DLL 0
+#endif
+#ifdef T3_ALIGN_POLL   // (diagnosis) the polls' loops start on a 64-byte line of the instruction cache
+#define T3_POLL_ALIGN ".p2align 6\n"
+#else
+#define T3_POLL_ALIGN
+#endif
 #define T3_STR2(x) #x
 #define T3_STR(x) T3_STR2(x)
-__device__ __forceinline__ int t3_poll1(unsigned long long& x, const unsigned long long* p, unsigned tag, int rounds) {
-    unsigned t;
+__device__ __forceinline__ int t3_poll1(unsigned long long& x, const unsigned long long* p, unsigned long long tag, int rounds) {
+    unsigned long long t;
     int left;
     // (THREE loads in flight here: the PLL wave's chain is the longer of the two filter waves')
     asm volatile(
@@ -987,22 +1002,23 @@ __device__ __forceinline__ int t3_poll1(unsigned long long& x, const unsigned lo
         "s_sleep " T3_STR(T3_POLL_GAP3) "\n\t"
         "global_load_dwordx2 v[254:255], %[p], off sc1\n\t"
         "s_mov_b32 %[n], %[r]\n"
+        T3_POLL_ALIGN
         "1:\n\t"
         "s_waitcnt vmcnt(2)\n\t"
-        "v_and_b32 %[t], 0xff, v250\n\t"
-        "v_cmp_eq_u32_e32 vcc, %[tag], %[t]\n\t"
+        "v_lshrrev_b64 %[t], 48, v[250:251]\n\t"
+        "v_cmp_eq_u64_e32 vcc, %[tag], %[t]\n\t"
         "s_cmp_eq_u64 vcc, exec\n\t"
         "s_cbranch_scc1 2f\n\t"
         "global_load_dwordx2 v[250:251], %[p], off sc1\n\t"
         "s_waitcnt vmcnt(2)\n\t"
-        "v_and_b32 %[t], 0xff, v252\n\t"
-        "v_cmp_eq_u32_e32 vcc, %[tag], %[t]\n\t"
+        "v_lshrrev_b64 %[t], 48, v[252:253]\n\t"
+        "v_cmp_eq_u64_e32 vcc, %[tag], %[t]\n\t"
         "s_cmp_eq_u64 vcc, exec\n\t"
         "s_cbranch_scc1 3f\n\t"
         "global_load_dwordx2 v[252:253], %[p], off sc1\n\t"
         "s_waitcnt vmcnt(2)\n\t"
-        "v_and_b32 %[t], 0xff, v254\n\t"
-        "v_cmp_eq_u32_e32 vcc, %[tag], %[t]\n\t"
+        "v_lshrrev_b64 %[t], 48, v[254:255]\n\t"
+        "v_cmp_eq_u64_e32 vcc, %[tag], %[t]\n\t"
         "s_cmp_eq_u64 vcc, exec\n\t"
         "s_cbranch_scc1 5f\n\t"
         "global_load_dwordx2 v[254:255], %[p], off sc1\n\t"
@@ -1031,16 +1047,16 @@ __device__ __forceinline__ int t3_poll1(unsigned long long& x, const unsigned lo
 #ifndef T3_POLL_GAPD
 #define T3_POLL_GAPD T3_POLL_GAP3    // s_sleep units between the DLL wave's three loads
 #endif
-#define T3_TAGSEL 0x0c0c0400u      // v_perm_b32: {0, 0, lowest byte of the first source, lowest byte of the second}
+#define T3_TAGSEL 0x07060302u      // v_perm_b32: {upper half of the first source, upper half of the second}
 __device__ __forceinline__ int t3_poll2(unsigned long long& x1, unsigned long long& x2, const unsigned long long* p1,
-                                        const unsigned long long* p2, unsigned tag, int rounds) {
+                                        const unsigned long long* p2, unsigned long long tag, int rounds) {
     (void)p2;
     unsigned t;
     int left;
-    const unsigned tag2 = tag | (tag << 8);
-#define T3_P2_CHECK(r0, r2, r3, lbl)                                   \
+    const unsigned tag2 = (unsigned)tag | ((unsigned)tag << 16);
+#define T3_P2_CHECK(r0, r1, r3, lbl)                                   \
         "s_waitcnt vmcnt(2)\n\t"                                        \
-        "v_perm_b32 %[t], v" #r2 ", v" #r0 ", %[sel]\n\t"               \
+        "v_perm_b32 %[t], v" #r3 ", v" #r1 ", %[sel]\n\t"               \
         "v_cmp_eq_u32_e32 vcc, %[tag2], %[t]\n\t"                       \
         "s_cmp_eq_u64 vcc, exec\n\t"                                    \
         "s_cbranch_scc1 " lbl "\n\t"                                    \
@@ -1053,10 +1069,11 @@ __device__ __forceinline__ int t3_poll2(unsigned long long& x1, unsigned long lo
         "s_sleep " T3_STR(T3_POLL_GAPD) "\n\t"
         "global_load_dwordx4 v[252:255], %[p], off sc1\n\t"
         "s_mov_b32 %[n], %[r]\n"
+        T3_POLL_ALIGN
         "1:\n\t"
-        T3_P2_CHECK(244, 246, 247, "2f")
-        T3_P2_CHECK(248, 250, 251, "3f")
-        T3_P2_CHECK(252, 254, 255, "5f")
+        T3_P2_CHECK(244, 245, 247, "2f")
+        T3_P2_CHECK(248, 249, 251, "3f")
+        T3_P2_CHECK(252, 253, 255, "5f")
         "s_sub_u32 %[n], %[n], 1\n\t"
         "s_cmp_lg_u32 %[n], 0\n\t"
         "s_cbranch_scc1 1b\n\t"
@@ -1193,7 +1210,7 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
         T2_PIN(cs_p); T2_PIN(sn_p); T2_PIN(mf); T2_PIN(rc);   // (keeps all of this ahead of the wait)
         __builtin_amdgcn_s_setprio(3);
         const unsigned long long* gp = xbase + ((((par * 3 + 0) * T3_XLINE + (lane & 31)) << 1) | (lane >> 5));   // (I_P, Q_P of a unit lie side by side)
-        const unsigned tag = (unsigned)(it + 1) & 0xFFu;
+        const unsigned long long tag = (unsigned long long)((unsigned)(it + 1) & 0xFFFFu);
         unsigned long long x = 0;
         int budget = T2_POLL_BUDGET;
         bool gave_up = false;
@@ -1218,7 +1235,7 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
 #else
         for (;;) {
             if (mine) x = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__all(!mine || ((unsigned)x & 0xFFu) == tag)) break;
+            if (__all(!mine || (x >> 48) == tag)) break;
             if ((--budget & 31) == 0) {
                 if (budget == 0 || lds_peek(&S.flag[1]) != 0) {
                     gave_up = true;
@@ -1294,9 +1311,18 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
         T2STAMP(prof_on, 10);  // carrier tables
         T3_TL(T3_TL_PLL, tl_on, 4, 4);   // at the barrier
         T3_WB(wb_on);
+#if T3_SLEEP_PLL > 0
+        __builtin_amdgcn_s_sleep(T3_SLEEP_PLL);    // the final pass has the SIMD to itself for a moment (see T3_SLEEP_PLL)
+#endif
         __builtin_amdgcn_s_setprio(T3_PRIO_PRE);   // what follows until the next poll is off the chain: the final pass (2) issues first,
                                          // the speculative pass (0) after it
         __builtin_amdgcn_sched_barrier(0);
+        // (a unit's prompt sum beyond half the room of the 48-bit payload, see T3_FIX: the guard of offset-binary records;
+        // for every record: without these few instructions behind the barrier the kernel is 0.6 ms SLOWER - the PLL wave's
+        // work in front of its poll then starts a moment earlier, beside the final pass)
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(mine && (unsigned)((int)(short)(unsigned short)(x >> 32) + 0x4000) > 0x7FFFu) != 0, 0)) {
+            if (lane == 0) atomicOr(err, TRK_ERR_SCALE);
+        }
         r_cf = carrFreq;                 // (the block's record values: nobody waits for these)
         r_ip = I_P * (s2_blk * unfix);
         r_qp = Q_P * (s2_blk * unfix);
@@ -1445,7 +1471,7 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
         // lanes 0..31 follow the early arm, lanes 32..63 the late one: gp1 the I sums (words 2 | 4), gp2 the Q sums (3 | 5)
         const unsigned long long* gp1 = xbase + (((par * 3 + 1 + (lane >> 5)) * T3_XLINE + (lane & 31)) << 1);   // 16 bytes: I and Q
         const unsigned long long* gp2 = gp1 + 1;
-        const unsigned tag = (unsigned)(it + 1) & 0xFFu;
+        const unsigned long long tag = (unsigned long long)((unsigned)(it + 1) & 0xFFFFu);
         unsigned long long x1 = 0, x2 = 0, xa = 0;
         int budget = T2_POLL_BUDGET;
         bool gave_up = false;
@@ -1470,7 +1496,7 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
                 x1 = __hip_atomic_load(gp1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 x2 = __hip_atomic_load(gp2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (__all(!mine || (((unsigned)x1 & 0xFFu) == tag && ((unsigned)x2 & 0xFFu) == tag))) break;
+            if (__all(!mine || ((x1 >> 48) == tag && (x2 >> 48) == tag))) break;
             if ((--budget & 15) == 0) {
                 xa = __hip_atomic_load(xabort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (xa != 0 || budget == 0) {
@@ -1561,6 +1587,9 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
 #endif
         T3_TL(T3_TL_DLL, tl_on, 5, 4);   // at the barrier
         T3_WB(wb_on);
+#if T3_SLEEP_DLL > 0
+        __builtin_amdgcn_s_sleep(T3_SLEEP_DLL);
+#endif
         __builtin_amdgcn_s_setprio(T3_PRIO_PRE);
         __builtin_amdgcn_sched_barrier(0);
         r_ve = vi * (s2_blk * unfix);    // (the block's record values: nobody waits for these)
@@ -1639,6 +1668,41 @@ __device__ __forceinline__ int t3_rec_role(T3Shared& S, const TrkConst& K, const
             if (K.mark == nullptr || (unsigned long long)(a + 128) <= mark_seen)   // (a streaming record: only what is resident)
                 asm volatile("global_load_dword %0, %1, off" : "+v"(dummy) : "v"(rec + a) : "memory");
         }
+#ifndef T3_NO_GUARD
+        if (K.mark != nullptr && K.uns == 0) {
+            // THE SCALE GUARD (see T3_FIX) of a STREAMING int8 record (a resident one has been scanned once by the host,
+            // sgx_trk.hip: if_mag_bound): the magnitudes of the unit's 2 048 bytes of THIS block (its aligned window: an
+            // L2 hit, the map waves read them two blocks ago) - signed bytes as |(b ^ 0x80) - 0x80| by v_sad_u8, a DPP
+            // reduction into lane 63.  On this wave because it has the time: the speculative pass has none to spare (15
+            // instructions more in its part B: 42.8 -> 44.9 ms; here, for every record: + 0.17 ms).
+            long long a = (C.pos & ~15ll) + (long long)unit * T3_UNIT + 32ll * lane;
+            const long long top = limit - 16;
+            a = a < 0 ? 0 : (a > top ? top : a);
+            if (K.mark == nullptr || (unsigned long long)(a + 32) <= mark_seen) {
+                const uint4 w0 = *reinterpret_cast<const uint4*>(rec + a);
+                const uint4 w1 = *reinterpret_cast<const uint4*>(rec + a + 16);
+                const unsigned bias = 0x80808080u;
+                int mag = 0;
+                mag = (int)__builtin_amdgcn_sad_u8(w0.x ^ bias, bias, (unsigned)mag);
+                mag = (int)__builtin_amdgcn_sad_u8(w0.y ^ bias, bias, (unsigned)mag);
+                mag = (int)__builtin_amdgcn_sad_u8(w0.z ^ bias, bias, (unsigned)mag);
+                mag = (int)__builtin_amdgcn_sad_u8(w0.w ^ bias, bias, (unsigned)mag);
+                mag = (int)__builtin_amdgcn_sad_u8(w1.x ^ bias, bias, (unsigned)mag);
+                mag = (int)__builtin_amdgcn_sad_u8(w1.y ^ bias, bias, (unsigned)mag);
+                mag = (int)__builtin_amdgcn_sad_u8(w1.z ^ bias, bias, (unsigned)mag);
+                mag = (int)__builtin_amdgcn_sad_u8(w1.w ^ bias, bias, (unsigned)mag);
+                mag += __builtin_amdgcn_update_dpp(0, mag, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+                mag += __builtin_amdgcn_update_dpp(0, mag, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+                mag += __builtin_amdgcn_update_dpp(0, mag, 0x141, 0xF, 0xF, true);   // row_half_mirror
+                mag += __builtin_amdgcn_update_dpp(0, mag, 0x140, 0xF, 0xF, true);   // row_mirror: every lane holds its row's sum
+                mag += __builtin_amdgcn_update_dpp(0, mag, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+                mag += __builtin_amdgcn_update_dpp(0, mag, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+                if (__builtin_expect(__builtin_amdgcn_readlane(mag, 63) >= 131072, 0)) {
+                    if (lane == 0) atomicOr(err, TRK_ERR_SCALE);
+                }
+            }
+        }
+#endif
 #ifdef T3_REC_LAT   // (diagnosis) how long the far prefetch is under way: the CU returns vector loads in order
         {
             const long long t0_ = (long long)__builtin_amdgcn_s_memtime();
@@ -1668,6 +1732,9 @@ __global__ __launch_bounds__(T3_THREADS) void trk3_kernel(const int8_t* __restri
                                                           long long* __restrict__ prof,
                                                           unsigned long long* __restrict__ xch, int* __restrict__ err) {
     __shared__ T3Shared S;
+#ifdef T3_PAD   // (diagnosis) moves every instruction behind this point by 4 T3_PAD bytes: does the code's placement matter?
+    asm volatile(".rept " T3_STR(T3_PAD) "\n\ts_nop 0\n\t.endr");
+#endif
     const int P = K.split;
     const int bq = blockIdx.x >> 3, br = blockIdx.x & 7;
     const int ch = br + 8 * (bq / P);

@@ -262,6 +262,7 @@ __device__ __forceinline__ void granule_store(unsigned long long* p, unsigned lo
 // once per several hundred blocks and not once per block.
 #define TRK_ERR_STREAM 0x40000000   // error word: the watermark of a streaming record did not advance in time
 #define TRK_ERR_RANGE 0x20000000    // error word: a block is longer than the units the launch provides
+#define TRK_ERR_SCALE 0x10000000    // error word: samples too strong for the speculative kernel's 2^30 fixed point (sgx_trk3.hip)
 
 __device__ __forceinline__ void wait_mark(const unsigned long long* mark, long long need, unsigned long long& seen,
                                           int* err, int ch) {

@@ -2027,3 +2027,56 @@ def test_deferred_search_raises_the_references_index_error_at_the_first_look():
     with pytest.raises(IndexError):
         t.track(m.DeviceFile(rec))                                 # the device found no channel table to make: the look raises
     rec.free()
+
+
+def _clean_record(m, s, amp, n_ms, prn=5, doppler=1250.0, start=7000):
+    """A NOISELESS one-satellite record: round(amp * chip * cos(carrier)) - every sample lines up with the replica."""
+    n = s.samplesPerCode
+    N = (n_ms + 2) * (n + 2)
+    t = np.arange(N, dtype=np.float64)
+    code = np.asarray(s.generateCAcode(prn - 1))
+    chip = code[(np.floor((t - start) * (s.codeFreqBasis / s.samplingFreq)).astype(np.int64)) % 1023]
+    x = np.rint(amp * chip * np.cos(2 * np.pi * ((s.IF + doppler) / s.samplingFreq) * t + 0.3))
+    return x.astype(np.int64)
+
+
+def test_a_record_too_strong_for_the_speculative_kernel_is_tracked_by_the_round_3_kernel(capfd):
+    """csrc/sgx_trk3.hip exchanges unit sums as 48-bit payloads at 2^30: a unit's total must stay below 2^17.  A noiseless
+    int8 record of amplitude 120 (mean magnitude 76) would pass that - and round 5's guard, which looked at payloads that had
+    already wrapped.  Round 6 bounds the sums by the samples' magnitudes (one scan per resident record, csrc/sgx_trk.hip:
+    if_mag_bound): the round-3 kernel tracks the record, SAID on stderr, and the results are the reference's.  Amplitude 70
+    (unit sums of 72 000: past HALF the room) is sent there by the kernel's own look at its prompt sums, with a repeated
+    launch that is said as well; amplitude 50 and an offset-binary uint8 record of amplitude 120 (whose scale is half) stay
+    on the speculative kernel - and are the reference's too."""
+    m = pkg()
+    for amp, kind, kernel in ((120, "int8", 2), (70, "int8", 2), (50, "int8", 5), (120, "uint8", 5)):
+        s = m.Settings()
+        os_ = orc.OracleSettings()
+        kw = dict(acqSatelliteList=range(1, 9), numberOfChannels=1, msToProcess=40.0)
+        for k, v in kw.items():
+            setattr(s, k, v)
+            setattr(os_, k, v)
+        x = _clean_record(m, s, amp, 40)
+        ctx = m.engine.get_context(s, 0)
+        if kind == "uint8":
+            s.dataType = os_.dataType = "uint8"
+            raw = (x + 128).astype(np.uint8)
+            ref = orc.acquire(os_, raw[:11 * s.samplesPerCode])
+            chans = orc.pre_run(os_, ref)
+            a = m.AcquisitionResult(s, device=0)
+            a.acquire(raw[:11 * s.samplesPerCode].astype(np.float64))     # (acquisition takes any real-valued signal)
+            assert np.array_equal(a.carrFreq, ref["carrFreq"]) and np.array_equal(a.codePhase, ref["codePhase"])
+            a.preRun()
+            t = m.TrackingResult(a, device=0)
+            rec = ctx.upload_bytes(raw)
+            t.track(m.DeviceFile(rec))
+            rec.free()
+            want = orc.stack_series(orc.track(os_, chans, raw))
+            assert np.array_equal(t.series[:, 0], want[:, 0])
+            assert _trk_err(t.series, want) < TRK_TOL
+        else:
+            _oracle_vs_gpu(m, s, os_, x.astype(np.int8), 40)
+        err = capfd.readouterr().err
+        tm = ctx.timing()
+        assert int(tm["track_kernel"]) == kernel, (amp, kind, tm)
+        assert ("too strong for the speculative kernel" in err) == (kernel == 2), err
