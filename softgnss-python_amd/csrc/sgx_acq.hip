@@ -1974,7 +1974,7 @@ extern "C" int sgx_acquire_sharded(sgx_ctx* c, sgx_comm* comm, int32_t rank, int
         if (rg != SGX_OK) return rg;
     }
     const size_t all_bytes = rec_bytes * (size_t)n_ranks_seen;
-    if (all_bytes > SGX_LOOK_BYTES - SGX_GATHER_LOOK_OFFSET - 16) {
+    if (all_bytes > SGX_TRK_LOOK_OFFSET - SGX_GATHER_LOOK_OFFSET - 16) {
         sgx_set_error("sgx_acquire_sharded: %d ranks x %d slots do not fit the result page", world, slots);
         return SGX_E_ARG;
     }

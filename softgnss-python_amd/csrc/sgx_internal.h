@@ -109,6 +109,10 @@ static_assert(sizeof(StepLook) <= 2048, "upper half of the result page");
 // the result "page" is two pages: [0, 2048) the search's CoarseLook, [2048, 4096) StepLook, [4096, 8192) the gathered peak
 // records of sgx_acquire_sharded behind the word the host spins on
 #define SGX_GATHER_LOOK_OFFSET 4096
+// ... and [6144, 8192): what a tracking launch leaves for the host's look (sgx_trk.hip: trk_finish_kernel) - the word, the
+// two error words, ms_done of up to SGX_TRK_LOOK_CH channels
+#define SGX_TRK_LOOK_OFFSET 6144
+#define SGX_TRK_LOOK_CH 256
 #define SGX_LOOK_BYTES 8192
 
 struct sgx_ctx {
@@ -142,6 +146,7 @@ struct sgx_ctx {
     void* h_look = nullptr;      // coherent pinned page a kernel publishes the coarse search's outcome to (host spins on it)
     void* d_look = nullptr;      // its device address
     unsigned long long look_seq = 0;
+    unsigned long long trk_seq = 0;
     // tracking
     double* d_trk_out = nullptr;
     size_t trk_out_elems = 0;

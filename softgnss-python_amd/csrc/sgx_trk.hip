@@ -62,6 +62,25 @@ __global__ __launch_bounds__(256) void trk_fill_kernel(double* __restrict__ out,
     out[i] = zero ? 0.0 : __longlong_as_double(0x7FF0000000000000ll);
 }
 
+// What a tracking launch leaves for the host (round 6): the error words and every channel's ms_done, copied to the pinned
+// result page by ONE small kernel behind the tracking kernel, then the word the host spins on - instead of two copies to
+// pageable memory with a stream synchronisation each (~80 us behind every launch).
+struct TrkLook {
+    unsigned long long seq;
+    int err[2];
+    int done[SGX_TRK_LOOK_CH];
+};
+static_assert(sizeof(TrkLook) <= SGX_LOOK_BYTES - SGX_TRK_LOOK_OFFSET, "the tracking look fits its part of the page");
+__global__ __launch_bounds__(SGX_TRK_LOOK_CH) void trk_finish_kernel(const int* __restrict__ d_err, const int* __restrict__ d_done,
+                                                                     int n_ch, TrkLook* __restrict__ look, unsigned long long seq) {
+    const int t = threadIdx.x;
+    if (t < 2) look->err[t] = d_err[t];
+    if (t < n_ch) look->done[t] = d_done[t];
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(&look->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // THE SPECULATIVE KERNEL'S SCALE GUARD for resident int8 records (sgx_trk3.hip: a unit's total must stay below 2^17, and no
 // arm's total can exceed the sum of the unit's magnitudes).  One pass over the record, once per record (cached in the
 // handle): the largest sum of |x| over 17 consecutive 128-byte blocks - any 2 048-byte window of the kernel lies inside
@@ -407,6 +426,10 @@ static int track_kind_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset,
     // what the launches so far have established: the record's streaming has been tried (and stalled), a member of a
     // cooperative layout timed out (the next launch runs with one workgroup per channel)
     bool stream_tried = false, fallback_one = false, v3_off = false;
+    // the launch's error words and ms_done through the pinned page (one small kernel, the host spins) when the series go
+    // straight to the caller's pinned buffer and the channels fit the page
+    const bool fast_look = direct && n_ch <= SGX_TRK_LOOK_CH && !want_prof;
+    const TrkLook* h_look = (const TrkLook*)((const char*)c->h_look + SGX_TRK_LOOK_OFFSET);
     if (use_v3 && kind == SGX_DT_INT8 && !(r->loader && !r->load_done.load())) {
         // (resident int8 record: the scale guard is a bound computed once per record; sgx_trk3.hip says why 2^17)
         const long long mag = if_mag_bound(c, r);
@@ -513,10 +536,39 @@ static int track_kind_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset,
         c->timing.track_streamed = streaming ? 1.f : 0.f;
         e = hipGetLastError();
         int h_err2[2] = {0, 0};   // [0] flags | 1 + channel of a timeout; [1] 1 + channel of a block beyond the units
-        if (e == hipSuccess) e = hipMemcpyAsync(h_err2, d_err, 2 * sizeof(int), hipMemcpyDeviceToHost, st);
-        stamp("error word copy queued");
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        stamp("stream synchronised");
+        if (fast_look) {
+            const unsigned long long seq = ++c->trk_seq;
+            if (e == hipSuccess) {
+                trk_finish_kernel<<<1, SGX_TRK_LOOK_CH, 0, st>>>(d_err, d_done, n_ch, (TrkLook*)((char*)c->d_look + SGX_TRK_LOOK_OFFSET), seq);
+                e = hipGetLastError();
+            }
+            stamp("finish kernel queued");
+            if (e == hipSuccess) {
+                // spin (the kernel takes tens of milliseconds), then sleep in the stream synchronisation
+                const auto t0 = std::chrono::steady_clock::now();
+                bool seen = false;
+                for (unsigned sp = 0; !seen; ++sp) {
+                    if (__atomic_load_n(&h_look->seq, __ATOMIC_ACQUIRE) == seq) seen = true;
+                    else if ((sp & 4095u) == 4095u &&
+                             std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.25) break;
+                }
+                if (!seen) {
+                    e = hipStreamSynchronize(st);
+                    if (e == hipSuccess && __atomic_load_n(&h_look->seq, __ATOMIC_ACQUIRE) != seq) {
+                        sgx_set_error("tracking: the launch's result words were not written");
+                        return SGX_E_HIP;
+                    }
+                }
+                h_err2[0] = h_look->err[0];
+                h_err2[1] = h_look->err[1];
+            }
+            stamp("result words seen");
+        } else {
+            if (e == hipSuccess) e = hipMemcpyAsync(h_err2, d_err, 2 * sizeof(int), hipMemcpyDeviceToHost, st);
+            stamp("error word copy queued");
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            stamp("stream synchronised");
+        }
         h_err = h_err2[0];
         reserved.drop();
         // test hooks: treat the first launch as timed out ('1'), or the one that follows a stalled stream ('2'); treat
@@ -558,9 +610,14 @@ static int track_kind_impl(sgx_ctx* c, const sgx_if* r, int64_t rec_file_offset,
                 members_now);
         fallback_one = true;
     }
-    if (e == hipSuccess && !direct) e = hipMemcpyAsync(out, d_out, elems * sizeof(double), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(ms_done, d_done, sizeof(int) * (size_t)n_ch, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (fast_look && e == hipSuccess) {
+        for (int i = 0; i < n_ch; ++i) ms_done[i] = h_look->done[i];
+        e = hipEventSynchronize(c->ev[4]);   // (the word is stored a moment before the kernels retire: the times need the event)
+    } else {
+        if (e == hipSuccess && !direct) e = hipMemcpyAsync(out, d_out, elems * sizeof(double), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(ms_done, d_done, sizeof(int) * (size_t)n_ch, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
     stamp("ms_done copied");
     if (want_prof && e == hipSuccess) {
         std::vector<long long> hp(T2_PROF_STRIDE * (size_t)n_ch);
