@@ -983,6 +983,12 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
 #ifndef T3_SLEEP_DLL
 #define T3_SLEEP_DLL 0
 #endif
+#ifndef T3_NOP_PLL
+#define T3_NOP_PLL 0
+#endif
+#ifndef T3_NOP_DLL
+#define T3_NOP_DLL 0
+#endif
 #ifdef T3_ALIGN_POLL   // (diagnosis) the polls' loops start on a 64-byte line of the instruction cache
 #define T3_POLL_ALIGN ".p2align 6\n"
 #else
@@ -1314,6 +1320,9 @@ __device__ __forceinline__ int t3_pll_role(T3Shared& S, const TrkConst& K, const
 #if T3_SLEEP_PLL > 0
         __builtin_amdgcn_s_sleep(T3_SLEEP_PLL);    // the final pass has the SIMD to itself for a moment (see T3_SLEEP_PLL)
 #endif
+#if T3_NOP_PLL > 0
+        asm volatile(".rept " T3_STR(T3_NOP_PLL) "\n\ts_nop 3\n\t.endr");   // 16 cycles each
+#endif
         __builtin_amdgcn_s_setprio(T3_PRIO_PRE);   // what follows until the next poll is off the chain: the final pass (2) issues first,
                                          // the speculative pass (0) after it
         __builtin_amdgcn_sched_barrier(0);
@@ -1589,6 +1598,9 @@ __device__ __forceinline__ int t3_dll_role(T3Shared& S, const TrkConst& K, const
         T3_WB(wb_on);
 #if T3_SLEEP_DLL > 0
         __builtin_amdgcn_s_sleep(T3_SLEEP_DLL);
+#endif
+#if T3_NOP_DLL > 0
+        asm volatile(".rept " T3_STR(T3_NOP_DLL) "\n\ts_nop 3\n\t.endr");
 #endif
         __builtin_amdgcn_s_setprio(T3_PRIO_PRE);
         __builtin_amdgcn_sched_barrier(0);
