@@ -272,6 +272,9 @@ int sgx_track_plan(const sgx_settings* s, int32_t data_type, int32_t n_ch, int32
  * (bin_runs == 1) or one PRN's rows of bins_per_run Doppler bins (bin_runs > 1, non-coherent sums only). */
 int sgx_acquire_plan(int32_t n_prn, int32_t n_bins, int32_t n_blocks, int32_t noncoh, int32_t chunk_rows,
                      int32_t max_queues, int32_t* prn_chunk, int32_t* bin_runs, int32_t* bins_per_run, int32_t* queues);
+/* The two constants behind that rule: the default chunk size (rows; SGX_ACQ_CHUNK_ROWS overrides it) and the largest batch
+ * of rows one launch takes. */
+int sgx_acquire_plan_limits(int32_t* default_chunk_rows, int32_t* max_rows);
 
 /* Measured HBM rates of this device for the roofline report (no reference counterpart): a read-only stream and a
  * copy (read + write bytes counted) over `bytes` of device memory, `reps` timed launches each, GB/s. */

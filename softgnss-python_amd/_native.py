@@ -97,6 +97,7 @@ _PROTOS = {
     "sgx_track_ex": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32]),
     "sgx_track_plan": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "sgx_acquire_plan": (C.c_int, [C.c_int32] * 6 + [C.POINTER(C.c_int32)] * 4),
+    "sgx_acquire_plan_limits": (C.c_int, [C.POINTER(C.c_int32)] * 2),
     "sgx_stream_rates": (C.c_int, [_P, C.c_size_t, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "sgx_probe_stats": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, C.c_double, _P, _P, _P, C.POINTER(C.c_int32)]),
     "sgx_find_preambles": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
@@ -185,6 +186,13 @@ def acquire_plan(n_prn=32, n_bins=29, n_blocks=2, noncoh=False, chunk_rows=0, ma
     check(lib().sgx_acquire_plan(int(n_prn), int(n_bins), int(n_blocks), 1 if noncoh else 0, int(chunk_rows), int(max_queues),
                                  *[C.byref(x) for x in v]))
     return tuple(x.value for x in v)
+
+
+def acquire_plan_limits():
+    """(default chunk rows, largest batch of rows per launch) of csrc/sgx_acq.hip's chunk rule."""
+    a, b = C.c_int32(0), C.c_int32(0)
+    check(lib().sgx_acquire_plan_limits(C.byref(a), C.byref(b)))
+    return a.value, b.value
 
 
 def scene_struct(scene):

@@ -41,6 +41,11 @@ class AcquisitionResult(Result):
         self._internals = value
 
     def _materialize(self):
+        merged = getattr(self, "_merged", None)
+        if merged is not None:
+            self._merged = None
+            self._results = np.rec.fromarrays([merged["carrFreq"], merged["codePhase"], merged["peakMetric"]],
+                                              names='carrFreq,codePhase,peakMetric')
         if self._pending is not None:
             ctx, prn_indices, token = self._pending
             self._pending = None
@@ -96,6 +101,7 @@ class AcquisitionResult(Result):
                     raise TypeError("longSignal must be real-valued")
                 f64 = arr.astype(np.float64)
         self._prerun_pending = False
+        self._merged = None
         if self._deferred and f64 is None and own is None and not self._verbose:
             token = ctx.acquire_begin(rec, off, n, prn_indices, n_blocks=n_blocks, noncoh=noncoh)
             self._pending = (ctx, prn_indices, token)
@@ -121,8 +127,8 @@ class AcquisitionResult(Result):
         self._pending = None
         self._prerun_pending = False
         self._internals = dict(freqBin=r["freqBin"], fineIdx=r["fineIdx"])
-        self._results = np.rec.fromarrays([r["carrFreq"], r["codePhase"], r["peakMetric"]],
-                                          names='carrFreq,codePhase,peakMetric')
+        self._results = None
+        self._merged = r               # the record array (acquisition.py:201-203) is packed on first access
 
     def _fill(self, prn_indices, r):
         """The reference's three 32-entry result arrays (acquisition.py:201-203) from the library's per-PRN outputs."""
@@ -153,7 +159,7 @@ class AcquisitionResult(Result):
         plt = _pyplot("AcquisitionResult.plot")
         if plt is None:
             return
-        assert isinstance(self._results, np.recarray)
+        assert isinstance(self.results, np.recarray)
         plt.figure(101)
         plt.clf()
         prn = np.arange(1, len(self.peakMetric) + 1)
@@ -186,7 +192,7 @@ class AcquisitionResult(Result):
                                            names='PRN,acquiredFreq,codePhase,status')
 
     def _prerun_host(self):
-        assert isinstance(self._results, np.recarray)
+        assert isinstance(self.results, np.recarray)
         settings = self._settings
         nch = int(settings.numberOfChannels)
         PRN = np.zeros(nch, dtype='int64')

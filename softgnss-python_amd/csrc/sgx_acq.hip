@@ -18,6 +18,7 @@
 
 #define ACQ_MAX_BINS 128
 #define ACQ_MAX_ROWS 2048
+#define ACQ_DEFAULT_CHUNK_ROWS 348   // correlation rows per chunk (the intermediate then stays in the Infinity Cache)
 
 struct MixArgs {
     double frq[ACQ_MAX_BINS];
@@ -1274,11 +1275,18 @@ extern "C" int sgx_acquire_plan(int32_t n_prn, int32_t n_bins, int32_t n_blocks,
                                 int32_t max_queues, int32_t* prn_chunk, int32_t* bin_runs, int32_t* bins_per_run,
                                 int32_t* queues) {
     SGX_CHECK_ARG(n_prn >= 1 && n_bins >= 1 && n_blocks >= 1 && prn_chunk && bin_runs && bins_per_run && queues);
-    const AcqPlan p = acq_plan(n_prn, n_bins, n_blocks, noncoh != 0, chunk_rows > 0 ? chunk_rows : 348, max_queues);
+    const AcqPlan p = acq_plan(n_prn, n_bins, n_blocks, noncoh != 0, chunk_rows > 0 ? chunk_rows : ACQ_DEFAULT_CHUNK_ROWS, max_queues);
     *prn_chunk = p.prn_chunk;
     *bin_runs = p.bin_runs;
     *bins_per_run = p.bins_per_run;
     *queues = p.queues;
+    return SGX_OK;
+}
+
+extern "C" int sgx_acquire_plan_limits(int32_t* default_chunk_rows, int32_t* max_rows) {
+    SGX_CHECK_ARG(default_chunk_rows && max_rows);
+    *default_chunk_rows = ACQ_DEFAULT_CHUNK_ROWS;
+    *max_rows = ACQ_MAX_ROWS;
     return SGX_OK;
 }
 
@@ -1339,7 +1347,7 @@ static int acquire_four_step(sgx_ctx* c, SgxSig x, size_t n_samples, const int32
     // round-3 kernels - bound by their stores and by the dirty lines on their way out, not by instruction issue or LDS
     // any more - that is 0.94 -> 0.80 ms for config 2 and 3.43 -> 3.24 ms for config 4 (tools/acq_chunk_probe.py; the
     // round-2 kernels measured no difference).
-    int chunk_rows = 348;
+    int chunk_rows = ACQ_DEFAULT_CHUNK_ROWS;
     {
         const char* ce = getenv("SGX_ACQ_CHUNK_ROWS");
         if (ce && atoi(ce) > 0) chunk_rows = atoi(ce);

@@ -42,6 +42,7 @@ class Result(object):
     @results.setter
     def results(self, records):
         assert isinstance(records, np.recarray)
+        self._merged = None        # (AcquisitionResult: arrays of a sharded search not yet packed)
         self._results = records
 
     def plot(self):

@@ -621,6 +621,8 @@ def test_acquisition_chunk_plan_covers_every_row_exactly_once():
     one chunk, a chunk of bin runs holds ONE PRN (round 5: with two it wrote the second PRN's maxima to the first one's
     slots), a queue's chunk fits its share of the chunk size, and two queues are only used where there are two chunks."""
     m = pkg()
+    default_rows, max_rows = m._native.acquire_plan_limits()     # (the library's own constants, not copies of them)
+    assert 1 <= default_rows <= max_rows
     for n_prn in (1, 2, 4, 7, 32):
         for n_bins in (1, 2, 29, 57):
             for n_blocks, noncoh in ((1, False), (2, False), (10, True), (3, True), (1, True)):
@@ -642,7 +644,7 @@ def test_acquisition_chunk_plan_covers_every_row_exactly_once():
                                     for b in range(b0, b0 + nb):
                                         seen[(p, b)] = seen.get((p, b), 0) + 1
                                 rows = min(prn_chunk, n_prn - p0) * nb * n_blocks
-                                limit = min(chunk_rows if chunk_rows > 0 else 348, 2048)
+                                limit = min(chunk_rows if chunk_rows > 0 else default_rows, max_rows)
                                 if rows > n_bins * n_blocks or bin_runs > 1:       # (more than one PRN, or a part of one)
                                     assert rows <= max(limit // queues, 1) + (n_blocks * bins_per_run if bin_runs > 1 else 0), what
                         assert len(seen) == n_prn * n_bins and set(seen.values()) == {1}, what
