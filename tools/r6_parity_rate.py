@@ -51,13 +51,14 @@ def nearest_boundary(rem, cf):
 def main():
     n_random = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    only = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else None   # (just these seeds, no default scene)
     ms = 37000
     m = importlib.import_module("softgnss-python_amd")
     s = m.Settings()
     s.msToProcess = float(ms)
     ctx = m.engine.get_context(s, 0)
     n = s.samplesPerCode
-    for seed in [None] + list(range(seed0, seed0 + n_random)):
+    for seed in (only if only else [None] + list(range(seed0, seed0 + n_random))):
         scene = m.synth.Scene.default() if seed is None else random_scene(m, seed)
         rec = ctx.synth(scene, m.synth.record_length(n, ms))
         a = m.AcquisitionResult(s, device=0)
@@ -90,7 +91,10 @@ def main():
                     dist, arm, i = nearest_boundary(rem, cf)
                     pos0 = int(want[ch, 0, j - 1]) if j else int(want[ch, 0, 0] - 38192)
                     x = int(host[pos0 + i]) if i is not None else 0
-                    d.update(blip_abs=float(np.max(np.abs(got[ch, 3:9, j] - want[ch, 3:9, j]))), sample_value=x,
+                    after = {str(o): float(rel[j + o]) for o in (1, 2, 5, 10, 50, 100, 500, 1000, 5000) if j + o < ms}
+                    d.update(rel_err_at_blip=float(rel[j]), rel_err_blocks_after=after, rel_err_max_last_1000=float(rel[-1000:].max()),
+                             code_freq_diff_after_Hz={str(o): float(abs(got[ch, 1, j + o] - want[ch, 1, j + o])) for o in (1, 100, 1000) if j + o < ms},
+                             blip_abs=float(np.max(np.abs(got[ch, 3:9, j] - want[ch, 3:9, j]))), sample_value=x,
                              nearest_sample_to_a_chip_boundary_chips=dist, arm=arm, sample_index_in_block=i,
                              max_rel_err_before_blip=float(rel[:j].max()) if j else 0.0)
                 out["divergences"].append(d)
