@@ -2080,3 +2080,29 @@ def test_a_record_too_strong_for_the_speculative_kernel_is_tracked_by_the_round_
         tm = ctx.timing()
         assert int(tm["track_kernel"]) == kernel, (amp, kind, tm)
         assert ("too strong for the speculative kernel" in err) == (kernel == 2), err
+
+
+def test_deferred_step_on_a_short_record_leaves_the_results_unset(default_record):
+    """The reference's short-read exit (tracking.py:159-163: message, fid.close(), results NOT set) through the queued
+    sequence: the chained launch reports the blocks it completed, the eager one the same."""
+    gs = load_golden("trk_short.npz")
+    m = pkg()
+    s = m.Settings()
+    s.numberOfChannels = 4
+    s.msToProcess = 400.0
+    ctx = m.engine.get_context(s, 0)
+    rec = ctx.upload(default_record[:int(gs["n_samples"])])
+    outs = []
+    for deferred in (False, True):
+        a = m.AcquisitionResult(s, device=0, deferred=deferred)
+        a.acquire(m.DeviceSignal(rec, 0, 11 * s.samplesPerCode))
+        a.preRun()
+        t = m.TrackingResult(a, device=0)
+        fid = m.DeviceFile(rec)
+        ret = t.track(fid)
+        assert ret is None and fid.closed and not t.has_results() and t.chained == deferred
+        with pytest.raises(AssertionError):
+            t.results
+        outs.append(np.array(a.channels.PRN))
+    assert np.array_equal(outs[0], outs[1])
+    rec.free()
