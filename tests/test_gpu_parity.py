@@ -2106,3 +2106,32 @@ def test_deferred_step_on_a_short_record_leaves_the_results_unset(default_record
         outs.append(np.array(a.channels.PRN))
     assert np.array_equal(outs[0], outs[1])
     rec.free()
+
+
+def test_sharded_search_reports_the_references_index_error_from_the_rank_that_met_it():
+    """sgx_acquire_sharded marks the record of a PRN whose coarse code phase equals the samples per chip (the reference's
+    IndexError, acquisition.py:152-162): the rank whose share holds it raises - and, through the gather, so would every other
+    rank; a rank whose share does not hold it, run alone, finishes."""
+    g = load_golden("acq_edges.npz")
+    m = pkg()
+    sh = pkg("shard")
+    s = m.Settings()
+    ctx = m.engine.get_context(s, 0)
+    i = [k for k in range(len(g["phases"])) if str(g["err"][k]) == "IndexError"][0]
+    x = m.synth.generate(scene_from_json(g["scenes"][i]), 11 * s.samplesPerCode)     # PRN 1 at code phase 37
+    rec = ctx.upload(x)
+    sig = m.DeviceSignal(rec, 0, 11 * s.samplesPerCode)
+    a = m.AcquisitionResult(s, device=0)
+    with pytest.raises(IndexError):
+        sh.acquire_sharded(a, sig, 0, 8, sh.LocalGather())        # PRN indices 0..3: the failing one is here
+    b = m.AcquisitionResult(s, device=0)
+    sh.acquire_sharded(b, sig, 3, 8, sh.LocalGather())            # PRN indices 12..15
+    assert not np.any(b.carrFreq)
+    comm = m._native.Comm(ctx, 1, 0, m._native.Comm.unique_id())
+    try:
+        c = m.AcquisitionResult(s, device=0)
+        with pytest.raises(IndexError):
+            sh.acquire_sharded(c, sig, 0, 1, sh.RcclGather(comm))  # ... and through a real (one-rank) gather
+    finally:
+        comm.close()
+    rec.free()
