@@ -41,7 +41,9 @@ void sgx_trk3_launch(int n_blocks, hipStream_t st, const int8_t* rec, const int8
                      int lds_pad);
 #define T3_LANES 128
 #define T3_MAXP 32
+#ifndef T3_XCH_STRIDE
 #define T3_XCH_STRIDE 512   // (as in sgx_trk3.hip)
+#endif
 
 // sgx_trk_multi.hip: the cooperative kernel with a per-sample replica lookup, for low sampling rates
 void sgx_trk_multi_launch(int n_blocks, hipStream_t st, const int8_t* rec, const int8_t* codes, const TrkChan* chans,

@@ -69,7 +69,9 @@
 #endif
 #define T3_XABORT (12 * T3_XLINE)
 #define T3_XPLACE (12 * T3_XLINE + 8)
+#ifndef T3_XCH_STRIDE
 #define T3_XCH_STRIDE 512          // words per channel (sgx_trk.hip sizes the allocation with the same figure)
+#endif
 // Fixed-point scale of a granule's 48-bit payload: 2^30 (sgx_trk2.hip: 2^28).  A lane's six sums are rounded to it before
 // the order-free integer reductions, 2 387 lanes x 20 units of them per block: at 2^28 that rounding was the largest
 // difference between this kernel's sums and the reference's own (9e-13 relative against 4e-13 from the reference's carrier
