@@ -28,6 +28,7 @@ class AcquisitionResult(Result):
         self._deferred = bool(deferred)
         self._pending = None           # (context, PRN indices) of a queued search nobody has looked at
         self._prerun_pending = False   # preRun() was called while the search was still queued
+        self._merged = None            # arrays of a sharded search (sgx_acquire_sharded) not yet packed into .results
         self._internals = None
 
     @property
@@ -41,7 +42,7 @@ class AcquisitionResult(Result):
         self._internals = value
 
     def _materialize(self):
-        merged = getattr(self, "_merged", None)
+        merged = self._merged
         if merged is not None:
             self._merged = None
             self._results = np.rec.fromarrays([merged["carrFreq"], merged["codePhase"], merged["peakMetric"]],

@@ -18,6 +18,7 @@ class Result(object):
         self._settings = settings
         self._results = None
         self._channels = None
+        self._merged = None
 
     @property
     def settings(self):
