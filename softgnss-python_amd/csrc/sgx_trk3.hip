@@ -60,6 +60,8 @@
 #ifndef T3_PRIO_PRE
 #define T3_PRIO_PRE 1
 #endif
+#define T3_STR2(x) #x
+#define T3_STR(x) T3_STR2(x)
 #define T3_LANES 128               // map lanes = groups per unit (two waves)
 #define T3_UNIT (T3_LANES * 16)    // samples per unit
 #define T3_THREADS 448             // 2 x 2 map waves (two SETS, alternating blocks) + PLL wave (4) + DLL wave (5) + record wave (6)
@@ -938,6 +940,9 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
             pend_b = true;
         }
         } else if (pend_b) {
+#if T3_NOP_SPEC > 0
+            asm volatile(".rept " T3_STR(T3_NOP_SPEC) "\n\ts_nop 3\n\t.endr");   // (diagnosis) part B starts 16 cycles later each
+#endif
             // ======== part B of that pass: the table is the one part A ran with - the block before this one's
             spec_b(S.carr[par ^ 1], true);
             pend_b = false;
@@ -991,13 +996,17 @@ __device__ __forceinline__ int t3_map_role(T3Shared& S, const int8_t* __restrict
 #ifndef T3_NOP_DLL
 #define T3_NOP_DLL 0
 #endif
+#ifndef T3_NOP_SPEC
+#define T3_NOP_SPEC 0
+#endif
+#ifndef T3_NOP_REC
+#define T3_NOP_REC 0
+#endif
 #ifdef T3_ALIGN_POLL   // (diagnosis) the polls' loops start on a 64-byte line of the instruction cache
 #define T3_POLL_ALIGN ".p2align 6\n"
 #else
 #define T3_POLL_ALIGN
 #endif
-#define T3_STR2(x) #x
-#define T3_STR(x) T3_STR2(x)
 __device__ __forceinline__ int t3_poll1(unsigned long long& x, const unsigned long long* p, unsigned long long tag, int rounds) {
     unsigned long long t;
     int left;
@@ -1676,6 +1685,9 @@ __device__ __forceinline__ int t3_rec_role(T3Shared& S, const TrkConst& K, const
         const int par = it & 1;
         const T3Code& C = S.code[par];
         if (C.stop) break;
+#if T3_NOP_REC > 0
+        asm volatile(".rept " T3_STR(T3_NOP_REC) "\n\ts_nop 3\n\t.endr");   // (diagnosis) the far prefetch leaves 16 cycles later each
+#endif
         if (lane < 20) {
             long long a = ((C.pos + 6ll * C.blk) & ~127ll) + (long long)unit * T3_UNIT + 128ll * (lane - 1);
             a = a < 0 ? 0 : (a > limit ? limit : a);
